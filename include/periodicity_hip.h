@@ -1,0 +1,140 @@
+/*
+ * periodicity_hip.h — C ABI of libperiodicity_hip.so: MI355X (gfx950) trial-frequency scans.
+ *
+ * The reference (dioph/periodicity) is pure Python and has no FFI of its own; the boundary a
+ * native replacement slots into is its callable API plus three private seams.
+ * Each entry point below names the reference interface it replaces
+ * (paths relative to /root/reference/src/periodicity/).  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - fp64 only; every array is C-contiguous; sizes are int64_t.
+ *   - Functions return 0 on success, a negative pdc_status otherwise; the message of the last
+ *     failure on the calling thread is available from pdc_last_error().
+ *   - "host" entry points take host pointers: the caller owns every buffer, the library copies
+ *     H2D/D2H itself, keeps no host pointer after return and caches its device workspace per
+ *     device (freed by pdc_release()).
+ *   - "_dev" entry points take device pointers on `device` and enqueue on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream).  They do not synchronise.
+ *   - NaN/Inf in the data are not errors: IEEE results propagate exactly as in numpy
+ *     (spectral.py:113-128 has no guards).
+ *   - No C++ exception crosses this boundary.
+ */
+#ifndef PERIODICITY_HIP_H
+#define PERIODICITY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pdc_status {
+    PDC_OK = 0,
+    PDC_ERR_INVALID = -1,   /* bad argument (NULL, negative size, incompatible lengths) -> ValueError */
+    PDC_ERR_NODEVICE = -2,  /* no usable gfx950 device                                 -> RuntimeError */
+    PDC_ERR_HIP = -3,       /* a HIP runtime call failed                               -> RuntimeError */
+    PDC_ERR_RCCL = -4,      /* an RCCL call failed                                     -> RuntimeError */
+    PDC_ERR_NOMEM = -5      /* device or host allocation failed                        -> MemoryError  */
+} pdc_status;
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+const char *pdc_last_error(void);
+int pdc_version(void);                                   /* 100*major + minor */
+int pdc_device_count(int *count);
+int pdc_device_info(int device, char *name, int name_len, int *cu_count, int64_t *hbm_bytes,
+                    int *clock_khz);
+int pdc_release(void);                                   /* free all cached device workspaces */
+
+/* device memory + events for callers that keep data resident (bench.py, tests) */
+int pdc_malloc(int device, int64_t bytes, void **dptr);
+int pdc_free(int device, void *dptr);
+int pdc_memcpy_h2d(int device, void *dst, const void *src, int64_t bytes);
+int pdc_memcpy_d2h(int device, void *dst, const void *src, int64_t bytes);
+int pdc_memset(int device, void *dst, int value, int64_t bytes);
+int pdc_stream_create(int device, void **stream);
+int pdc_stream_destroy(int device, void *stream);
+int pdc_stream_sync(int device, void *stream);
+int pdc_device_sync(int device);
+int pdc_event_create(int device, void **event);
+int pdc_event_destroy(int device, void *event);
+int pdc_event_record(int device, void *event, void *stream);
+int pdc_event_elapsed_ms(int device, void *start, void *stop, float *ms);  /* syncs on stop */
+
+/* ---- generalized Lomb-Scargle --------------------------------------------------------------
+ * Replaces GLS.__call__ from the weights onward (spectral.py:99-132): w = dy^-2 / sum(dy^-2)
+ * (dy == NULL -> ones, :99-103), y centred by the weighted mean when fit_mean (:105-108), the
+ * three _trig_sum calls (:109-112) evaluated as exact direct sums, and the fused epilogue
+ * (:113-132).  The grid is the one np.arange(fmin, fmax + df, df) produced on the host (:97):
+ * frequency[j] = f0 + j*delta with f0 = frequency[0], delta = frequency[1] - frequency[0]
+ * (numpy's own fill rule), j = j_begin .. j_begin + nf - 1; power_out[0..nf) receives that slab.
+ */
+int pdc_gls_scan(const double *t, const double *y, const double *dy, int64_t n,
+                 double f0, double delta, int64_t j_begin, int64_t nf,
+                 int fit_mean, int psd, double *power_out, int device);
+
+/* Batch of independent light curves on one shared grid (the shape of GLS.bootstrap,
+ * spectral.py:140-152, when shared_t != 0: one time axis, B resampled (y, dy) rows).
+ * Curve b occupies [offsets[b], offsets[b+1]) of y/dy (and of t unless shared_t, in which case
+ * t has offsets[1]-offsets[0] entries and every curve must have that length).
+ * power_out is [B][nf] or NULL; amax_out / argmax_out are [B] or NULL and receive the NaN-aware
+ * maximum and its index (Signal.amax / argmax, core.py:202-215), computed on the device. */
+int pdc_gls_scan_batch(const double *t, const double *y, const double *dy,
+                       const int64_t *offsets, int64_t n_curves, int shared_t,
+                       double f0, double delta, int64_t j_begin, int64_t nf,
+                       int fit_mean, int psd,
+                       double *power_out, double *amax_out, int64_t *argmax_out, int device);
+
+/* One periodogram with the grid split into contiguous equal slabs over `n_devices` GPUs of this
+ * node (one process, one stream per device), gathered with one RCCL all-gather over xGMI. */
+int pdc_gls_scan_multi(const double *t, const double *y, const double *dy, int64_t n,
+                       double f0, double delta, int64_t nf, int fit_mean, int psd,
+                       double *power_out, const int *devices, int n_devices);
+
+/* Seam-level: replaces _trig_sum(t, w, df, nf, fmin) (spectral.py:11-40) by what its docstring
+ * defines (:13-15): S_j = sum_i w_i sin(2 pi f_j t_i), C_j = sum_i w_i cos(2 pi f_j t_i),
+ * f_j = f0 + j*delta. */
+int pdc_trig_sums(const double *t, const double *w, int64_t n,
+                  double f0, double delta, int64_t nf,
+                  double *S_out, double *C_out, int device);
+
+/* Device-resident form used by bench.py: inputs already in HBM, no synchronisation.
+ * `work` is scratch of at least pdc_gls_work_bytes(n_total, n_curves, nf) bytes on the same
+ * device.  d_offsets may be NULL for a single curve of n_total samples. */
+int64_t pdc_gls_work_bytes(int64_t n_total, int64_t n_curves, int64_t nf);
+int pdc_gls_scan_dev(int device, void *stream,
+                     const double *d_t, const double *d_y, const double *d_dy,
+                     const int64_t *d_offsets, int64_t n_total, int64_t n_curves, int shared_t,
+                     double f0, double delta, int64_t j_begin, int64_t nf,
+                     int fit_mean, int psd,
+                     double *d_power, double *d_amax, int64_t *d_argmax,
+                     void *work, int64_t work_bytes);
+
+/* ---- Phase Dispersion Minimization -----------------------------------------------------------
+ * Replaces pool.map(PDM._pdm, periods) (phase.py:128-149, 185-187): theta_out[p] for every trial
+ * period, bins phi in [k/m0, (k+nc)/m0) U [0, (k+nc-m0)/m0), m0 = nb*nc, phi = (t/period) % 1
+ * with IEEE division and Python modulo; sigma = var(x, ddof=1) is the caller's (phase.py:165). */
+int pdc_pdm_scan(const double *t, const double *x, int64_t n,
+                 const double *periods, int64_t n_periods, int nb, int nc, double sigma,
+                 double *theta_out, int device);
+int pdc_pdm_scan_dev(int device, void *stream, const double *d_t, const double *d_x, int64_t n,
+                     const double *d_periods, int64_t n_periods, int nb, int nc, double sigma,
+                     double *d_theta);
+
+/* ---- String Length -----------------------------------------------------------------------------
+ * Replaces pool.map(StringLength._stringlength, periods) (phase.py:45-51, 69-70) including the
+ * fold ((t - 0)/period) % 1 (core.py:543-544) and the stable sort by phase of the TSeries
+ * constructor (core.py:473-477); the closing segment is not phase-wrapped. `m` is the scaled
+ * signal of phase.py:65-66. */
+int pdc_stringlength_scan(const double *t, const double *m, int64_t n,
+                          const double *periods, int64_t n_periods,
+                          double *ell_out, int device);
+int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods);
+int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
+                              int64_t n, const double *d_periods, int64_t n_periods,
+                              double *d_ell, void *work, int64_t work_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PERIODICITY_HIP_H */

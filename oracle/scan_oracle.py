@@ -1,0 +1,286 @@
+"""TEST INFRASTRUCTURE — CPU restatement (numpy) of the reference's trial-frequency scans.
+
+This is the *oracle*: the checker the HIP path is compared with.  It is never the product
+path; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import it.
+
+Every function names the reference lines it restates (paths relative to
+``/root/reference/src/periodicity/``).  Pinning: ``tests/test_oracle_vs_reference.py`` runs
+each function against the reference's own source (loaded by ``oracle/refstub.py``) in the
+build container, and ``tests/test_oracle_golden.py`` checks it against the vectors under
+``tests/golden/`` (generated from the reference by ``tests/golden/make_golden.py``),
+including the two known-answer tests of ``/root/reference/tests/test_spectral.py``.
+
+Two flavours of the Lomb-Scargle trig sums exist because the reference itself is an
+approximation:
+
+* ``trig_sum_fft``   — the Press-Rybicki extirpolation + FFT the reference executes
+                       (``spectral.py:11-40``); reproduces ``power_ref`` ("Tier R").
+* ``trig_sum_exact`` — the sums that function's docstring *defines* (``spectral.py:13-15``)
+                       evaluated directly in 80-bit ``np.longdouble`` ("Tier E", the
+                       <=1e-6 gate for the direct-sum HIP kernel).
+"""
+import numpy as np
+
+# 2*pi to the full 64-bit mantissa (np.pi is only a double)
+TWO_PI_L = np.longdouble(2) * np.arctan2(np.longdouble(0), np.longdouble(-1))
+
+
+# ------------------------------------------------------------------------------------------
+# Grid rules
+# ------------------------------------------------------------------------------------------
+def gls_grid(time, n=5, fmin=None, fmax=None):
+    """Frequency grid of ``GLS.__call__`` (``spectral.py:88-98``).
+
+    Returns ``(frequency, df, fmin)``; ``frequency`` is produced by ``np.arange`` itself so
+    its length and every value carry numpy's own rounding.
+    """
+    time = np.asarray(time)
+    baseline = time[-1] - time[0]
+    df = 1.0 / baseline / n
+    if fmin is None:
+        fmin = 0.5 * df
+    if fmax is None:
+        fmax = 0.5 / np.median(np.diff(time))
+    return np.arange(fmin, fmax + df, df), df, fmin
+
+
+def stringlength_periods(baseline, dphi=0.1, n_periods=1000):
+    """Trial periods of ``StringLength.__call__`` (``phase.py:67-68``): uniform in frequency."""
+    df = dphi / baseline
+    return 1 / np.linspace(n_periods * df, df, n_periods)
+
+
+def stringlength_scale(values):
+    """Scaling to [-0.25, +0.25] stated at ``phase.py:65-66`` (NaN-aware max/min,
+    ``core.py:202-240``)."""
+    vmax, vmin = np.nanmax(values), np.nanmin(values)
+    return (values - vmax) / (2 * (vmax - vmin)) + 0.25
+
+
+def pdm_periods(time, p_min=None, p_max=None, n_periods=1000, oversample=1):
+    """Trial periods of ``PDM.__call__`` (``phase.py:167-180``): uniform in period."""
+    time = np.asarray(time)
+    t0 = time[-1] - time[0]
+    if p_min is None:
+        p_min = 2 * np.median(np.diff(time))
+    if p_max is None:
+        p_max = oversample * t0
+    if n_periods is None:
+        n_periods = int((1 / p_min - 1 / p_max) * oversample * t0 + 1)
+    return np.linspace(p_min, p_max, n_periods), p_min, p_max
+
+
+# ------------------------------------------------------------------------------------------
+# Lomb-Scargle trig sums
+# ------------------------------------------------------------------------------------------
+def trig_sum_fft(t, h, df, nf, fmin, oversampling=5):
+    """``S_j, C_j = sum_i h_i {sin,cos}(2 pi (fmin + j df) t_i)`` by extirpolation + inverse FFT.
+
+    Restates ``_trig_sum`` (``spectral.py:11-40``): grid length ``2**ceil(log2(5 nf))`` (:18),
+    weights pre-rotated to ``fmin`` about ``tmin`` (:19-20), sample positions in grid units
+    (:21), exact hits deposited whole (:23-24), all others spread over four neighbours with
+    cubic Lagrange weights (:26-33), ``ifft`` truncated to ``nf`` (:34), the ``tmin`` shift
+    undone (:35-37) and scaled by the grid length (:38-39).
+    """
+    t = np.asarray(t, dtype=float)
+    nfft = 1 << int(nf * oversampling - 1).bit_length()
+    tmin = t.min()
+    hc = h * np.exp(2j * np.pi * fmin * (t - tmin))
+    pos = ((t - tmin) * nfft * df) % nfft
+    grid = np.zeros(nfft, dtype=hc.dtype)
+    whole = pos % 1 == 0
+    np.add.at(grid, pos[whole].astype(int), hc[whole])
+    pos, hc = pos[~whole], hc[~whole]
+    lo = np.clip((pos - 2).astype(int), 0, nfft - 4)
+    x = pos - lo                                   # in (0, 4): offset from the first node
+    full = hc * (x * (x - 1) * (x - 2) * (x - 3))   # prod over all four nodes
+    # Lagrange basis l_m(x) = full / ((x - m) * prod_{k != m}(m - k)); the constants are
+    # -6, 2, -2, 6 for m = 0..3 (the reference walks them from m = 3 down: 6, -2, 2, -6).
+    for m, const in ((3, 6.0), (2, -2.0), (1, 2.0), (0, -6.0)):
+        np.add.at(grid, lo + m, full / (const * (pos - (lo + m))))
+    spec = np.fft.ifft(grid)[:nf]
+    if tmin != 0:
+        spec = spec * np.exp(2j * np.pi * tmin * (fmin + df * np.arange(nf)))
+    return nfft * spec.imag, nfft * spec.real
+
+
+def trig_sum_exact(t, h, frequency, chunk=1 << 14):
+    """The sums ``spectral.py:13-15`` defines, evaluated directly in 80-bit long double at the
+    given grid frequencies.  O(N nf): for fixtures and small parity cases only."""
+    tl = np.asarray(t, dtype=np.longdouble)
+    hl = np.asarray(h, dtype=np.longdouble)
+    fl = np.asarray(frequency, dtype=np.longdouble)
+    S = np.empty(fl.size, dtype=np.longdouble)
+    C = np.empty(fl.size, dtype=np.longdouble)
+    step = max(1, chunk * 64 // max(1, tl.size))
+    for a in range(0, fl.size, step):
+        ph = TWO_PI_L * np.outer(fl[a:a + step], tl)
+        S[a:a + step] = np.sin(ph) @ hl
+        C[a:a + step] = np.cos(ph) @ hl
+    return S.astype(float), C.astype(float)
+
+
+def gls_weights(values, err=None, fit_mean=True):
+    """Prologue of ``GLS.__call__`` (``spectral.py:99-108``): ``w``, centred ``y``, ``err``."""
+    values = np.asarray(values)
+    if err is None:
+        err = np.ones_like(values)
+    w = err ** -2.0
+    w /= w.sum()
+    y = values - np.dot(w, values) if fit_mean else values
+    return w, y, err
+
+
+def gls_epilogue(Sh, Ch, S2, C2, S, C, YY, fit_mean=True, psd=False, err=None):
+    """Elementwise epilogue of ``GLS.__call__`` (``spectral.py:111-132``)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if fit_mean:
+            tan2 = (S2 - 2 * S * C) / (C2 - (C * C - S * S))
+        else:
+            tan2 = S2 / C2
+        norm = np.sqrt(1 + tan2 * tan2)
+        S2w = tan2 / norm
+        C2w = 1 / norm
+        Cw = np.sqrt(0.5) * np.sqrt(1 + C2w)
+        Sw = np.sqrt(0.5) * np.sign(S2w) * np.sqrt(1 - C2w)
+        YC = Ch * Cw + Sh * Sw
+        YS = Sh * Cw - Ch * Sw
+        CC = 0.5 * (1 + C2 * C2w + S2 * S2w)
+        SS = 0.5 * (1 - C2 * C2w - S2 * S2w)
+        if fit_mean:
+            CC -= (C * Cw + S * Sw) ** 2
+            SS -= (S * Cw - C * Sw) ** 2
+        power = YC * YC / CC + YS * YS / SS
+        if psd:
+            power *= 0.5 * (err ** -2.0).sum()
+        else:
+            power /= YY
+    return power
+
+
+def gls_power(t, values, err, frequency, df, fmin, fit_mean=True, psd=False, sums="fft"):
+    """Periodogram of ``GLS.__call__`` (``spectral.py:99-132``) on a given grid.
+
+    ``sums="fft"`` follows the reference to the letter (three ``_trig_sum`` calls at
+    ``spectral.py:109-112``); ``sums="exact"`` swaps in the long-double direct sums.
+    """
+    t = np.asarray(t)
+    nf = frequency.size
+    w, y, err = gls_weights(values, err, fit_mean)
+    if sums == "fft":
+        Sh, Ch = trig_sum_fft(t, w * y, df, nf, fmin)
+        S2, C2 = trig_sum_fft(t, w, 2 * df, nf, 2 * fmin)
+        S, C = trig_sum_fft(t, w, df, nf, fmin) if fit_mean else (None, None)
+    elif sums == "exact":
+        Sh, Ch = trig_sum_exact(t, w * y, frequency)
+        S2, C2 = trig_sum_exact(t, w, 2 * np.asarray(frequency, dtype=np.longdouble))
+        S, C = trig_sum_exact(t, w, frequency) if fit_mean else (None, None)
+    else:
+        raise ValueError(sums)
+    YY = np.dot(w, y ** 2)
+    return gls_epilogue(Sh, Ch, S2, C2, S, C, YY, fit_mean, psd, err)
+
+
+def gls(time, values, err=None, fit_mean=True, n=5, fmin=None, fmax=None, psd=False,
+        sums="fft"):
+    """``GLS(fmin, fmax, n, psd)(TSeries(time, values), err, fit_mean)`` → (frequency, power)."""
+    frequency, df, f0 = gls_grid(time, n, fmin, fmax)
+    return frequency, gls_power(time, values, err, frequency, df, f0, fit_mean, psd, sums)
+
+
+def gls_bootstrap_maxima(time, values, err, n_bootstraps, random_seed=None, sums="fft", **grid):
+    """Replicate maxima of ``GLS.bootstrap`` (``spectral.py:140-152``): resample ``(y, err)``
+    jointly with replacement on the unchanged time axis; keep the NaN-aware maximum."""
+    rng = np.random.default_rng(random_seed)
+    values = np.asarray(values)
+    err = np.ones_like(values) if err is None else np.asarray(err)
+    frequency, df, f0 = gls_grid(time, grid.get("n", 5), grid.get("fmin"), grid.get("fmax"))
+    out = np.empty(n_bootstraps)
+    for i in range(n_bootstraps):
+        pick = rng.integers(0, values.size, values.size)
+        out[i] = np.nanmax(gls_power(time, values[pick], err[pick], frequency, df, f0,
+                                     True, grid.get("psd", False), sums))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# Phase-folding scans
+# ------------------------------------------------------------------------------------------
+def pdm_theta(t, x, period, nb=5, nc=2, sigma=None):
+    """Stellingwerf's theta for one trial period (``PDM._pdm``, ``phase.py:128-149``)."""
+    if sigma is None:
+        sigma = np.var(x, ddof=1)
+    m0 = nb * nc
+    phi = (t / period) % 1
+    order = np.argsort(phi)                        # phase.py:132-134 (numerically inert)
+    phi, xs = phi[order], x[order]
+    num, n_sum, good = 0.0, 0, 0
+    var_terms, sizes = [], []
+    for k in range(m0):
+        member = (phi >= k / m0) & (phi < (k + nc) / m0)
+        member |= phi < (k - (m0 - nc)) / m0        # wrap-around cover
+        xk = xs[member]
+        if xk.size > 1:
+            var_terms.append(np.var(xk, ddof=1))
+            sizes.append(xk.size)
+            good += 1
+    sj, nj = np.array(var_terms), np.array(sizes)
+    return (np.sum((nj - 1) * sj) / (np.sum(nj) - good)) / sigma
+
+
+def pdm_scan(t, x, periods, nb=5, nc=2):
+    """theta for every trial period, in the order of ``periods`` (``phase.py:185-187``)."""
+    sigma = np.var(x, ddof=1)
+    return np.array([pdm_theta(t, x, p, nb, nc, sigma) for p in periods])
+
+
+def pdm_subharmonic(thetas, periods, n_samples, p_min, p_max):
+    """Sub-harmonic averaging of ``PDM.__call__`` (``phase.py:166,181,188-193``)."""
+    thetas = np.array(thetas, dtype=float)
+    theta_crit = 1.0 - 11.0 / n_samples ** 0.8
+    dp = periods[1] - periods[0]
+    (ok,) = np.where((thetas < theta_crit) & (periods <= p_max / 2))
+    sub = np.round(2 * ok + p_min / dp).astype(int)
+    thetas[ok] = (thetas[ok] + thetas[sub]) / 2
+    return thetas
+
+
+def pdm(time, values, nb=5, nc=2, p_min=None, p_max=None, n_periods=1000, oversample=1,
+        do_subharmonic=False):
+    """``PDM(...)(TSeries(time, values))`` → (frequency ascending, theta) (``phase.py:151-195``)."""
+    time, values = np.asarray(time), np.asarray(values)
+    periods, p_lo, p_hi = pdm_periods(time, p_min, p_max, n_periods, oversample)
+    thetas = pdm_scan(time, values, periods, nb, nc)
+    if do_subharmonic:
+        thetas = pdm_subharmonic(thetas, periods, values.size, p_lo, p_hi)
+    freq = 1 / periods
+    order = np.argsort(freq, kind="stable")        # FSeries sorts ascending, core.py:877-881
+    return freq[order], thetas[order]
+
+
+def stringlength_one(t, m, period):
+    """Dworetsky string length for one trial period: ``StringLength._stringlength``
+    (``phase.py:45-51``) through ``TSeries.fold`` (``core.py:543-544``) and the stable
+    sort-by-phase of the ``TSeries`` constructor (``core.py:473-477``).  The polygon is closed
+    with ``np.roll`` and the closing segment is *not* phase-wrapped."""
+    phi = ((t - 0) / period) % 1
+    order = np.argsort(phi, kind="stable")
+    phi, mm = phi[order], m[order]
+    return np.hypot(np.roll(mm, -1) - mm, np.roll(phi, -1) - phi).sum()
+
+
+def stringlength_scan(t, m, periods):
+    return np.array([stringlength_one(t, m, p) for p in periods])
+
+
+def stringlength(time, values, dphi=0.1, n_periods=1000):
+    """Intended behaviour of ``StringLength(dphi, n_periods)(signal)`` (``phase.py:53-72``;
+    broken at HEAD — SURVEY.md fact 4) → (frequency ascending, ell)."""
+    time, values = np.asarray(time), np.asarray(values)
+    m = stringlength_scale(values)
+    periods = stringlength_periods(time[-1] - time[0], dphi, n_periods)
+    ell = stringlength_scan(time, m, periods)
+    freq = 1 / periods
+    order = np.argsort(freq, kind="stable")
+    return freq[order], ell[order]

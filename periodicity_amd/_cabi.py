@@ -1,0 +1,233 @@
+"""ctypes binding of ``libperiodicity_hip.so`` (``include/periodicity_hip.h``).
+
+This is the only place the Python host code touches native code.  There is **no CPU fallback**:
+if the shared library is missing, or no gfx950 device is visible, every scan raises — loudly.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_LIB_NAME = "libperiodicity_hip.so"
+_lib = None
+_lock = threading.Lock()
+
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+
+STATUS_EXC = {-1: ValueError, -2: RuntimeError, -3: RuntimeError, -4: RuntimeError,
+              -5: MemoryError}
+
+# name -> (restype, argtypes); kept in the order of include/periodicity_hip.h
+_VP, _I, _L, _D = C.c_void_p, C.c_int, C.c_int64, C.c_double
+PROTOTYPES = {
+    "pdc_last_error": (C.c_char_p, []),
+    "pdc_version": (_I, []),
+    "pdc_device_count": (_I, [C.POINTER(_I)]),
+    "pdc_device_info": (_I, [_I, C.c_char_p, _I, C.POINTER(_I), c_int64_p, C.POINTER(_I)]),
+    "pdc_release": (_I, []),
+    "pdc_malloc": (_I, [_I, _L, C.POINTER(_VP)]),
+    "pdc_free": (_I, [_I, _VP]),
+    "pdc_memcpy_h2d": (_I, [_I, _VP, _VP, _L]),
+    "pdc_memcpy_d2h": (_I, [_I, _VP, _VP, _L]),
+    "pdc_memset": (_I, [_I, _VP, _I, _L]),
+    "pdc_stream_create": (_I, [_I, C.POINTER(_VP)]),
+    "pdc_stream_destroy": (_I, [_I, _VP]),
+    "pdc_stream_sync": (_I, [_I, _VP]),
+    "pdc_device_sync": (_I, [_I]),
+    "pdc_event_create": (_I, [_I, C.POINTER(_VP)]),
+    "pdc_event_destroy": (_I, [_I, _VP]),
+    "pdc_event_record": (_I, [_I, _VP, _VP]),
+    "pdc_event_elapsed_ms": (_I, [_I, _VP, _VP, C.POINTER(C.c_float)]),
+    "pdc_gls_scan": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _L, _I, _I, _VP, _I]),
+    "pdc_gls_scan_batch": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _L, _I, _I,
+                                _VP, _VP, _VP, _I]),
+    "pdc_gls_scan_multi": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _I, _I, _VP, _VP, _I]),
+    "pdc_trig_sums": (_I, [_VP, _VP, _L, _D, _D, _L, _VP, _VP, _I]),
+    "pdc_gls_work_bytes": (_L, [_L, _L, _L]),
+    "pdc_gls_scan_dev": (_I, [_I, _VP, _VP, _VP, _VP, _VP, _L, _L, _I, _D, _D, _L, _L, _I, _I,
+                              _VP, _VP, _VP, _VP, _L]),
+    "pdc_pdm_scan": (_I, [_VP, _VP, _L, _VP, _L, _I, _I, _D, _VP, _I]),
+    "pdc_pdm_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _I, _I, _D, _VP]),
+    "pdc_stringlength_scan": (_I, [_VP, _VP, _L, _VP, _L, _VP, _I]),
+    "pdc_stringlength_work_bytes": (_L, [_L, _L]),
+    "pdc_stringlength_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _VP, _VP, _L]),
+}
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def lib():
+    """The loaded shared library; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                path = library_path()
+                if not os.path.isfile(path):
+                    raise RuntimeError(
+                        f"{path} is missing: the HIP extension has not been built "
+                        "(run `make -C periodicity_amd/csrc` or `python -c 'import "
+                        "__graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+                handle = C.CDLL(path)
+                for name, (res, args) in PROTOTYPES.items():
+                    fn = getattr(handle, name)
+                    fn.restype, fn.argtypes = res, args
+                _lib = handle
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        msg = lib().pdc_last_error().decode("utf-8", "replace")
+        raise STATUS_EXC.get(status, RuntimeError)(f"libperiodicity_hip: {msg} (status {status})")
+
+
+def device_count():
+    n = C.c_int(0)
+    status = lib().pdc_device_count(C.byref(n))
+    return n.value if status == 0 else 0
+
+
+def device_info(device=0):
+    name = C.create_string_buffer(256)
+    cu, mem, clk = C.c_int(0), C.c_int64(0), C.c_int(0)
+    check(lib().pdc_device_info(device, name, 256, C.byref(cu), C.byref(mem), C.byref(clk)))
+    return {"name": name.value.decode(), "cu_count": cu.value, "hbm_bytes": mem.value,
+            "clock_khz": clk.value}
+
+
+def default_device():
+    return int(os.environ.get("PERIODICITY_AMD_DEVICE", "0"))
+
+
+def _f64(a, name):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.ndim != 1:
+        raise ValueError(f"{name} must be one-dimensional")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def grid_params(frequency):
+    """(f0, delta, nf) of a grid built by ``np.arange`` — numpy fills ``start + i*delta`` with
+    ``delta = a[1] - a[0]``, which is what the kernels recompute bit-for-bit."""
+    frequency = np.asarray(frequency, dtype=np.float64)
+    nf = frequency.size
+    if nf == 0:
+        return 0.0, 0.0, 0
+    f0 = float(frequency[0])
+    delta = float(frequency[1] - frequency[0]) if nf > 1 else 0.0
+    return f0, delta, nf
+
+
+# ---- host-buffer entry points ---------------------------------------------------------------------
+def gls_scan(t, y, dy, f0, delta, nf, fit_mean=True, psd=False, j_begin=0, device=None):
+    t, y = _f64(t, "t"), _f64(y, "y")
+    dy = None if dy is None else _f64(dy, "dy")
+    if y.size != t.size or (dy is not None and dy.size != t.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    out = np.empty(nf, dtype=np.float64)
+    dev = default_device() if device is None else device
+    check(lib().pdc_gls_scan(_ptr(t), _ptr(y), _ptr(dy), t.size, f0, delta, j_begin, nf,
+                             int(bool(fit_mean)), int(bool(psd)), _ptr(out), dev))
+    return out
+
+
+def gls_scan_batch(t, y, dy, offsets, f0, delta, nf, fit_mean=True, psd=False, shared_t=False,
+                   want_power=True, want_peaks=False, j_begin=0, device=None):
+    t, y = _f64(t, "t"), _f64(y, "y")
+    dy = None if dy is None else _f64(dy, "dy")
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    nb = offsets.size - 1
+    if nb < 1 or offsets[-1] != y.size or (dy is not None and dy.size != y.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    if (shared_t and t.size != offsets[1]) or (not shared_t and t.size != y.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    power = np.empty((nb, nf), dtype=np.float64) if want_power else None
+    amax = np.empty(nb, dtype=np.float64) if want_peaks else None
+    argmax = np.empty(nb, dtype=np.int64) if want_peaks else None
+    dev = default_device() if device is None else device
+    check(lib().pdc_gls_scan_batch(_ptr(t), _ptr(y), _ptr(dy), _ptr(offsets), nb, int(shared_t),
+                                   f0, delta, j_begin, nf, int(bool(fit_mean)), int(bool(psd)),
+                                   _ptr(power), _ptr(amax), _ptr(argmax), dev))
+    return power, amax, argmax
+
+
+def gls_scan_multi(t, y, dy, f0, delta, nf, fit_mean=True, psd=False, devices=(0,)):
+    t, y = _f64(t, "t"), _f64(y, "y")
+    dy = None if dy is None else _f64(dy, "dy")
+    if y.size != t.size or (dy is not None and dy.size != t.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    devs = np.ascontiguousarray(devices, dtype=np.int32)
+    out = np.empty(nf, dtype=np.float64)
+    check(lib().pdc_gls_scan_multi(_ptr(t), _ptr(y), _ptr(dy), t.size, f0, delta, nf,
+                                   int(bool(fit_mean)), int(bool(psd)), _ptr(out), _ptr(devs),
+                                   devs.size))
+    return out
+
+
+def trig_sums(t, w, f0, delta, nf, device=None):
+    t, w = _f64(t, "t"), _f64(w, "w")
+    if w.size != t.size:
+        raise ValueError("Input arrays have incompatible lengths.")
+    S, Cc = np.empty(nf), np.empty(nf)
+    dev = default_device() if device is None else device
+    check(lib().pdc_trig_sums(_ptr(t), _ptr(w), t.size, f0, delta, nf, _ptr(S), _ptr(Cc), dev))
+    return S, Cc
+
+
+def pdm_scan(t, x, periods, nb, nc, sigma, device=None):
+    t, x, periods = _f64(t, "t"), _f64(x, "x"), _f64(periods, "periods")
+    if x.size != t.size:
+        raise ValueError("Input arrays have incompatible lengths.")
+    out = np.empty(periods.size, dtype=np.float64)
+    dev = default_device() if device is None else device
+    check(lib().pdc_pdm_scan(_ptr(t), _ptr(x), t.size, _ptr(periods), periods.size, int(nb),
+                             int(nc), float(sigma), _ptr(out), dev))
+    return out
+
+
+def stringlength_scan(t, m, periods, device=None):
+    t, m, periods = _f64(t, "t"), _f64(m, "m"), _f64(periods, "periods")
+    if m.size != t.size:
+        raise ValueError("Input arrays have incompatible lengths.")
+    out = np.empty(periods.size, dtype=np.float64)
+    dev = default_device() if device is None else device
+    check(lib().pdc_stringlength_scan(_ptr(t), _ptr(m), t.size, _ptr(periods), periods.size,
+                                      _ptr(out), dev))
+    return out
+
+
+# ---- device-resident helpers (bench.py, tests) ----------------------------------------------------
+class DeviceBuffer:
+    """A raw HBM allocation owned by the caller."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = device, int(nbytes)
+        p = C.c_void_p()
+        check(lib().pdc_malloc(device, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_array(cls, a, device=0):
+        a = np.ascontiguousarray(a)
+        buf = cls(a.nbytes, device)
+        check(lib().pdc_memcpy_h2d(device, buf.ptr, _ptr(a), a.nbytes))
+        return buf
+
+    def to_array(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        check(lib().pdc_memcpy_d2h(self.device, _ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            check(lib().pdc_free(self.device, self.ptr))
+            self.ptr = None

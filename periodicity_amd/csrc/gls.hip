@@ -1,0 +1,537 @@
+// Generalized Lomb-Scargle as an exact direct summation on gfx950 (fp64 VALU bound).
+//
+// Replaces GLS.__call__ from the weights onward (/root/reference/src/periodicity/
+// spectral.py:99-132) and the _trig_sum seam (spectral.py:11-40, by the sums its docstring
+// defines at :13-15).
+//
+// Decomposition
+//   gls_prep_kernel   one workgroup per light curve: weights (spectral.py:99-108), YY (:120) and
+//                     one 48-byte record per sample {t - t0, w*y, w, cos(2 pi delta t'),
+//                     sin(2 pi delta t'), 0}.
+//   gls_scan_kernel   each thread owns K consecutive trial frequencies; the workgroup streams the
+//                     curve's records once through LDS (coalesced 16-byte loads, register
+//                     prefetch of the next chunk) and every lane reads each record as an LDS
+//                     broadcast.  Per (sample, thread): ONE software sincos at the tile's first
+//                     frequency (phase carried in cycles with an exact fma product), then K-1
+//                     plane rotations by the per-sample angle 2 pi delta t' walk the uniform
+//                     grid; 6 running sums per frequency (Sh, Ch, S, C, sum w s^2, sum w s c —
+//                     the 2-omega sums follow from the double-angle identities).  The epilogue
+//                     (spectral.py:113-132) is fused, so only power[nf] is written.
+//   gls_peak_kernel   NaN-aware max / argmax per curve from per-workgroup partials.
+//
+// No MFMA: with one weight vector per curve the accumulation is a matrix-vector product and the
+// cost is the transcendental/rotation work on the vector ALU.
+#include "pdc_internal.h"
+
+#include <cstdlib>
+
+using namespace pdc;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kChunk = 256;  // samples staged in LDS per step (12 KiB)
+
+enum Mode { MODE_FIT_MEAN = 0, MODE_NO_MEAN = 1, MODE_RAW = 2 };
+
+struct GlsArgs {
+    const double *rec;       // [n_total][6]
+    const int64_t *offsets;  // [n_curves + 1] or nullptr (single curve)
+    const double *scal;      // [n_curves][4] = {YY, sum w, sum err^-2, t0}
+    int64_t n_total, n_curves, tiles;
+    double f0, delta;
+    int64_t j_begin, nf;
+    int psd;
+    double *power;     // [n_curves][nf] or nullptr
+    double *raw_s;     // MODE_RAW outputs
+    double *raw_c;
+    double *blk_max;   // [n_curves * tiles] or nullptr
+    int64_t *blk_arg;
+};
+
+struct PrepArgs {
+    const double *t, *y, *dy;
+    const int64_t *offsets;
+    int64_t n_total;
+    int shared_t, fit_mean, raw;
+    double delta;
+    double *rec, *scal;
+};
+
+// ---- prologue: spectral.py:99-108, 120 ------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void gls_prep_kernel(PrepArgs a) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    const int64_t off = a.offsets ? a.offsets[blockIdx.x] : 0;
+    const int64_t n = a.offsets ? a.offsets[blockIdx.x + 1] - off : a.n_total;
+    const double *t = a.shared_t ? a.t : a.t + off;
+    const double *y = a.y + off;
+    const double *dy = a.dy ? a.dy + off : nullptr;
+    double *rec = a.rec + off * 6;
+    const double t0 = n > 0 ? t[0] : 0.0;
+
+    double W = 1.0, ybar = 0.0;
+    if (!a.raw) {
+        double acc = 0.0;  // w = err**-2 ; w.sum()
+        for (int64_t i = tid; i < n; i += kBlock) {
+            const double e = dy ? dy[i] : 1.0;
+            acc += 1.0 / (e * e);
+        }
+        W = block_sum_256(acc, red);
+        if (a.fit_mean) {  // np.dot(w / w.sum(), values)
+            acc = 0.0;
+            for (int64_t i = tid; i < n; i += kBlock) {
+                const double e = dy ? dy[i] : 1.0;
+                acc += (1.0 / (e * e)) / W * y[i];
+            }
+            ybar = block_sum_256(acc, red);
+        }
+    }
+    double yy = 0.0, wsum = 0.0;
+    for (int64_t i = tid; i < n; i += kBlock) {
+        const double tp = t[i] - t0;
+        double w, wy;
+        if (a.raw) {
+            w = y[i];  // the caller's weights, used as given (spectral.py:13-15)
+            wy = w;
+        } else {
+            const double e = dy ? dy[i] : 1.0;
+            w = (1.0 / (e * e)) / W;
+            const double yc = y[i] - ybar;
+            wy = w * yc;
+            yy += wy * yc;
+            wsum += w;
+        }
+        double sd, cd;
+        sincos_cycles(frac_product(a.delta, tp), sd, cd);
+        double2 *r = reinterpret_cast<double2 *>(rec + i * 6);
+        r[0] = make_double2(tp, wy);
+        r[1] = make_double2(w, cd);
+        r[2] = make_double2(sd, 0.0);
+    }
+    yy = block_sum_256(yy, red);
+    wsum = block_sum_256(wsum, red);
+    if (tid == 0) {
+        double *s = a.scal + (int64_t)blockIdx.x * 4;
+        s[0] = yy;
+        s[1] = wsum;
+        s[2] = W;
+        s[3] = t0;
+    }
+}
+
+// ---- epilogue: spectral.py:113-132, written in the reference's own operation order ------------------
+template <int MODE>
+__device__ __forceinline__ double gls_power(double Sh, double Ch, double S, double C, double SS,
+                                            double SC, double YY, double Wsum, double Werr,
+                                            int psd) {
+    const double S2 = 2.0 * SC;            // sum w sin(2 omega t)
+    const double C2 = Wsum - 2.0 * SS;     // sum w cos(2 omega t)
+    double tan2;
+    if (MODE == MODE_FIT_MEAN) {
+        tan2 = (S2 - 2.0 * S * C) / (C2 - (C * C - S * S));
+    } else {
+        tan2 = S2 / C2;
+    }
+    const double nrm = __builtin_sqrt(1.0 + tan2 * tan2);
+    const double S2w = tan2 / nrm;
+    const double C2w = 1.0 / nrm;
+    const double rh = __builtin_sqrt(0.5);
+    const double Cw = rh * __builtin_sqrt(1.0 + C2w);
+    const double sgn = (S2w != S2w) ? S2w : (double)((S2w > 0.0) - (S2w < 0.0));  // np.sign
+    const double Sw = rh * sgn * __builtin_sqrt(1.0 - C2w);
+    const double YC = Ch * Cw + Sh * Sw;
+    const double YS = Sh * Cw - Ch * Sw;
+    double CC = 0.5 * (1.0 + C2 * C2w + S2 * S2w);
+    double SSw = 0.5 * (1.0 - C2 * C2w - S2 * S2w);
+    if (MODE == MODE_FIT_MEAN) {
+        const double a = C * Cw + S * Sw;
+        const double b = S * Cw - C * Sw;
+        CC -= a * a;
+        SSw -= b * b;
+    }
+    double power = YC * YC / CC + YS * YS / SSw;
+    if (psd) {
+        power *= 0.5 * Werr;
+    } else {
+        power /= YY;
+    }
+    return power;
+}
+
+// ---- the scan ------------------------------------------------------------------------------------------
+template <int K, int MODE>
+__global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
+    __shared__ double2 stage[kChunk * 3];
+    __shared__ double red_v[4];
+    __shared__ long long red_i[4];
+    const int tid = threadIdx.x;
+
+    // Workgroup p runs on XCD p % 8 (observed dispatch rule, used for speed only): hand each XCD a
+    // contiguous run of logical tiles so the tiles of one curve share that XCD's L2.
+    const int64_t G = a.n_curves * a.tiles;
+    const int64_t per_xcd = (G + 7) / 8;
+    const int64_t L = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (L >= G) return;
+    const int64_t curve = L / a.tiles;
+    const int64_t tile = L - curve * a.tiles;
+
+    const int64_t off = a.offsets ? a.offsets[curve] : 0;
+    const int64_t n = a.offsets ? a.offsets[curve + 1] - off : a.n_total;
+    const int64_t jl = (tile * kBlock + tid) * (int64_t)K;  // first local frequency of this thread
+    // numpy's arange fill rule: start + i*delta, two roundings (no fma)
+    const double fb = __dadd_rn(a.f0, __dmul_rn((double)(a.j_begin + jl), a.delta));
+
+    double Sh[K], Ch[K], S[K], C[K], SS[K], SC[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) Sh[k] = Ch[k] = S[k] = C[k] = SS[k] = SC[k] = 0.0;
+
+    const double2 *src = reinterpret_cast<const double2 *>(a.rec + off * 6);
+    const int64_t n2 = n * 3;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    double2 p0, p1, p2;
+    {
+        const int64_t i0 = tid;
+        p0 = i0 < n2 ? src[i0] : zero2;
+        p1 = i0 + kBlock < n2 ? src[i0 + kBlock] : zero2;
+        p2 = i0 + 2 * kBlock < n2 ? src[i0 + 2 * kBlock] : zero2;
+    }
+    for (int64_t base = 0; base < n; base += kChunk) {
+        __syncthreads();  // everyone is done with the previous chunk
+        stage[tid] = p0;
+        stage[tid + kBlock] = p1;
+        stage[tid + 2 * kBlock] = p2;
+        __syncthreads();
+        if (base + kChunk < n) {  // prefetch the next chunk while this one is consumed
+            const int64_t i0 = (base + kChunk) * 3 + tid;
+            p0 = i0 < n2 ? src[i0] : zero2;
+            p1 = i0 + kBlock < n2 ? src[i0 + kBlock] : zero2;
+            p2 = i0 + 2 * kBlock < n2 ? src[i0 + 2 * kBlock] : zero2;
+        }
+        const int cnt = (int)((n - base) < kChunk ? (n - base) : kChunk);
+        const double *recs = reinterpret_cast<const double *>(stage);
+        for (int i = 0; i < cnt; ++i) {
+            const double2 r0 = *reinterpret_cast<const double2 *>(recs + i * 6);
+            const double2 r1 = *reinterpret_cast<const double2 *>(recs + i * 6 + 2);
+            const double sd = recs[i * 6 + 4];
+            const double t = r0.x, wy = r0.y, w = r1.x, cd = r1.y;
+            double s, c;
+            sincos_cycles(frac_product(fb, t), s, c);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                Sh[k] = __builtin_fma(wy, s, Sh[k]);
+                Ch[k] = __builtin_fma(wy, c, Ch[k]);
+                if (MODE != MODE_RAW) {
+                    const double ws = w * s;
+                    if (MODE == MODE_FIT_MEAN) {
+                        S[k] += ws;
+                        C[k] = __builtin_fma(w, c, C[k]);
+                    }
+                    SS[k] = __builtin_fma(ws, s, SS[k]);
+                    SC[k] = __builtin_fma(ws, c, SC[k]);
+                }
+                if (k + 1 < K) {  // advance one grid step: rotate by 2 pi delta t'
+                    const double cn = __builtin_fma(c, cd, -(s * sd));
+                    const double sn = __builtin_fma(s, cd, c * sd);
+                    c = cn;
+                    s = sn;
+                }
+            }
+        }
+    }
+
+    const double *sc = a.scal + curve * 4;
+    if (MODE == MODE_RAW) {
+        // undo the t0 shift: sums were taken over t' = t - t0
+        const double t0 = sc[3];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int64_t j = jl + k;
+            if (j < a.nf) {
+                const double f = __dadd_rn(a.f0, __dmul_rn((double)(a.j_begin + j), a.delta));
+                double s0, c0;
+                sincos_cycles(frac_product(f, t0), s0, c0);
+                a.raw_s[curve * a.nf + j] = Sh[k] * c0 + Ch[k] * s0;
+                a.raw_c[curve * a.nf + j] = Ch[k] * c0 - Sh[k] * s0;
+            }
+        }
+        return;
+    }
+
+    const double YY = sc[0], Wsum = sc[1], Werr = sc[2];
+    double best = 0.0;
+    long long best_j = -1;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int64_t j = jl + k;
+        if (j < a.nf) {
+            const double p = gls_power<MODE>(Sh[k], Ch[k], S[k], C[k], SS[k], SC[k], YY, Wsum,
+                                             Werr, a.psd);
+            if (a.power) a.power[curve * a.nf + j] = p;
+            if (p == p && (best_j < 0 || p > best)) {
+                best = p;
+                best_j = j;
+            }
+        }
+    }
+    if (a.blk_max) {
+        // NaN-aware max with lowest-index ties (np.nanargmax): lanes hold ascending index ranges
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_down(best, o, 64);
+            const long long oj = __shfl_down(best_j, o, 64);
+            if (oj >= 0 && (best_j < 0 || ov > best || (ov == best && oj < best_j))) {
+                best = ov;
+                best_j = oj;
+            }
+        }
+        if ((tid & 63) == 0) {
+            red_v[tid >> 6] = best;
+            red_i[tid >> 6] = best_j;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int wv = 1; wv < 4; ++wv) {
+                if (red_i[wv] >= 0 && (best_j < 0 || red_v[wv] > best)) {
+                    best = red_v[wv];
+                    best_j = red_i[wv];
+                }
+            }
+            a.blk_max[L] = best;
+            a.blk_arg[L] = best_j;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void gls_peak_kernel(const double *blk_max, const int64_t *blk_arg,
+                                                      int64_t tiles, double *amax, int64_t *argmax) {
+    const int64_t curve = blockIdx.x;
+    double best = 0.0;
+    long long best_j = -1;
+    for (int64_t i = threadIdx.x; i < tiles; i += 64) {  // ascending per lane
+        const double v = blk_max[curve * tiles + i];
+        const long long j = blk_arg[curve * tiles + i];
+        if (j >= 0 && (best_j < 0 || v > best)) {
+            best = v;
+            best_j = j;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(best, o, 64);
+        const long long oj = __shfl_down(best_j, o, 64);
+        if (oj >= 0 && (best_j < 0 || ov > best || (ov == best && oj < best_j))) {
+            best = ov;
+            best_j = oj;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (amax) amax[curve] = best_j >= 0 ? best : __builtin_nan("");
+        if (argmax) argmax[curve] = best_j;
+    }
+}
+
+int tile_width() {
+    static int k = [] {
+        const char *e = getenv("PDC_GLS_K");
+        int v = e ? atoi(e) : 8;
+        return (v == 4 || v == 8 || v == 12 || v == 16) ? v : 8;
+    }();
+    return k;
+}
+
+template <int MODE>
+void launch_scan(int K, dim3 grid, hipStream_t st, const GlsArgs &a) {
+    switch (K) {
+        case 4: hipLaunchKernelGGL((gls_scan_kernel<4, MODE>), grid, dim3(kBlock), 0, st, a); break;
+        case 12: hipLaunchKernelGGL((gls_scan_kernel<12, MODE>), grid, dim3(kBlock), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((gls_scan_kernel<16, MODE>), grid, dim3(kBlock), 0, st, a); break;
+        default: hipLaunchKernelGGL((gls_scan_kernel<8, MODE>), grid, dim3(kBlock), 0, st, a); break;
+    }
+}
+
+struct WorkLayout {
+    int64_t rec, scal, blk_max, blk_arg, total;
+};
+
+WorkLayout layout(int64_t n_total, int64_t n_curves, int64_t nf) {
+    auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+    const int64_t tiles_max = (nf + kBlock * 4 - 1) / (kBlock * 4);  // smallest K is 4
+    WorkLayout w;
+    w.rec = 0;
+    w.scal = up(n_total * 48);
+    w.blk_max = w.scal + up(n_curves * 32);
+    w.blk_arg = w.blk_max + up(n_curves * tiles_max * 8);
+    w.total = w.blk_arg + up(n_curves * tiles_max * 8);
+    return w;
+}
+
+// Shared by the GLS and raw (trig_sums) paths.
+int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, const double *d_dy,
+             const int64_t *d_offsets, int64_t n_total, int64_t n_curves, int shared_t, double f0,
+             double delta, int64_t j_begin, int64_t nf, int mode, int psd, double *d_power,
+             double *d_raw_s, double *d_raw_c, double *d_amax, int64_t *d_argmax, void *work,
+             int64_t work_bytes) {
+    PDC_REQUIRE(d_t && d_y, "gls: t and y must not be NULL");
+    PDC_REQUIRE(n_total >= 0 && n_curves >= 1 && nf >= 0 && j_begin >= 0, "gls: negative size");
+    PDC_REQUIRE(n_curves == 1 || d_offsets, "gls: a batch needs offsets");
+    PDC_REQUIRE(n_curves * ((nf + 1023) / 1024 + 1) < (int64_t)1 << 31, "gls: grid too large");
+    const WorkLayout w = layout(n_total, n_curves, nf);
+    PDC_REQUIRE(work && work_bytes >= w.total, "gls: workspace too small (%lld < %lld bytes)",
+                (long long)work_bytes, (long long)w.total);
+    if (nf == 0) return PDC_OK;
+    PDC_TRY(use_device(device));
+    char *base = static_cast<char *>(work);
+
+    PrepArgs p;
+    p.t = d_t;
+    p.y = d_y;
+    p.dy = d_dy;
+    p.offsets = d_offsets;
+    p.n_total = n_total;
+    p.shared_t = shared_t;
+    p.fit_mean = mode == MODE_FIT_MEAN;
+    p.raw = mode == MODE_RAW;
+    p.delta = delta;
+    p.rec = reinterpret_cast<double *>(base + w.rec);
+    p.scal = reinterpret_cast<double *>(base + w.scal);
+    hipLaunchKernelGGL(gls_prep_kernel, dim3((unsigned)n_curves), dim3(kBlock), 0, st, p);
+    PDC_HIP(hipGetLastError());
+
+    const int K = tile_width();
+    GlsArgs a;
+    a.rec = p.rec;
+    a.offsets = d_offsets;
+    a.scal = p.scal;
+    a.n_total = n_total;
+    a.n_curves = n_curves;
+    a.tiles = (nf + (int64_t)kBlock * K - 1) / ((int64_t)kBlock * K);
+    a.f0 = f0;
+    a.delta = delta;
+    a.j_begin = j_begin;
+    a.nf = nf;
+    a.psd = psd;
+    a.power = d_power;
+    a.raw_s = d_raw_s;
+    a.raw_c = d_raw_c;
+    const bool peaks = d_amax || d_argmax;
+    a.blk_max = peaks ? reinterpret_cast<double *>(base + w.blk_max) : nullptr;
+    a.blk_arg = peaks ? reinterpret_cast<int64_t *>(base + w.blk_arg) : nullptr;
+    const int64_t G = a.n_curves * a.tiles;
+    const dim3 grid((unsigned)(((G + 7) / 8) * 8));
+    if (mode == MODE_FIT_MEAN) {
+        launch_scan<MODE_FIT_MEAN>(K, grid, st, a);
+    } else if (mode == MODE_NO_MEAN) {
+        launch_scan<MODE_NO_MEAN>(K, grid, st, a);
+    } else {
+        launch_scan<MODE_RAW>(K, grid, st, a);
+    }
+    PDC_HIP(hipGetLastError());
+    if (peaks) {
+        hipLaunchKernelGGL(gls_peak_kernel, dim3((unsigned)n_curves), dim3(64), 0, st, a.blk_max,
+                           a.blk_arg, a.tiles, d_amax, d_argmax);
+        PDC_HIP(hipGetLastError());
+    }
+    return PDC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t pdc_gls_work_bytes(int64_t n_total, int64_t n_curves, int64_t nf) {
+    if (n_total < 0 || n_curves < 1 || nf < 0) return -1;
+    return layout(n_total, n_curves, nf).total;
+}
+
+int pdc_gls_scan_dev(int device, void *stream, const double *d_t, const double *d_y,
+                     const double *d_dy, const int64_t *d_offsets, int64_t n_total,
+                     int64_t n_curves, int shared_t, double f0, double delta, int64_t j_begin,
+                     int64_t nf, int fit_mean, int psd, double *d_power, double *d_amax,
+                     int64_t *d_argmax, void *work, int64_t work_bytes) {
+    PDC_REQUIRE(d_power || d_amax || d_argmax, "gls: no output requested");
+    return scan_dev(device, (hipStream_t)stream, d_t, d_y, d_dy, d_offsets, n_total, n_curves,
+                    shared_t, f0, delta, j_begin, nf, fit_mean ? MODE_FIT_MEAN : MODE_NO_MEAN, psd,
+                    d_power, nullptr, nullptr, d_amax, d_argmax, work, work_bytes);
+}
+
+int pdc_gls_scan_batch(const double *t, const double *y, const double *dy, const int64_t *offsets,
+                       int64_t n_curves, int shared_t, double f0, double delta, int64_t j_begin,
+                       int64_t nf, int fit_mean, int psd, double *power_out, double *amax_out,
+                       int64_t *argmax_out, int device) {
+    PDC_REQUIRE(t && y && offsets, "gls: t, y and offsets must not be NULL");
+    PDC_REQUIRE(n_curves >= 1 && nf >= 0 && j_begin >= 0, "gls: negative size");
+    PDC_REQUIRE(power_out || amax_out || argmax_out, "gls: no output requested");
+    for (int64_t b = 0; b < n_curves; ++b) {
+        PDC_REQUIRE(offsets[b + 1] >= offsets[b], "gls: offsets must be non-decreasing");
+        PDC_REQUIRE(!shared_t || offsets[b + 1] - offsets[b] == offsets[1] - offsets[0],
+                    "gls: with a shared time axis every curve must have the same length");
+    }
+    PDC_REQUIRE(offsets[0] == 0, "gls: offsets[0] must be 0");
+    PDC_TRY(use_device(device));
+    DeviceLock lock(device);
+    const int64_t n_total = offsets[n_curves];
+    const int64_t n_t = shared_t ? offsets[1] : n_total;
+    const int64_t wb = pdc_gls_work_bytes(n_total, n_curves, nf);
+    void *d_t, *d_y, *d_dy = nullptr, *d_off, *d_pow = nullptr, *d_amax = nullptr, *d_arg = nullptr,
+                     *d_work;
+    PDC_TRY(cached(device, SLOT_IN0, n_t * 8, &d_t));
+    PDC_TRY(cached(device, SLOT_IN1, n_total * 8, &d_y));
+    if (dy) PDC_TRY(cached(device, SLOT_IN2, n_total * 8, &d_dy));
+    PDC_TRY(cached(device, SLOT_IN3, (n_curves + 1) * 8, &d_off));
+    if (power_out) PDC_TRY(cached(device, SLOT_OUT0, n_curves * nf * 8, &d_pow));
+    if (amax_out) PDC_TRY(cached(device, SLOT_OUT1, n_curves * 8, &d_amax));
+    if (argmax_out) PDC_TRY(cached(device, SLOT_OUT2, n_curves * 8, &d_arg));
+    PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
+    hipStream_t st = nullptr;
+    PDC_HIP(hipMemcpyAsync(d_t, t, n_t * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemcpyAsync(d_y, y, n_total * 8, hipMemcpyHostToDevice, st));
+    if (dy) PDC_HIP(hipMemcpyAsync(d_dy, dy, n_total * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemcpyAsync(d_off, offsets, (n_curves + 1) * 8, hipMemcpyHostToDevice, st));
+    PDC_TRY(scan_dev(device, st, (double *)d_t, (double *)d_y, (double *)d_dy, (int64_t *)d_off,
+                     n_total, n_curves, shared_t, f0, delta, j_begin, nf,
+                     fit_mean ? MODE_FIT_MEAN : MODE_NO_MEAN, psd, (double *)d_pow, nullptr, nullptr,
+                     (double *)d_amax, (int64_t *)d_arg, d_work, wb));
+    if (power_out) PDC_HIP(hipMemcpyAsync(power_out, d_pow, n_curves * nf * 8, hipMemcpyDeviceToHost, st));
+    if (amax_out) PDC_HIP(hipMemcpyAsync(amax_out, d_amax, n_curves * 8, hipMemcpyDeviceToHost, st));
+    if (argmax_out) PDC_HIP(hipMemcpyAsync(argmax_out, d_arg, n_curves * 8, hipMemcpyDeviceToHost, st));
+    PDC_HIP(hipStreamSynchronize(st));
+    return PDC_OK;
+}
+
+int pdc_gls_scan(const double *t, const double *y, const double *dy, int64_t n, double f0,
+                 double delta, int64_t j_begin, int64_t nf, int fit_mean, int psd,
+                 double *power_out, int device) {
+    PDC_REQUIRE(n >= 0, "gls: negative sample count");
+    PDC_REQUIRE(power_out || nf == 0, "gls: power_out is NULL");
+    const int64_t offsets[2] = {0, n};
+    return pdc_gls_scan_batch(t, y, dy, offsets, 1, 0, f0, delta, j_begin, nf, fit_mean, psd,
+                              power_out, nullptr, nullptr, device);
+}
+
+int pdc_trig_sums(const double *t, const double *w, int64_t n, double f0, double delta, int64_t nf,
+                  double *S_out, double *C_out, int device) {
+    PDC_REQUIRE(t && w && S_out && C_out, "trig_sums: NULL argument");
+    PDC_REQUIRE(n >= 0 && nf >= 0, "trig_sums: negative size");
+    PDC_TRY(use_device(device));
+    DeviceLock lock(device);
+    const int64_t wb = pdc_gls_work_bytes(n, 1, nf);
+    void *d_t, *d_w, *d_s, *d_c, *d_work;
+    PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
+    PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_w));
+    PDC_TRY(cached(device, SLOT_OUT0, nf * 8, &d_s));
+    PDC_TRY(cached(device, SLOT_OUT1, nf * 8, &d_c));
+    PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
+    hipStream_t st = nullptr;
+    PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemcpyAsync(d_w, w, n * 8, hipMemcpyHostToDevice, st));
+    PDC_TRY(scan_dev(device, st, (double *)d_t, (double *)d_w, nullptr, nullptr, n, 1, 0, f0, delta,
+                     0, nf, MODE_RAW, 0, nullptr, (double *)d_s, (double *)d_c, nullptr, nullptr,
+                     d_work, wb));
+    PDC_HIP(hipMemcpyAsync(S_out, d_s, nf * 8, hipMemcpyDeviceToHost, st));
+    PDC_HIP(hipMemcpyAsync(C_out, d_c, nf * 8, hipMemcpyDeviceToHost, st));
+    PDC_HIP(hipStreamSynchronize(st));
+    return PDC_OK;
+}
+
+}  // extern "C"

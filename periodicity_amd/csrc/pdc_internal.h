@@ -1,0 +1,118 @@
+// Internal helpers shared by the translation units of libperiodicity_hip.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/periodicity_hip.h"
+
+namespace pdc {
+
+// Per-thread message returned by pdc_last_error().
+void set_error(const char *fmt, ...);
+
+// Grow-only device scratch cached per (device, slot); released by pdc_release().
+// Slots keep the buffers of one host-level call apart.
+enum Slot { SLOT_IN0 = 0, SLOT_IN1, SLOT_IN2, SLOT_IN3, SLOT_OUT0, SLOT_OUT1, SLOT_OUT2, SLOT_WORK,
+            SLOT_COUNT };
+int cached(int device, Slot slot, int64_t bytes, void **dptr);
+
+// hipSetDevice + range check; every entry point starts here.
+int use_device(int device);
+
+// Serialises the host-level entry points that share the cached workspace of one device.
+struct DeviceLock {
+    explicit DeviceLock(int device);
+    ~DeviceLock();
+    int device;
+};
+
+}  // namespace pdc
+
+#define PDC_HIP(call)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (call);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            pdc::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                     \
+            return _e == hipErrorOutOfMemory ? PDC_ERR_NOMEM : PDC_ERR_HIP;               \
+        }                                                                                 \
+    } while (0)
+
+#define PDC_TRY(call)          \
+    do {                       \
+        int _s = (call);       \
+        if (_s != PDC_OK) return _s; \
+    } while (0)
+
+#define PDC_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            pdc::set_error(__VA_ARGS__); \
+            return PDC_ERR_INVALID;     \
+        }                               \
+    } while (0)
+
+// ---- device-side helpers -------------------------------------------------------------------------
+namespace pdc {
+
+// sin(2 pi r), cos(2 pi r) for r given in CYCLES, |r| <= ~0.5 (any finite r works; accuracy is
+// that of the reduction r - q/4, exact in fp64).  gfx950 has no fp64 transcendental unit, so this
+// is a polynomial on [-pi/4, pi/4] (degree 13 / 14 minimax, the classic fdlibm kernel
+// coefficients) plus a quadrant fix-up done with integer ops on the high word.
+__device__ __forceinline__ void sincos_cycles(double r, double &s, double &c) {
+    const double q = __builtin_rint(4.0 * r);
+    const double z = __builtin_fma(-0.25, q, r);           // exact: |z| <= 1/8 cycle
+    const double x = z * 6.283185307179586476925;          // radians, |x| <= pi/4
+    const double x2 = x * x;
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(ps, x2, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, x2, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, x2, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, x2, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, x2, -1.66666666666666324348e-01);
+    const double sx = __builtin_fma(x * x2, ps, x);
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(pc, x2, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, x2, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, x2, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, x2, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, x2, 4.16666666666666019037e-02);
+    const double cx = __builtin_fma(x2 * x2, pc, __builtin_fma(-0.5, x2, 1.0));
+    const int qi = (int)q;
+    const bool swap = qi & 1;
+    double s1 = swap ? cx : sx;
+    double c1 = swap ? sx : cx;
+    // quadrant 1: (c, -s)  2: (-s, -c)  3: (-c, s)
+    const unsigned long long sflip = (unsigned long long)(qi & 2) << 62;
+    const unsigned long long cflip = (unsigned long long)((qi + 1) & 2) << 62;
+    s = __longlong_as_double(__double_as_longlong(s1) ^ sflip);
+    c = __longlong_as_double(__double_as_longlong(c1) ^ cflip);
+}
+
+// frac(a*b) in (-0.5, 0.5] cycles with the product carried exactly (fma error term), so the
+// phase stays accurate to ~1e-16 cycle however many whole cycles a*b spans.
+__device__ __forceinline__ double frac_product(double a, double b) {
+    const double hi = a * b;
+    const double lo = __builtin_fma(a, b, -hi);
+    return (hi - __builtin_rint(hi)) + lo;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Deterministic block-wide sum for 256-thread blocks; result valid in every thread.
+__device__ __forceinline__ double block_sum_256(double v, double *lds4) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+}
+
+}  // namespace pdc

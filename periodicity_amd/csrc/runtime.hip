@@ -1,0 +1,234 @@
+// Runtime side of the C ABI: errors, device selection, cached workspaces, memory/stream/event
+// wrappers.  Nothing here is on the hot path.
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "pdc_internal.h"
+
+namespace pdc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct DeviceState {
+    void *buf[SLOT_COUNT] = {};
+    int64_t cap[SLOT_COUNT] = {};
+    std::mutex call_mutex;
+};
+
+static std::mutex g_mutex;
+static std::vector<DeviceState *> g_devices;
+static int g_count = -1;
+
+static int device_count_cached() {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    if (g_count < 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess) {
+            set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+            (void)hipGetLastError();
+            return -1;  // not cached: a later call may succeed
+        }
+        g_count = n;
+        g_devices.resize(n, nullptr);
+        for (int i = 0; i < n; ++i) g_devices[i] = new DeviceState();
+    }
+    return g_count;
+}
+
+int use_device(int device) {
+    int n = device_count_cached();
+    if (n <= 0) {
+        if (n == 0) set_error("no HIP device is visible to this process");
+        return PDC_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (0..%d)", device, n - 1);
+        return PDC_ERR_INVALID;
+    }
+    PDC_HIP(hipSetDevice(device));
+    return PDC_OK;
+}
+
+int cached(int device, Slot slot, int64_t bytes, void **dptr) {
+    DeviceState *st = g_devices[device];
+    if (bytes < 256) bytes = 256;
+    if (st->cap[slot] < bytes) {
+        if (st->buf[slot]) {
+            PDC_HIP(hipFree(st->buf[slot]));
+            st->buf[slot] = nullptr;
+            st->cap[slot] = 0;
+        }
+        int64_t want = bytes + bytes / 8;  // head-room so a slowly growing caller does not thrash
+        hipError_t e = hipMalloc(&st->buf[slot], (size_t)want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            want = bytes;
+            PDC_HIP(hipMalloc(&st->buf[slot], (size_t)want));
+        }
+        st->cap[slot] = want;
+    }
+    *dptr = st->buf[slot];
+    return PDC_OK;
+}
+
+DeviceLock::DeviceLock(int d) : device(d) {
+    if (d >= 0 && d < (int)g_devices.size()) g_devices[d]->call_mutex.lock();
+}
+DeviceLock::~DeviceLock() {
+    if (device >= 0 && device < (int)g_devices.size()) g_devices[device]->call_mutex.unlock();
+}
+
+}  // namespace pdc
+
+using namespace pdc;
+
+extern "C" {
+
+const char *pdc_last_error(void) { return g_err; }
+
+int pdc_version(void) { return 1; }
+
+int pdc_device_count(int *count) {
+    PDC_REQUIRE(count != nullptr, "count is NULL");
+    int n = device_count_cached();
+    if (n < 0) {
+        *count = 0;
+        return PDC_ERR_NODEVICE;
+    }
+    *count = n;
+    return PDC_OK;
+}
+
+int pdc_device_info(int device, char *name, int name_len, int *cu_count, int64_t *hbm_bytes,
+                    int *clock_khz) {
+    PDC_TRY(use_device(device));
+    hipDeviceProp_t prop;
+    PDC_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    return PDC_OK;
+}
+
+int pdc_release(void) {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    for (size_t d = 0; d < g_devices.size(); ++d) {
+        DeviceState *st = g_devices[d];
+        std::lock_guard<std::mutex> lk2(st->call_mutex);
+        bool any = false;
+        for (int s = 0; s < SLOT_COUNT; ++s) any |= st->buf[s] != nullptr;
+        if (!any) continue;
+        PDC_HIP(hipSetDevice((int)d));
+        for (int s = 0; s < SLOT_COUNT; ++s) {
+            if (st->buf[s]) PDC_HIP(hipFree(st->buf[s]));
+            st->buf[s] = nullptr;
+            st->cap[s] = 0;
+        }
+    }
+    return PDC_OK;
+}
+
+int pdc_malloc(int device, int64_t bytes, void **dptr) {
+    PDC_REQUIRE(dptr != nullptr && bytes >= 0, "pdc_malloc: bad arguments");
+    PDC_TRY(use_device(device));
+    PDC_HIP(hipMalloc(dptr, (size_t)(bytes > 0 ? bytes : 1)));
+    return PDC_OK;
+}
+
+int pdc_free(int device, void *dptr) {
+    PDC_TRY(use_device(device));
+    if (dptr) PDC_HIP(hipFree(dptr));
+    return PDC_OK;
+}
+
+int pdc_memcpy_h2d(int device, void *dst, const void *src, int64_t bytes) {
+    PDC_REQUIRE(bytes >= 0 && (bytes == 0 || (dst && src)), "pdc_memcpy_h2d: bad arguments");
+    PDC_TRY(use_device(device));
+    if (bytes) PDC_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return PDC_OK;
+}
+
+int pdc_memcpy_d2h(int device, void *dst, const void *src, int64_t bytes) {
+    PDC_REQUIRE(bytes >= 0 && (bytes == 0 || (dst && src)), "pdc_memcpy_d2h: bad arguments");
+    PDC_TRY(use_device(device));
+    if (bytes) PDC_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return PDC_OK;
+}
+
+int pdc_memset(int device, void *dst, int value, int64_t bytes) {
+    PDC_REQUIRE(bytes >= 0 && (bytes == 0 || dst), "pdc_memset: bad arguments");
+    PDC_TRY(use_device(device));
+    if (bytes) PDC_HIP(hipMemset(dst, value, (size_t)bytes));
+    return PDC_OK;
+}
+
+int pdc_stream_create(int device, void **stream) {
+    PDC_REQUIRE(stream != nullptr, "stream is NULL");
+    PDC_TRY(use_device(device));
+    hipStream_t s;
+    PDC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return PDC_OK;
+}
+
+int pdc_stream_destroy(int device, void *stream) {
+    PDC_TRY(use_device(device));
+    if (stream) PDC_HIP(hipStreamDestroy((hipStream_t)stream));
+    return PDC_OK;
+}
+
+int pdc_stream_sync(int device, void *stream) {
+    PDC_TRY(use_device(device));
+    PDC_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return PDC_OK;
+}
+
+int pdc_device_sync(int device) {
+    PDC_TRY(use_device(device));
+    PDC_HIP(hipDeviceSynchronize());
+    return PDC_OK;
+}
+
+int pdc_event_create(int device, void **event) {
+    PDC_REQUIRE(event != nullptr, "event is NULL");
+    PDC_TRY(use_device(device));
+    hipEvent_t e;
+    PDC_HIP(hipEventCreate(&e));
+    *event = (void *)e;
+    return PDC_OK;
+}
+
+int pdc_event_destroy(int device, void *event) {
+    PDC_TRY(use_device(device));
+    if (event) PDC_HIP(hipEventDestroy((hipEvent_t)event));
+    return PDC_OK;
+}
+
+int pdc_event_record(int device, void *event, void *stream) {
+    PDC_REQUIRE(event != nullptr, "event is NULL");
+    PDC_TRY(use_device(device));
+    PDC_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return PDC_OK;
+}
+
+int pdc_event_elapsed_ms(int device, void *start, void *stop, float *ms) {
+    PDC_REQUIRE(start && stop && ms, "pdc_event_elapsed_ms: NULL argument");
+    PDC_TRY(use_device(device));
+    PDC_HIP(hipEventSynchronize((hipEvent_t)stop));
+    PDC_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return PDC_OK;
+}
+
+}  // extern "C"

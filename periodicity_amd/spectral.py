@@ -1,0 +1,162 @@
+"""Generalized Lomb-Scargle periodogram with the reference's callable API, computed on MI355X.
+
+Drop-in for ``periodicity.spectral`` (``/root/reference/src/periodicity/spectral.py``):
+``GLS(fmin, fmax, n, psd)(signal, err, fit_mean) -> FSeries`` with the same positional order,
+defaults and attribute side effects (``.frequency .err .signal .periodogram``,
+``spectral.py:97,101,133-134``), plus ``bootstrap / fap / fal / window / model / copy``
+(``spectral.py:137-204``).  ``LombScargle`` is an alias of ``GLS``.
+
+What differs, deliberately: the three ``_trig_sum`` calls (``spectral.py:109-112``) are an
+FFT/extirpolation *approximation* upstream; here they are the exact direct sums that function's
+docstring defines (``spectral.py:13-15``), evaluated by the HIP kernel in
+``csrc/gls.hip``.  The frequency grid, weights and epilogue follow the reference line by line.
+Nothing in this module computes a periodogram on the CPU.
+"""
+import copy as _copy
+
+import numpy as np
+
+from . import _cabi
+from .core import FSeries, TSeries
+
+__all__ = ["GLS", "LombScargle", "BGLST"]
+
+
+def _as_tseries(signal):
+    """``spectral.py:86-87``: anything that is not a time series is wrapped as values on
+    ``arange`` times.  Real ``periodicity.core.TSeries`` objects pass through (duck typing)."""
+    if isinstance(signal, TSeries) or (hasattr(signal, "time") and hasattr(signal, "values")
+                                       and hasattr(signal, "baseline")):
+        return signal
+    return TSeries(values=signal)
+
+
+class GLS(object):
+    """Generalized Lomb-Scargle periodogram (Zechmeister & Kurster 2009) of a discrete signal.
+
+    Parameters (``spectral.py:53-72``)
+    ----------
+    fmin, fmax: float, optional
+        Grid limits; default half a cycle per baseline and the pseudo-Nyquist ``0.5/median_dt``.
+    n: float, optional
+        Samples per peak (default 5): grid spacing is ``1 / baseline / n``.
+    psd: bool, optional
+        Leave the periodogram un-normalised.
+    device: int, keyword-only, optional
+        GPU ordinal (default ``$PERIODICITY_AMD_DEVICE`` or 0).
+    devices: sequence of int, keyword-only, optional
+        Shard the frequency grid over these GPUs of one node (RCCL all-gather of the power array).
+    """
+
+    def __init__(self, fmin=None, fmax=None, n=5, psd=False, *, device=None, devices=None):
+        self.fmin = fmin
+        self.fmax = fmax
+        self.n = n
+        self.psd = psd
+        self.device = device
+        self.devices = None if devices is None else tuple(devices)
+
+    def _grid(self, signal):
+        """Uniform frequency grid of ``spectral.py:88-98`` — built by ``np.arange`` itself so its
+        length and values carry numpy's rounding; the kernel reproduces ``start + j*step``."""
+        df = 1.0 / signal.baseline / self.n
+        fmin = 0.5 * df if self.fmin is None else self.fmin
+        fmax = 0.5 / signal.median_dt if self.fmax is None else self.fmax
+        return np.arange(fmin, fmax + df, df)
+
+    def __call__(self, signal, err=None, fit_mean=True):
+        """Periodogram of ``signal`` on the default (or configured) uniform grid.
+
+        Parameters (``spectral.py:74-85``)
+        ----------
+        err: array-like, optional
+            Measurement uncertainties for each sample (may be heteroscedastic).
+        fit_mean: bool, optional
+            Let the mean float with the fit (the "generalized" part).
+        """
+        signal = _as_tseries(signal)
+        self.frequency = self._grid(signal)
+        f0, delta, nf = _cabi.grid_params(self.frequency)
+        have_err = err is not None
+        if not have_err:
+            err = np.ones_like(signal.values)
+        self.err = err
+        dy = np.asarray(err, dtype=float) if have_err else None
+        t = np.asarray(signal.time, dtype=float)
+        y = np.asarray(signal.values, dtype=float)
+        if self.devices is not None and len(self.devices) > 1:
+            power = _cabi.gls_scan_multi(t, y, dy, f0, delta, nf, fit_mean, self.psd,
+                                         self.devices)
+        else:
+            dev = self.device if self.devices is None else self.devices[0]
+            power = _cabi.gls_scan(t, y, dy, f0, delta, nf, fit_mean, self.psd, device=dev)
+        self.signal = signal
+        self.periodogram = FSeries(self.frequency, power)
+        return self.periodogram
+
+    def copy(self):
+        return _copy.deepcopy(self)
+
+    def bootstrap(self, n_bootstraps, random_seed=None):
+        """Maxima of ``n_bootstraps`` periodograms of ``(values, err)`` resampled with replacement
+        on the unchanged time axis (``spectral.py:140-152``).  The draws come from
+        ``default_rng(seed).integers(0, n, n)`` once per replicate, in order, exactly as
+        upstream; the replicates then run as ONE batched launch that shares the time axis and
+        returns only the NaN-aware maximum of each spectrum."""
+        rng = np.random.default_rng(random_seed)
+        ndata = len(self.signal)
+        values = np.asarray(self.signal.values, dtype=float)
+        err = np.asarray(self.err, dtype=float)
+        t = np.asarray(self.signal.time, dtype=float)
+        f0, delta, nf = _cabi.grid_params(self._grid(self.signal))
+        picks = np.empty((n_bootstraps, ndata), dtype=np.int64)
+        for i in range(n_bootstraps):
+            picks[i] = rng.integers(0, ndata, ndata)
+        offsets = np.arange(n_bootstraps + 1, dtype=np.int64) * ndata
+        bs_replicates = np.empty(n_bootstraps)
+        if n_bootstraps:
+            _, amax, _ = _cabi.gls_scan_batch(
+                t, values[picks].ravel(), err[picks].ravel(), offsets, f0, delta, nf, True,
+                self.psd, shared_t=True, want_power=False, want_peaks=True, device=self.device)
+            bs_replicates[:] = amax
+        self.bs_replicates = bs_replicates
+        return self.bs_replicates
+
+    def fap(self, power):
+        """Fraction of bootstrap maxima above ``power`` (``spectral.py:154-160``)."""
+        return np.mean(power < self.bs_replicates)
+
+    def fal(self, fap):
+        """Power level at false-alarm probability ``fap`` (``spectral.py:162-163``)."""
+        return np.quantile(self.bs_replicates, 1 - fap)
+
+    def window(self):
+        """Spectral window: periodogram of an all-ones signal, no floating mean
+        (``spectral.py:165-167``)."""
+        gls = self.copy()
+        return gls(0.0 * self.signal + 1.0, fit_mean=False)
+
+    def model(self, tf, f0):
+        """Weighted least-squares sinusoid-plus-offset at frequency ``f0`` evaluated at times
+        ``tf`` (``spectral.py:169-204``).  O(N) host arithmetic, not part of the scan."""
+        t = np.asarray(self.signal.time, dtype=float)
+        sigma = np.asarray(self.err, dtype=float)
+        w = sigma ** -2.0
+        y = np.asarray(self.signal.values, dtype=float)
+        y_mean = np.dot(y, w) / w.sum()
+
+        def basis(times):
+            arg = 2 * np.pi * f0 * np.asarray(times, dtype=float)
+            return np.vstack([np.ones_like(arg), np.sin(arg), np.cos(arg)])
+
+        A = basis(t) / sigma
+        theta = np.linalg.solve(A @ A.T, A @ ((y - y_mean) / sigma))
+        return TSeries(tf, y_mean + basis(tf).T @ theta)
+
+
+LombScargle = GLS
+
+
+class BGLST(object):
+    """Placeholder, as upstream (``spectral.py:207-208``)."""
+    pass
