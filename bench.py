@@ -1,0 +1,245 @@
+"""Headline benchmark: fp64 generalized Lomb-Scargle, N=1e5 unevenly sampled points x 1e6 trial
+frequencies per GPU (BASELINE.json configs[1]); prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over resident inputs: ``pdc_gls_scan_dev`` (weights prologue +
+direct-sum scan + fused epilogue) writing power[nf] in HBM; with N > 1 ranks each rank scans its
+own contiguous slab of an N-times longer grid (weak scaling, samples replicated) and the slabs are
+all-gathered with RCCL so every rank ends the step holding the whole power array.
+
+The product path is the C ABI (libperiodicity_hip.so) — torch is used only under torchrun, for
+rendezvous, the barrier and the RCCL all-gather.  ``oracle/`` is touched only by the
+``cpu_baseline`` leg and the spot check, never inside the timed region.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR = 50.0          # algorithmic fp64 flop per (sample, frequency) pair
+PEAK_FP64_VECTOR_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz (MI355X, spec)
+N_SAMPLES = 100_000
+NF_PER_GPU = 1_000_000
+
+
+def synth_curve(n, k=2, period=37.3):
+    """SURVEY.md §8d synthetic light curve (draw order t, dy, noise)."""
+    rng = np.random.default_rng(20241008 + k)
+    t = np.sort(rng.uniform(0, float(n), n))
+    dy = rng.uniform(0.05, 0.2, n)
+    y = 1.0 + 0.5 * np.sin(2 * np.pi * t / period) + dy * rng.standard_normal(n)
+    return t, y, dy
+
+
+def throughput_grid(t, nf):
+    df = 1.0 / (t[-1] - t[0]) / 5
+    fmin = 0.5 * df
+    freq = np.arange(fmin, fmin + (nf - 1.5) * df + df, df)
+    assert freq.size == nf, (freq.size, nf)
+    return freq, df, fmin
+
+
+def cpu_baseline(t, y, dy, freq, df, fmin):
+    """The reference's own CPU algorithm (FFT/extirpolation, single-threaded numpy as upstream),
+    restated in oracle/scan_oracle.py, on the full N=1e5 x nf=1e6 workload; plus the exact
+    direct sum (the arithmetic the GPU kernel does) on a bounded sample, all host cores."""
+    from oracle import c_oracle as co
+    from oracle import scan_oracle as so
+    t0 = time.perf_counter()
+    p_fft = so.gls_power(t, y, dy, freq, df, fmin, True, False, sums="fft")
+    dt_fft = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    n_s, nf_s = 10_000, 2_000 * cores
+    t0 = time.perf_counter()
+    co.trig_sums_exact(t[:n_s], dy[:n_s], freq[:nf_s])
+    dt_direct = time.perf_counter() - t0
+    base = {
+        "value": round(t.size * freq.size / dt_fft / 1e9, 3), "unit": "Gpair/s (effective)",
+        "cores": 1, "kind": "port",
+        "sample": f"full workload N={t.size} x nf={freq.size}, one pass of the reference's "
+                  f"O(nfft log nfft) FFT-extirpolation path in numpy: {dt_fft:.2f} s",
+        "direct_sum": {"value": round(n_s * nf_s / dt_direct / 1e9, 4), "unit": "Gpair/s",
+                       "cores": cores, "kind": "port",
+                       "sample": f"long-double direct sums, N={n_s} x nf={nf_s} "
+                                 f"(one trig-sum pair), OpenMP: {dt_direct:.2f} s"},
+    }
+    return base, p_fft
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the torch.distributed path even with one rank (testing)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_mode = world > 1 or args.force_dist
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
+
+    torch = dist = None
+    if dist_mode:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from periodicity_amd import _cabi
+    lib = _cabi.lib()
+    dev = local_rank
+    if _cabi.device_count() <= dev:
+        raise SystemExit("bench.py needs a GPU per rank; no CPU fallback exists")
+
+    # ---- workload --------------------------------------------------------------------------
+    n = N_SAMPLES
+    nf_total = NF_PER_GPU * world
+    t, y, dy = synth_curve(n)
+    freq, df, fmin = throughput_grid(t, nf_total)
+    f0, delta, _ = _cabi.grid_params(freq)
+    slab = NF_PER_GPU
+    j_begin = rank * slab
+
+    if dist_mode:
+        tt = torch.from_numpy(np.stack([t, y, dy])).cuda()
+        d_t, d_y, d_dy = (tt[i].data_ptr() for i in range(3))
+        power = torch.empty(nf_total, dtype=torch.float64, device="cuda")
+        work_bytes = lib.pdc_gls_work_bytes(n, 1, slab)
+        work = torch.empty(work_bytes, dtype=torch.uint8, device="cuda")
+        d_work = work.data_ptr()
+        slab_out = torch.empty(slab, dtype=torch.float64, device="cuda")
+        d_power_slab = slab_out.data_ptr()
+        stream = torch.cuda.current_stream().cuda_stream
+    else:
+        bufs = [_cabi.DeviceBuffer.from_array(a, dev) for a in (t, y, dy)]
+        d_t, d_y, d_dy = (b.ptr for b in bufs)
+        power_buf = _cabi.DeviceBuffer(nf_total * 8, dev)
+        work_bytes = lib.pdc_gls_work_bytes(n, 1, slab)
+        work_buf = _cabi.DeviceBuffer(work_bytes, dev)
+        d_work, d_power_slab = work_buf.ptr, power_buf.ptr
+        sp = C.c_void_p()
+        _cabi.check(lib.pdc_stream_create(dev, C.byref(sp)))
+        stream = sp.value
+
+    def new_event():
+        e = C.c_void_p()
+        _cabi.check(lib.pdc_event_create(dev, C.byref(e)))
+        return e.value
+
+    def step(ev=None):
+        if ev:
+            _cabi.check(lib.pdc_event_record(dev, ev[0], stream))
+        _cabi.check(lib.pdc_gls_scan_dev(dev, stream, d_t, d_y, d_dy, None, n, 1, 0, f0, delta,
+                                         j_begin, slab, 1, 0, d_power_slab, None, None, d_work,
+                                         work_bytes))
+        if ev:
+            _cabi.check(lib.pdc_event_record(dev, ev[1], stream))
+        if dist_mode and world >= 1:
+            dist.all_gather_into_tensor(power, slab_out)
+
+    def sync():
+        if dist_mode:
+            torch.cuda.synchronize()
+        else:
+            _cabi.check(lib.pdc_stream_sync(dev, stream))
+
+    def barrier():
+        if dist_mode:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    events = [(new_event(), new_event()) for _ in range(args.steps)]
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist_mode:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kernel_ms = []
+    for a, b in events:
+        ms = C.c_float()
+        _cabi.check(lib.pdc_event_elapsed_ms(dev, a, b, C.byref(ms)))
+        kernel_ms.append(ms.value)
+    kernel_s = float(np.mean(kernel_ms)) / 1e3
+
+    if rank == 0:
+        if dist_mode:
+            got = power.cpu().numpy()
+        else:
+            got = power_buf.to_array(np.float64, nf_total)
+        pairs_per_step = float(n) * float(nf_total)
+        value = pairs_per_step * args.steps / elapsed / 1e9
+        launch_pairs = float(n) * float(slab)
+        achieved = launch_pairs * FLOP_PER_PAIR / kernel_s / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.isfile(tpath):
+            traffic = json.load(open(tpath)).get("gls_scan_c2_bytes_per_launch")
+        out = {
+            "metric": "Lomb-Scargle Gpair/s (sample x freq), fp64, N=1e5 x 1e6 per GPU",
+            "value": round(value, 2), "unit": "Gpair/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "fp64 generalized Lomb-Scargle (fit_mean, heteroscedastic dy), "
+                                   f"N={n} unevenly sampled points x {NF_PER_GPU} trial "
+                                   "frequencies per GPU (BASELINE configs[1]); inputs resident in "
+                                   "HBM, exact direct summation",
+                       "n_samples": n, "n_freq_total": nf_total,
+                       "sharding": f"frequency grid in {world} contiguous slab(s)"
+                                   + (", RCCL all-gather of power" if world > 1 else "")},
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3),
+                         "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP64_VECTOR_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "gls_scan_kernel (+ gls_prep_kernel, <0.1%)",
+                         "kernel_ms": round(kernel_s * 1e3, 4),
+                         "note": "fp64 vector-ALU bound (software sincos + rotations; no fp64 "
+                                 "transcendental unit, not a contraction): achieved = 50 "
+                                 "algorithmic flop/pair x pairs per launch / HIP-event time; the "
+                                 "rotation recurrence executes ~27 flop/pair, so frac may exceed "
+                                 "the direct-evaluation roofline"},
+            "peak_bin": int(np.nanargmax(got)),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            base, p_fft = cpu_baseline(t, y, dy, freq, df, fmin)
+            out["cpu_baseline"] = base
+            out["peak_bin_matches_cpu_reference_path"] = bool(
+                int(np.nanargmax(p_fft)) == out["peak_bin"])
+        print(json.dumps(out), flush=True)
+
+    if dist_mode:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

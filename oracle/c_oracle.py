@@ -1,0 +1,82 @@
+"""TEST INFRASTRUCTURE — ctypes access to oracle/_build/liboracle.so (``scan_oracle.c``).
+
+Same role and rules as ``scan_oracle.py``: a checker for tests / smoke / the CPU-baseline leg of
+bench.py, never the product path.  Multi-threaded with OpenMP (``threads`` = cores used).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_PATH):
+            build()
+        _lib = C.CDLL(_PATH)
+    return _lib
+
+
+def set_threads(n):
+    os.environ["OMP_NUM_THREADS"] = str(int(n))
+    try:
+        omp = C.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def trig_sums_exact(t, h, frequency):
+    t, h, f = _f(t), _f(h), _f(frequency)
+    S, Cc = np.empty(f.size), np.empty(f.size)
+    lib().oracle_trig_sums_exact(_p(t), _p(h), C.c_int64(t.size), _p(f), C.c_int64(f.size),
+                                 _p(S), _p(Cc))
+    return S, Cc
+
+
+def pdm_scan(t, x, periods, nb=5, nc=2, sigma=None):
+    t, x, p = _f(t), _f(x), _f(periods)
+    if sigma is None:
+        sigma = np.var(x, ddof=1)
+    out = np.empty(p.size)
+    lib().oracle_pdm_scan(_p(t), _p(x), C.c_int64(t.size), _p(p), C.c_int64(p.size),
+                          C.c_int(nb), C.c_int(nc), C.c_double(sigma), _p(out))
+    return out
+
+
+def stringlength_scan(t, m, periods):
+    t, m, p = _f(t), _f(m), _f(periods)
+    out = np.empty(p.size)
+    lib().oracle_stringlength_scan(_p(t), _p(m), C.c_int64(t.size), _p(p), C.c_int64(p.size),
+                                   _p(out))
+    return out
+
+
+def gls_power_exact(t, values, err, frequency, fit_mean=True, psd=False):
+    """Reference prologue/epilogue (numpy restatement) around the C long-double sums."""
+    from . import scan_oracle as so
+    w, y, err = so.gls_weights(values, err, fit_mean)
+    f = _f(frequency)
+    Sh, Ch = trig_sums_exact(t, w * y, f)
+    # doubling a double is exact, so 2*f is the grid the 2-omega sums are defined on
+    S2, C2 = trig_sums_exact(t, w, 2 * f)
+    S, Cc = trig_sums_exact(t, w, f) if fit_mean else (None, None)
+    return so.gls_epilogue(Sh, Ch, S2, C2, S, Cc, np.dot(w, y ** 2), fit_mean, psd, err)

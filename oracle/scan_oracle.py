@@ -101,7 +101,9 @@ def trig_sum_fft(t, h, df, nf, fmin, oversampling=5):
         np.add.at(grid, lo + m, full / (const * (pos - (lo + m))))
     spec = np.fft.ifft(grid)[:nf]
     if tmin != 0:
-        spec = spec * np.exp(2j * np.pi * tmin * (fmin + df * np.arange(nf)))
+        # in place on the truncated view, as upstream: numpy's complex multiply rounds the last
+        # bit differently for a fresh output array (SIMD body vs. peeled elements)
+        spec *= np.exp(2j * np.pi * tmin * (fmin + df * np.arange(nf)))
     return nfft * spec.imag, nfft * spec.real
 
 

@@ -1,0 +1,261 @@
+"""GPU parity tests of the Lomb-Scargle path, all through the C ABI (ctypes).
+
+Tier E: power within 1e-6 relative of the long-double exact-sum oracle at every well-conditioned
+bin.  Tier R: peak bin identical to the unmodified reference (golden ``power_ref``)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import scan_oracle as so
+from periodicity_amd import _cabi
+from periodicity_amd.core import FSeries, TSeries
+from periodicity_amd.spectral import GLS, LombScargle
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6  # BASELINE.json north_star: "<= 1e-6 relative in fp64"
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def assert_tier_e(power, exact, rtol=RTOL, floor=1e-13):
+    """Relative parity on every bin whose exact power is above ``floor`` x the spectrum's maximum
+    (bins that are exact zeros / 0-over-0 singularities carry only rounding noise in any
+    implementation, the oracle's included)."""
+    exact = np.asarray(exact)
+    ok = np.abs(exact) > floor * np.nanmax(np.abs(exact))
+    assert ok.mean() > 0.99
+    rel = np.abs(power[ok] - exact[ok]) / np.abs(exact[ok])
+    assert rel.max() <= rtol, rel.max()
+    return rel.max()
+
+
+def synth(n, seed, period=37.3, t_offset=0.0):
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(0, float(n), n)) + t_offset
+    dy = rng.uniform(0.05, 0.2, n)
+    y = 1.0 + 0.5 * np.sin(2 * np.pi * t / period) + dy * rng.standard_normal(n)
+    return t, y, dy
+
+
+def test_device_is_gfx950():
+    info = _cabi.device_info(0)
+    assert "gfx950" in info["name"] and info["cu_count"] == 256
+
+
+def test_reference_test_default_grid():
+    # /root/reference/tests/test_spectral.py:7-24, verbatim assertions, through the GPU class
+    t0, ts = 2.5, 0.1
+    fs, f0 = 1 / ts, 1 / t0
+    ls = GLS(n=1)(TSeries(np.arange(0, t0 + ts, ts)))
+    freq = ls.frequency
+    assert sorted(freq) == list(freq)
+    assert freq[0] == f0 / 2
+    assert np.round(freq[-1], 6) == fs / 2
+    assert np.max(np.abs(np.diff(freq) - f0)) < 1e-10
+    assert ls.values.shape == freq.shape
+
+
+def test_reference_test_can_find_periods(golden_dir):
+    # /root/reference/tests/test_spectral.py:27-31
+    sine = TSeries(values=np.sin((np.arange(100) / 100) * 20 * np.pi))
+    ls = LombScargle()(sine)
+    assert ls.period_at_highest_peak == 10.0
+    g = load(golden_dir, "g2_sine100")
+    assert np.array_equal(ls.frequency, g["frequency"])
+    assert ls.argmax() == int(g["argmax"]) == 49
+    ok = np.abs(g["power_exact"]) > 1e-20
+    ok[-1] = False  # Nyquist bin of integer times: 0/0
+    rel = np.abs(ls.values[ok] - g["power_exact"][ok]) / np.abs(g["power_exact"][ok])
+    assert rel.max() <= RTOL
+
+
+@pytest.mark.parametrize("fit_mean", [True, False])
+@pytest.mark.parametrize("psd", [False, True])
+def test_spotted_star_all_flags(golden_dir, fit_mean, psd):
+    g = load(golden_dir, "g3_spotted_star")
+    gls = GLS(psd=psd)
+    ls = gls(TSeries(g["t"], g["y"]), err=g["dy"], fit_mean=fit_mean)
+    tag = f"fm{int(fit_mean)}_psd{int(psd)}"
+    assert np.array_equal(ls.frequency, g["frequency"])
+    assert_tier_e(ls.values, g["power_exact_" + tag])
+    ref = g["power_ref_" + tag]
+    assert ls.argmax() == int(np.nanargmax(ref))                       # tier R: same peak bin
+    assert ls.pmax() == FSeries(g["frequency"], ref).pmax()            # identical double
+    assert gls.periodogram is ls and gls.signal.size == g["t"].size
+    assert np.array_equal(gls.err, g["dy"]) and np.array_equal(gls.frequency, g["frequency"])
+
+
+def test_spotted_star_without_errors(golden_dir):
+    g = load(golden_dir, "g3_spotted_star")
+    gls = GLS()
+    ls = gls(TSeries(g["t"], g["y"]))
+    assert_tier_e(ls.values, g["power_exact_noerr"])
+    assert ls.argmax() == int(np.nanargmax(g["power_ref_noerr"]))
+    assert np.array_equal(gls.err, np.ones_like(g["y"]))               # spectral.py:99-101
+
+
+@pytest.mark.parametrize("n", [1000, 5000])
+def test_synthetic_power_and_seams(golden_dir, n):
+    g = load(golden_dir, f"g4_synth{n}")
+    t, y, dy, f = g["t"], g["y"], g["dy"], g["frequency"]
+    ls = GLS()(TSeries(t, y), err=dy)
+    assert np.array_equal(ls.frequency, f)
+    assert_tier_e(ls.values, g["power_exact"])
+    assert ls.argmax() == int(np.nanargmax(g["power_ref"]))
+    # seam level: _trig_sum(t, w*y, df, nf, fmin) and _trig_sum(t, w, 2df, nf, 2fmin)
+    w, yc, _ = so.gls_weights(y, dy, True)
+    f0, delta, nf = _cabi.grid_params(f)
+    for h, sname, cname, scale in ((w * yc, "Sh_exact", "Ch_exact", 1), (w, "S_exact", "C_exact", 1),
+                                   (w, "S2_exact", "C2_exact", 2)):
+        S, C = _cabi.trig_sums(t, h, scale * f0, scale * delta, nf)
+        amp = np.max(np.hypot(g[sname], g[cname]))
+        assert np.max(np.abs(S - g[sname])) <= 1e-9 * amp
+        assert np.max(np.abs(C - g[cname])) <= 1e-9 * amp
+
+
+def test_window_and_model(golden_dir):
+    g = load(golden_dir, "g5_window")
+    gls = GLS()
+    gls(TSeries(g["t"], g["y"]), err=g["dy"])
+    win = gls.window()
+    assert np.array_equal(win.frequency, g["frequency"])
+    assert_tier_e(win.values, g["power_exact"], floor=1e-9)
+    assert win.argmax() == int(np.nanargmax(g["power_ref"]))
+    fit = gls.model(g["t"], 1 / 37.3)
+    assert fit.size == g["t"].size and abs(np.std(fit.values) - 0.5 / np.sqrt(2)) < 0.05
+
+
+def test_bootstrap_fap_fal(golden_dir):
+    g = load(golden_dir, "g6_bootstrap")
+    gls = GLS()
+    gls(TSeries(g["t"], g["y"]), err=g["dy"])
+    reps = gls.bootstrap(20, random_seed=42)
+    np.testing.assert_allclose(reps, g["replicates_exact"], rtol=RTOL)
+    np.testing.assert_allclose(reps, g["replicates_ref"], rtol=0, atol=5e-4)  # FFT-path error
+    assert gls.fap(0.3) == float(g["fap_at_0p3_exact"])
+    np.testing.assert_allclose(gls.fal(0.1), float(g["fal_at_0p1_exact"]), rtol=RTOL)
+
+
+def test_batch_ragged_equals_single_and_peaks():
+    rng = np.random.default_rng(11)
+    lens = [1, 2, 255, 256, 257, 1000, 3, 777]
+    curves = [synth(n, 100 + i, period=5.0 + i) for i, n in enumerate(lens)]
+    offsets = np.concatenate([[0], np.cumsum(lens)])
+    t = np.concatenate([c[0] for c in curves])
+    y = np.concatenate([c[1] for c in curves])
+    dy = np.concatenate([c[2] for c in curves])
+    freq = np.arange(0.0007, 0.5, 0.00037)
+    f0, delta, nf = _cabi.grid_params(freq)
+    power, amax, argmax = _cabi.gls_scan_batch(t, y, dy, offsets, f0, delta, nf,
+                                               want_power=True, want_peaks=True)
+    for b, (tb, yb, dyb) in enumerate(curves):
+        single = _cabi.gls_scan(tb, yb, dyb, f0, delta, nf)
+        assert np.array_equal(single, power[b], equal_nan=True)
+        if np.all(np.isnan(single)):
+            assert argmax[b] == -1 and np.isnan(amax[b])
+        else:
+            assert argmax[b] == np.nanargmax(single) and amax[b] == np.nanmax(single)
+    _, amax2, argmax2 = _cabi.gls_scan_batch(t, y, dy, offsets, f0, delta, nf,
+                                             want_power=False, want_peaks=True)
+    assert np.array_equal(amax, amax2, equal_nan=True) and np.array_equal(argmax, argmax2)
+    big = curves[5]
+    exact = co.gls_power_exact(big[0], big[1], big[2], freq)
+    assert_tier_e(power[5], exact)
+    del rng
+
+
+def test_shared_time_axis_batch():
+    t, y, dy = synth(400, 5)
+    rng = np.random.default_rng(3)
+    picks = rng.integers(0, 400, (6, 400))
+    offsets = np.arange(7) * 400
+    freq = np.arange(0.001, 0.4, 0.0009)
+    f0, delta, nf = _cabi.grid_params(freq)
+    power, _, _ = _cabi.gls_scan_batch(t, y[picks].ravel(), dy[picks].ravel(), offsets, f0, delta,
+                                       nf, shared_t=True)
+    for b in range(6):
+        single = _cabi.gls_scan(t, y[picks[b]], dy[picks[b]], f0, delta, nf)
+        assert np.array_equal(single, power[b])
+
+
+def test_slabs_tile_the_grid_bitwise():
+    t, y, dy = synth(3000, 21)
+    freq = np.arange(0.0001, 0.9, 0.00011)
+    f0, delta, nf = _cabi.grid_params(freq)
+    full = _cabi.gls_scan(t, y, dy, f0, delta, nf)
+    cuts = [0, 1, 2047, 2048, 5000, nf]
+    parts = [_cabi.gls_scan(t, y, dy, f0, delta, b - a, j_begin=a) for a, b in zip(cuts, cuts[1:])]
+    stitched = np.concatenate(parts)
+    # a slab starts its rotation recurrence at its own first frequency, so agreement is to
+    # rounding, not bitwise; the first bin of each slab is seeded directly in both runs
+    np.testing.assert_allclose(stitched, full, rtol=1e-10)
+    multi = _cabi.gls_scan_multi(t, y, dy, f0, delta, nf, devices=(0,))
+    assert np.array_equal(multi, full)
+    ls = GLS(fmin=freq[0], fmax=freq[-1], n=1 / ((t[-1] - t[0]) * 0.00011), devices=(0,))
+    assert ls(TSeries(t, y), err=dy).size > 0
+
+
+def test_large_time_offset_is_harmless():
+    # Kepler-style barycentric dates: f*t spans ~1e7 cycles, the phase must not lose bits
+    t, y, dy = synth(2000, 33)
+    freq = np.arange(0.001, 2.0, 0.0021)
+    f0, delta, nf = _cabi.grid_params(freq)
+    p0 = _cabi.gls_scan(t, y, dy, f0, delta, nf)
+    p1 = _cabi.gls_scan(t + 2454953.5, y, dy, f0, delta, nf)
+    np.testing.assert_allclose(p1, p0, rtol=1e-7)
+    to = t + 2454953.5
+    S, C = _cabi.trig_sums(to, dy ** -2.0, f0, delta, nf)
+    Se, Ce = co.trig_sums_exact(to, dy ** -2.0, freq)
+    amp = np.max(np.hypot(Se, Ce))
+    assert np.max(np.abs(S - Se)) <= 1e-9 * amp and np.max(np.abs(C - Ce)) <= 1e-9 * amp
+
+
+def test_edge_cases():
+    t, y, dy = synth(50, 1)
+    assert _cabi.gls_scan(t, y, dy, 0.01, 0.01, 0).size == 0                # empty grid
+    p = _cabi.gls_scan(t, y, dy, 0.3, 0.0, 1)                                  # one frequency
+    assert p.shape == (1,) and np.isfinite(p[0])
+    ynan = y.copy()
+    ynan[7] = np.nan                                                           # NaN propagates
+    assert np.all(np.isnan(_cabi.gls_scan(t, ynan, dy, 0.01, 0.01, 64)))
+    with pytest.raises(ValueError):
+        _cabi.gls_scan(t, y[:-1], dy, 0.01, 0.01, 8)
+    with pytest.raises(ValueError):
+        GLS()(TSeries(t, y), err=dy[:-1])
+    with pytest.raises(ValueError):
+        TSeries([1, 2], [1, 2, 3])
+    raw = GLS()(y)                                                             # spectral.py:86-87
+    assert np.array_equal(raw.frequency, GLS()(TSeries(values=y)).frequency)
+    one = _cabi.gls_scan(t[:1], y[:1], dy[:1], 0.01, 0.01, 4)                # single sample: 0/0
+    assert one.shape == (4,)
+
+
+def test_full_size_c2_properties():
+    """BASELINE configs[1] at full size (1e11 pairs): a random subset of bins against the exact
+    oracle, plus invariances the domain offers (amplitude scaling, slab consistency)."""
+    n, nf = 100_000, 1_000_000
+    t, y, dy = synth(n, 20241010)
+    df = 1.0 / (t[-1] - t[0]) / 5
+    fmin = 0.5 * df
+    freq = np.arange(fmin, fmin + (nf - 1.5) * df + df, df)
+    assert freq.size == nf
+    f0, delta, _ = _cabi.grid_params(freq)
+    power = _cabi.gls_scan(t, y, dy, f0, delta, nf)
+    assert np.all(np.isfinite(power)) and power.min() >= -1e-12 and power.max() <= 1 + 1e-9
+    peak = int(np.argmax(power))
+    assert abs(1 / freq[peak] - 37.3) < 0.01
+    rng = np.random.default_rng(0)
+    pick = np.unique(np.concatenate([rng.integers(0, nf, 96), [0, nf - 1, peak, peak + 1]]))
+    exact = co.gls_power_exact(t, y, dy, freq[pick])
+    rel = np.abs(power[pick] - exact) / np.abs(exact)
+    assert rel.max() <= RTOL, rel.max()
+    # normalised power is invariant under y -> a*y + b
+    again = _cabi.gls_scan(t, 3.0 * y - 7.0, 3.0 * dy, f0, delta, nf)
+    np.testing.assert_allclose(again, power, rtol=1e-7, atol=1e-14)
+    # a slab cut out of the middle reproduces the same bins
+    part = _cabi.gls_scan(t, y, dy, f0, delta, 4096, j_begin=500_000)
+    np.testing.assert_allclose(part, power[500_000:504_096], rtol=1e-9)

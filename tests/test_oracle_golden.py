@@ -1,0 +1,139 @@
+"""The oracle against the golden vectors generated from the reference's own code
+(tests/golden/make_golden.py), including both known-answer tests of
+/root/reference/tests/test_spectral.py.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import scan_oracle as so
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def test_reference_grid_known_answer(golden_dir):
+    # tests/test_spectral.py:7-24
+    g = load(golden_dir, "g1_grid")
+    t0, ts = 2.5, 0.1
+    freq, df, fmin = so.gls_grid(g["time"], n=1)
+    assert np.array_equal(freq, g["frequency"])
+    assert sorted(freq) == list(freq)
+    assert freq[0] == (1 / t0) / 2
+    assert np.round(freq[-1], 6) == (1 / ts) / 2
+    assert np.max(np.abs(np.diff(freq) - 1 / t0)) < 1e-10
+
+
+def test_reference_sine_known_answer(golden_dir):
+    # tests/test_spectral.py:27-31: period_at_highest_peak == 10.0 exactly, index 49 of 248
+    from periodicity_amd.core import FSeries
+    g = load(golden_dir, "g2_sine100")
+    freq, power = so.gls(np.arange(100), g["values"])
+    assert np.array_equal(freq, g["frequency"]) and freq.size == 248
+    assert np.array_equal(power, g["power_ref"])
+    assert int(np.nanargmax(power)) == int(g["argmax"]) == 49
+    assert FSeries(freq, power).period_at_highest_peak == 10.0 == float(g["period_at_highest_peak"])
+    exact = so.gls(np.arange(100), g["values"], sums="exact")[1]
+    # integer times: bin 148 is an exact zero and the last bin sits on the Nyquist singularity
+    # (sin(pi t) == 0 -> 0/0), both pure rounding noise in any implementation
+    ok = np.abs(g["power_exact"]) > 1e-20
+    ok[-1] = False
+    np.testing.assert_allclose(exact[ok], g["power_exact"][ok], rtol=1e-9)
+    assert int(np.nanargmax(exact)) == 49
+
+
+@pytest.mark.parametrize("fit_mean", [True, False])
+@pytest.mark.parametrize("psd", [False, True])
+def test_spotted_star_fft_path_is_bit_exact(golden_dir, fit_mean, psd):
+    g = load(golden_dir, "g3_spotted_star")
+    freq, power = so.gls(g["t"], g["y"], g["dy"], fit_mean=fit_mean, psd=psd)
+    assert np.array_equal(freq, g["frequency"])
+    assert np.array_equal(power, g[f"power_ref_fm{int(fit_mean)}_psd{int(psd)}"])
+
+
+def test_spotted_star_exact_path(golden_dir):
+    g = load(golden_dir, "g3_spotted_star")
+    sel = slice(0, 1500)
+    f = g["frequency"]
+    for fm in (True, False):
+        p = co.gls_power_exact(g["t"], g["y"], g["dy"], f[sel], fit_mean=fm)
+        np.testing.assert_allclose(p, g[f"power_exact_fm{int(fm)}_psd0"][sel], rtol=2e-8)
+    p = co.gls_power_exact(g["t"], g["y"], None, f[sel])
+    np.testing.assert_allclose(p, g["power_exact_noerr"][sel], rtol=2e-8)
+    # tier R fact: the approximate and the exact spectrum peak in the same bin
+    assert np.argmax(g["power_exact_fm1_psd0"]) == np.argmax(g["power_ref_fm1_psd0"])
+
+
+@pytest.mark.parametrize("n", [1000, 5000])
+def test_synthetic_seams_and_power(golden_dir, n):
+    g = load(golden_dir, f"g4_synth{n}")
+    t, y, dy, f = g["t"], g["y"], g["dy"], g["frequency"]
+    df, fmin = float(g["df"]), float(g["fmin"])
+    w, yc, _ = so.gls_weights(y, dy, True)
+    S, C = so.trig_sum_fft(t, w, df, f.size, fmin)
+    assert np.array_equal(S, g["S_fft"]) and np.array_equal(C, g["C_fft"])
+    Sh, Ch = so.trig_sum_fft(t, w * yc, df, f.size, fmin)
+    assert np.array_equal(Sh, g["Sh_fft"]) and np.array_equal(Ch, g["Ch_fft"])
+    S2, C2 = so.trig_sum_fft(t, w, 2 * df, f.size, 2 * fmin)
+    assert np.array_equal(S2, g["S2_fft"]) and np.array_equal(C2, g["C2_fft"])
+    assert np.array_equal(so.gls(t, y, dy)[1], g["power_ref"])
+    sel = slice(0, 600)
+    Se, Ce = so.trig_sum_exact(t, w * yc, f[sel])
+    np.testing.assert_allclose(Se, g["Sh_exact"][sel], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(Ce, g["Ch_exact"][sel], rtol=0, atol=1e-13)
+    Sc, Cc = co.trig_sums_exact(t, w * yc, f[sel])
+    np.testing.assert_allclose(Sc, Se, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(Cc, Ce, rtol=0, atol=1e-15)
+    p = co.gls_power_exact(t, y, dy, f)
+    np.testing.assert_allclose(p, g["power_exact"], rtol=1e-8)
+
+
+def test_window_and_bootstrap(golden_dir):
+    g = load(golden_dir, "g5_window")
+    freq, df, fmin = so.gls_grid(g["t"])
+    p = so.gls_power(g["t"], np.ones_like(g["t"]), None, freq, df, fmin, fit_mean=False)
+    assert np.array_equal(p, g["power_ref"])
+    g = load(golden_dir, "g6_bootstrap")
+    reps = so.gls_bootstrap_maxima(g["t"], g["y"], g["dy"], 20, random_seed=42)
+    assert np.array_equal(reps, g["replicates_ref"])
+    assert np.mean(0.3 < reps) == float(g["fap_at_0p3_ref"])
+    assert np.quantile(reps, 0.9) == float(g["fal_at_0p1_ref"])
+
+
+@pytest.mark.parametrize("nb,nc", [(5, 2), (10, 3)])
+def test_pdm_seam_and_call(golden_dir, nb, nc):
+    g = load(golden_dir, "g7_pdm")
+    periods = g[f"periods_{nb}_{nc}"]
+    theta = so.pdm_scan(g["t"], g["y"], periods, nb, nc)
+    assert np.array_equal(theta, g[f"theta_seam_{nb}_{nc}"])
+    freq, th = so.pdm(g["t"], g["y"], nb, nc, p_min=1.0, p_max=60.0, n_periods=200)
+    assert np.array_equal(freq, g[f"frequency_{nb}_{nc}"])
+    assert np.array_equal(th, g[f"theta_call_{nb}_{nc}"])
+    np.testing.assert_allclose(co.pdm_scan(g["t"], g["y"], periods, nb, nc), theta, rtol=1e-13)
+
+
+def test_pdm_variants(golden_dir):
+    g = load(golden_dir, "g7_pdm")
+    freq, th = so.pdm(g["t"], g["y"], p_min=1.0, p_max=60.0, n_periods=200, do_subharmonic=True)
+    assert np.array_equal(freq, g["frequency_sub"]) and np.array_equal(th, g["theta_call_sub"])
+    freq, th = so.pdm(g["t"], g["y"], n_periods=150)
+    assert np.array_equal(freq, g["frequency_default"])
+    assert np.array_equal(th, g["theta_call_default"])
+    freq, th = so.pdm(g["t_negative"], g["y"], p_min=1.0, p_max=60.0, n_periods=200)
+    assert np.array_equal(th, g["theta_call_negative"])
+    assert float(g["sigma"]) == np.var(g["y"], ddof=1)
+
+
+def test_stringlength_seam(golden_dir):
+    g = load(golden_dir, "g8_stringlength")
+    assert np.array_equal(so.stringlength_scale(g["y"]), g["m"])
+    assert np.array_equal(so.stringlength_periods(g["t"][-1] - g["t"][0], 0.1, 200), g["periods"])
+    assert np.array_equal(so.stringlength_scan(g["t"], g["m"], g["periods"]), g["ell"])
+    assert np.array_equal(so.stringlength_scan(g["t_even"], g["m_even"], g["periods_even"]),
+                          g["ell_even"])
+    np.testing.assert_allclose(co.stringlength_scan(g["t"], g["m"], g["periods"]), g["ell"],
+                               rtol=1e-13)
+    np.testing.assert_allclose(co.stringlength_scan(g["t_even"], g["m_even"], g["periods_even"]),
+                               g["ell_even"], rtol=1e-13)
