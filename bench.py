@@ -58,8 +58,13 @@ def cpu_baseline(t, y, dy, freq, df, fmin):
     t0 = time.perf_counter()
     p_fft = so.gls_power(t, y, dy, freq, df, fmin, True, False, sums="fft")
     dt_fft = time.perf_counter() - t0
-    cores = os.cpu_count() or 1
-    n_s, nf_s = 10_000, 2_000 * cores
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    co.set_threads(cores)
+    n_s, nf_s = 10_000, 8 * cores
+    t0 = time.perf_counter()
+    co.trig_sums_exact(t[:n_s], dy[:n_s], freq[:nf_s])      # calibration pass (also warms OpenMP)
+    probe = max(time.perf_counter() - t0, 1e-3)
+    nf_s = int(min(freq.size, max(nf_s, nf_s * 10.0 / probe)))  # aim at ~10 s of CPU work
     t0 = time.perf_counter()
     co.trig_sums_exact(t[:n_s], dy[:n_s], freq[:nf_s])
     dt_direct = time.perf_counter() - t0

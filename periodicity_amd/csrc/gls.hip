@@ -7,13 +7,14 @@
 // Decomposition
 //   gls_prep_kernel   one workgroup per light curve: weights (spectral.py:99-108), YY (:120) and
 //                     one 48-byte record per sample {t - t0, w*y, w, cos(2 pi delta t'),
-//                     sin(2 pi delta t'), 0}.
+//                     sin(2 pi delta t'), 2 cos(2 pi delta t')}.
 //   gls_scan_kernel   each thread owns K consecutive trial frequencies; the workgroup streams the
 //                     curve's records once through LDS (coalesced 16-byte loads, register
 //                     prefetch of the next chunk) and every lane reads each record as an LDS
 //                     broadcast.  Per (sample, thread): ONE software sincos at the tile's first
-//                     frequency (phase carried in cycles with an exact fma product), then K-1
-//                     plane rotations by the per-sample angle 2 pi delta t' walk the uniform
+//                     frequency (phase carried in cycles with an exact fma product), then one
+//                     plane rotation by the per-sample angle 2 pi delta t' and K-2 steps of the
+//                     three-term recurrence x[k+1] = 2cos(theta) x[k] - x[k-1] walk the uniform
 //                     grid; 6 running sums per frequency (Sh, Ch, S, C, sum w s^2, sum w s c —
 //                     the 2-omega sums follow from the double-angle identities).  The epilogue
 //                     (spectral.py:113-132) is fused, so only power[nf] is written.
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void gls_prep_kernel(PrepArgs a) {
         double2 *r = reinterpret_cast<double2 *>(rec + i * 6);
         r[0] = make_double2(tp, wy);
         r[1] = make_double2(w, cd);
-        r[2] = make_double2(sd, 0.0);
+        r[2] = make_double2(sd, cd + cd);
     }
     yy = block_sum_256(yy, red);
     wsum = block_sum_256(wsum, red);
@@ -213,10 +214,12 @@ __global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
         for (int i = 0; i < cnt; ++i) {
             const double2 r0 = *reinterpret_cast<const double2 *>(recs + i * 6);
             const double2 r1 = *reinterpret_cast<const double2 *>(recs + i * 6 + 2);
-            const double sd = recs[i * 6 + 4];
-            const double t = r0.x, wy = r0.y, w = r1.x, cd = r1.y;
+            const double2 r2 = *reinterpret_cast<const double2 *>(recs + i * 6 + 4);
+            const double t = r0.x, wy = r0.y, w = r1.x, cd = r1.y, sd = r2.x, cd2 = r2.y;
+            // k = 0: one software sincos at this thread's first frequency
             double s, c;
-            sincos_cycles(frac_product(fb, t), s, c);
+            sincos_cycles_half(frac_product(fb, t), s, c);
+            double sp = 0.0, cp = 0.0;  // previous step of the recurrence
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 Sh[k] = __builtin_fma(wy, s, Sh[k]);
@@ -230,9 +233,20 @@ __global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
                     SS[k] = __builtin_fma(ws, s, SS[k]);
                     SC[k] = __builtin_fma(ws, c, SC[k]);
                 }
-                if (k + 1 < K) {  // advance one grid step: rotate by 2 pi delta t'
-                    const double cn = __builtin_fma(c, cd, -(s * sd));
-                    const double sn = __builtin_fma(s, cd, c * sd);
+                if (k + 1 < K) {
+                    double sn, cn;
+                    if (k == 0) {
+                        // first grid step: plane rotation by 2 pi delta t'
+                        cn = __builtin_fma(c, cd, -(s * sd));
+                        sn = __builtin_fma(s, cd, c * sd);
+                    } else {
+                        // later steps: x[k+1] = 2 cos(theta) x[k] - x[k-1]  (1 fma per component;
+                        // rounding grows like K^2 eps, far below the 1e-6 gate for K <= 16)
+                        cn = __builtin_fma(cd2, c, -cp);
+                        sn = __builtin_fma(cd2, s, -sp);
+                    }
+                    cp = c;
+                    sp = s;
                     c = cn;
                     s = sn;
                 }

@@ -92,6 +92,42 @@ __device__ __forceinline__ void sincos_cycles(double r, double &s, double &c) {
     c = __longlong_as_double(__double_as_longlong(c1) ^ cflip);
 }
 
+// Hot-loop variant for |r| <= 0.5 cycle (always true after frac_product): evaluate at a quarter of
+// the angle, where |a| <= pi/4 needs no quadrant logic, then double the angle twice
+// (sin 2a = 2 s c, cos 2a = 1 - 2 s^2).  All fp64 VALU, no integer/select instructions; the two
+// doublings cost 8 ops and keep the absolute error at a few 1e-16.
+__device__ __forceinline__ void sincos_cycles_half(double r, double &s, double &c) {
+    const double x = r * 1.570796326794896619231;          // (2 pi r) / 4
+    // Polynomials summed term by term over explicit powers of x^2 (not Horner): every step is an
+    // accumulate-into-self fma with a constant source, which hipcc emits as one v_fmac_f64 with
+    // no register copy (Horner needs the constant in the destination: a v_mov_b64 per step), and
+    // the two chains are short and independent.
+    const double x2 = x * x;
+    const double x4 = x2 * x2;
+    const double x6 = x4 * x2;
+    const double x8 = x4 * x4;
+    const double x10 = x8 * x2;
+    double ps = __builtin_fma(8.33333333332248946124e-03, x2, -1.66666666666666324348e-01);
+    ps = __builtin_fma(-1.98412698298579493134e-04, x4, ps);
+    ps = __builtin_fma(2.75573137070700676789e-06, x6, ps);
+    ps = __builtin_fma(-2.50507602534068634195e-08, x8, ps);
+    ps = __builtin_fma(1.58969099521155010221e-10, x10, ps);
+    const double s1 = __builtin_fma(x * x2, ps, x);
+    double pc = __builtin_fma(-1.38888888888741095749e-03, x2, 4.16666666666666019037e-02);
+    pc = __builtin_fma(2.48015872894767294178e-05, x4, pc);
+    pc = __builtin_fma(-2.75573143513906633035e-07, x6, pc);
+    pc = __builtin_fma(2.08757232129817482790e-09, x8, pc);
+    pc = __builtin_fma(-1.13596475577881948265e-11, x10, pc);
+    const double c1 = __builtin_fma(x4, pc, __builtin_fma(-0.5, x2, 1.0));
+    // angle doubling, twice
+    double sc = s1 * c1;
+    const double c2 = __builtin_fma(-2.0 * s1, s1, 1.0);
+    const double s2 = sc + sc;
+    sc = s2 * c2;
+    c = __builtin_fma(-2.0 * s2, s2, 1.0);
+    s = sc + sc;
+}
+
 // frac(a*b) in (-0.5, 0.5] cycles with the product carried exactly (fma error term), so the
 // phase stays accurate to ~1e-16 cycle however many whole cycles a*b spans.
 __device__ __forceinline__ double frac_product(double a, double b) {
