@@ -1,0 +1,179 @@
+"""GPU parity tests of the phase-folding scans (PDM, StringLength) through the C ABI.
+
+fp64 tolerance: the discrete decisions (bin membership, sort order) are reproduced exactly, so
+what is left is summation order: 1e-9 relative is the gate (observed ~1e-13)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import scan_oracle as so
+from periodicity_amd import _cabi
+from periodicity_amd.core import TSeries
+from periodicity_amd.phase import PDM, StringLength
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def synth(n, seed, period=13.7):
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(0, float(n), n))
+    y = 1.0 + 0.5 * np.sin(2 * np.pi * t / period) + 0.1 * rng.standard_normal(n)
+    return t, y
+
+
+# ---- PDM -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nb,nc", [(5, 2), (10, 3)])
+def test_pdm_seam_and_call_golden(golden_dir, nb, nc):
+    g = load(golden_dir, "g7_pdm")
+    periods = g[f"periods_{nb}_{nc}"]
+    theta = _cabi.pdm_scan(g["t"], g["y"], periods, nb, nc, float(g["sigma"]))
+    np.testing.assert_allclose(theta, g[f"theta_seam_{nb}_{nc}"], rtol=RTOL)
+    pdm = PDM(nb=nb, nc=nc, p_min=1.0, p_max=60.0, n_periods=200, cores=1)
+    res = pdm(TSeries(g["t"], g["y"]))
+    assert np.array_equal(res.frequency, g[f"frequency_{nb}_{nc}"])
+    np.testing.assert_allclose(res.values, g[f"theta_call_{nb}_{nc}"], rtol=RTOL)
+    assert np.array_equal(pdm.periods, periods) and pdm.sigma == float(g["sigma"])
+    assert pdm.periodogram is res and pdm.signal.size == g["t"].size
+    np.testing.assert_allclose(pdm._pdm(periods[17]), g[f"theta_seam_{nb}_{nc}"][17], rtol=RTOL)
+
+
+def test_pdm_variants_golden(golden_dir):
+    g = load(golden_dir, "g7_pdm")
+    sig = TSeries(g["t"], g["y"])
+    res = PDM(p_min=1.0, p_max=60.0, n_periods=200, do_subharmonic=True)(sig)
+    assert np.array_equal(res.frequency, g["frequency_sub"])
+    np.testing.assert_allclose(res.values, g["theta_call_sub"], rtol=RTOL)
+    res = PDM(n_periods=150)(sig)                       # default p_min / p_max
+    assert np.array_equal(res.frequency, g["frequency_default"])
+    np.testing.assert_allclose(res.values, g["theta_call_default"], rtol=RTOL)
+    res = PDM(p_min=1.0, p_max=60.0, n_periods=200)(TSeries(g["t_negative"], g["y"]))
+    np.testing.assert_allclose(res.values, g["theta_call_negative"], rtol=RTOL)
+    # theta has its minimum at the injected period
+    res = PDM(p_min=1.0, p_max=60.0, n_periods=200)(sig)
+    ratio = res.period[np.argmin(res.values)] / 13.7     # the injected period or a multiple of it
+    assert abs(ratio - round(ratio)) < 0.03
+
+
+def test_pdm_shapes_and_edges():
+    t, y = synth(3000, 4)
+    sigma = np.var(y, ddof=1)
+    for nb, nc, n_per in ((5, 2, 1), (7, 7, 300), (10, 5, 257), (19, 10, 70), (1, 1, 5), (3, 1, 64)):
+        periods = np.linspace(0.9, 77.0, n_per)
+        got = _cabi.pdm_scan(t, y, periods, nb, nc, sigma)
+        want = so.pdm_scan(t, y, periods, nb, nc)
+        np.testing.assert_allclose(got, want, rtol=RTOL, err_msg=f"{nb}x{nc}")
+    # samples on and next to bin edges, phases that round to exactly 1.0, negative times
+    te = np.array([-1e-20, -0.75, 0.0, 0.2, 0.4, 0.6000000000000001, 0.8, 1.0, 1.2, 2.0 - 1e-16,
+                   3.0, 5.5, -7.25, 10.0, 0.1, 0.30000000000000004])
+    ye = np.cos(np.arange(te.size)) + 0.01 * np.arange(te.size)
+    pe = np.array([1.0, 2.0, 0.5, 0.2, 4.0, 1e-3, 3.3333333333333335, 1e6])
+    got = _cabi.pdm_scan(te, ye, pe, 5, 2, np.var(ye, ddof=1))
+    with np.errstate(all="ignore"):
+        want = so.pdm_scan(te, ye, pe, 5, 2)
+    np.testing.assert_allclose(got, want, rtol=RTOL, equal_nan=True)
+    assert _cabi.pdm_scan(t, y, np.empty(0), 5, 2, sigma).size == 0
+    with pytest.raises(ValueError):
+        _cabi.pdm_scan(t, y[:-1], [1.0], 5, 2, sigma)
+    with pytest.raises(ValueError):
+        _cabi.pdm_scan(t, y, [1.0], 50, 50, sigma)
+    raw = PDM(n_periods=40)(y)                            # phase.py:160-161: raw array-likes
+    assert raw.size == 40
+
+
+def test_pdm_mid_size_vs_c_oracle():
+    t, y = synth(20000, 9)
+    periods = np.linspace(1.0, 100.0, 1500)
+    got = _cabi.pdm_scan(t, y, periods, 5, 2, np.var(y, ddof=1))
+    want = co.pdm_scan(t, y, periods, 5, 2)
+    np.testing.assert_allclose(got, want, rtol=RTOL)
+
+
+# ---- StringLength ------------------------------------------------------------------------------
+def test_stringlength_seam_golden(golden_dir):
+    g = load(golden_dir, "g8_stringlength")
+    ell = _cabi.stringlength_scan(g["t"], g["m"], g["periods"])
+    np.testing.assert_allclose(ell, g["ell"], rtol=RTOL)
+    # evenly sampled: many bit-identical phases, the stable (time) order of ties matters
+    ell = _cabi.stringlength_scan(g["t_even"], g["m_even"], g["periods_even"])
+    np.testing.assert_allclose(ell, g["ell_even"], rtol=RTOL)
+
+
+def test_stringlength_call_matches_restated_reference(golden_dir):
+    g = load(golden_dir, "g8_stringlength")
+    sl = StringLength(n_periods=200, cores=1)
+    res = sl(TSeries(g["t"], g["y"]))
+    freq, ell = so.stringlength(g["t"], g["y"], n_periods=200)
+    assert np.array_equal(res.frequency, freq)
+    np.testing.assert_allclose(res.values, ell, rtol=RTOL)
+    assert np.array_equal(sl.m.values, g["m"]) and sl.periodogram is res
+    np.testing.assert_allclose(res.values[::-1], g["ell"], rtol=RTOL)   # ascending frequency
+    np.testing.assert_allclose(sl._stringlength(g["periods"][5]), g["ell"][5], rtol=RTOL)
+    assert abs(res.period[np.argmin(res.values)] / 13.7 - round(res.period[np.argmin(res.values)] / 13.7)) < 0.05
+
+
+def test_stringlength_clusters_take_the_scratch_path():
+    # 20000 evenly spaced samples folded at commensurate periods: every phase falls into a
+    # handful of values (one bucket holds > CAP samples) -> sorted in global scratch
+    t = np.arange(20000.0)
+    y = np.sin(2 * np.pi * t / 12.5) + 0.05 * np.cos(0.37 * t)
+    m = so.stringlength_scale(y)
+    periods = np.array([1.0, 2.0, 2.5, 4.0, 12.5, 3.0000000000000004, 7.3, 20000.0, 1e-3])
+    got = _cabi.stringlength_scan(t, m, periods)
+    want = co.stringlength_scan(t, m, periods)
+    np.testing.assert_allclose(got, want, rtol=RTOL)
+    np.testing.assert_allclose(got[:3], so.stringlength_scan(t, m, periods[:3]), rtol=RTOL)
+
+
+def test_stringlength_edges():
+    t, y = synth(700, 2)
+    m = so.stringlength_scale(y)
+    assert _cabi.stringlength_scan(t, m, np.empty(0)).size == 0
+    one = _cabi.stringlength_scan(t[:1], m[:1], [3.0])
+    assert one[0] == 0.0
+    two = _cabi.stringlength_scan(t[:2], m[:2], [3.0])
+    np.testing.assert_allclose(two, so.stringlength_scan(t[:2], m[:2], [3.0]), rtol=RTOL)
+    tn = t - 350.0                                        # negative times
+    np.testing.assert_allclose(_cabi.stringlength_scan(tn, m, [0.7, 13.7, 401.0]),
+                               so.stringlength_scan(tn, m, [0.7, 13.7, 401.0]), rtol=RTOL)
+    with pytest.raises(ValueError):
+        _cabi.stringlength_scan(t, m[:-1], [1.0])
+    for n in (4095, 4096, 4097, 9000):                    # around one LDS range
+        tt, yy = synth(n, n)
+        mm = so.stringlength_scale(yy)
+        pp = np.array([0.77, 13.7, 55.5])
+        np.testing.assert_allclose(_cabi.stringlength_scan(tt, mm, pp),
+                                   co.stringlength_scan(tt, mm, pp), rtol=RTOL)
+
+
+def test_phase_scans_full_size_c5():
+    """BASELINE configs[4]: N=5e4 samples x 1e5 trial periods, both scans, with a random subset
+    of periods against the C oracle and invariances of the statistics."""
+    n, n_per = 50_000, 100_000
+    t, y = synth(n, 20241012)
+    periods = np.linspace(1.0, 100.0, n_per)
+    sigma = np.var(y, ddof=1)
+    theta = _cabi.pdm_scan(t, y, periods, 5, 2, sigma)
+    assert np.all(np.isfinite(theta)) and theta.min() > 0 and theta.max() < 1.5
+    assert abs(periods[np.argmin(theta)] / 13.7 - round(periods[np.argmin(theta)] / 13.7)) < 0.01
+    rng = np.random.default_rng(1)
+    pick = np.unique(np.concatenate([rng.integers(0, n_per, 40), [0, n_per - 1, int(np.argmin(theta))]]))
+    np.testing.assert_allclose(theta[pick], co.pdm_scan(t, y, periods[pick], 5, 2), rtol=RTOL)
+    # theta is invariant under x -> a*x + b (sigma scales with it)
+    again = _cabi.pdm_scan(t, 2.5 * y - 3.0, periods[:4096], 5, 2, 2.5 ** 2 * sigma)
+    np.testing.assert_allclose(again, theta[:4096], rtol=1e-8)
+
+    m = so.stringlength_scale(y)
+    df = 0.1 / (t[-1] - t[0])
+    sl_periods = 1 / np.linspace(n_per * df, df, n_per)
+    ell = _cabi.stringlength_scan(t, m, sl_periods)
+    assert np.all(np.isfinite(ell)) and ell.min() > 0
+    np.testing.assert_allclose(ell[pick], co.stringlength_scan(t, m, sl_periods[pick]), rtol=RTOL)
+    # the closed polygon is at least twice the phase span plus twice the value span
+    assert ell.min() >= 2 * (m.max() - m.min())
