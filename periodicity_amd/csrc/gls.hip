@@ -32,6 +32,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kChunk = 256;  // samples staged in LDS per step (12 KiB)
+constexpr int kPrepBlock = 1024;
 
 enum Mode { MODE_FIT_MEAN = 0, MODE_NO_MEAN = 1, MODE_RAW = 2 };
 
@@ -60,8 +61,8 @@ struct PrepArgs {
 };
 
 // ---- prologue: spectral.py:99-108, 120 ------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void gls_prep_kernel(PrepArgs a) {
-    __shared__ double red[4];
+__global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
+    __shared__ double red[kPrepBlock / 64];
     const int tid = threadIdx.x;
     const int64_t off = a.offsets ? a.offsets[blockIdx.x] : 0;
     const int64_t n = a.offsets ? a.offsets[blockIdx.x + 1] - off : a.n_total;
@@ -74,22 +75,22 @@ __global__ __launch_bounds__(kBlock) void gls_prep_kernel(PrepArgs a) {
     double W = 1.0, ybar = 0.0;
     if (!a.raw) {
         double acc = 0.0;  // w = err**-2 ; w.sum()
-        for (int64_t i = tid; i < n; i += kBlock) {
+        for (int64_t i = tid; i < n; i += kPrepBlock) {
             const double e = dy ? dy[i] : 1.0;
             acc += 1.0 / (e * e);
         }
-        W = block_sum_256(acc, red);
+        W = block_sum<kPrepBlock>(acc, red);
         if (a.fit_mean) {  // np.dot(w / w.sum(), values)
             acc = 0.0;
-            for (int64_t i = tid; i < n; i += kBlock) {
+            for (int64_t i = tid; i < n; i += kPrepBlock) {
                 const double e = dy ? dy[i] : 1.0;
                 acc += (1.0 / (e * e)) / W * y[i];
             }
-            ybar = block_sum_256(acc, red);
+            ybar = block_sum<kPrepBlock>(acc, red);
         }
     }
     double yy = 0.0, wsum = 0.0;
-    for (int64_t i = tid; i < n; i += kBlock) {
+    for (int64_t i = tid; i < n; i += kPrepBlock) {
         const double tp = t[i] - t0;
         double w, wy;
         if (a.raw) {
@@ -110,8 +111,8 @@ __global__ __launch_bounds__(kBlock) void gls_prep_kernel(PrepArgs a) {
         r[1] = make_double2(w, cd);
         r[2] = make_double2(sd, cd + cd);
     }
-    yy = block_sum_256(yy, red);
-    wsum = block_sum_256(wsum, red);
+    yy = block_sum<kPrepBlock>(yy, red);
+    wsum = block_sum<kPrepBlock>(wsum, red);
     if (tid == 0) {
         double *s = a.scal + (int64_t)blockIdx.x * 4;
         s[0] = yy;
@@ -161,7 +162,11 @@ __device__ __forceinline__ double gls_power(double Sh, double Ch, double S, doub
 }
 
 // ---- the scan ------------------------------------------------------------------------------------------
-template <int K, int MODE>
+// K = trial frequencies per thread; SPLIT ("S") = waves of the workgroup that share one 64-lane frequency
+// tile and split every staged chunk of samples between them (S = 1, 2 or 4), so that a short grid
+// still puts >= 2 waves on every SIMD; their partial sums are combined through LDS in a fixed
+// order before the epilogue, so results do not depend on timing.
+template <int K, int MODE, int SPLIT>
 __global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
     __shared__ double2 stage[kChunk * 3];
     __shared__ double red_v[4];
@@ -179,7 +184,10 @@ __global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
 
     const int64_t off = a.offsets ? a.offsets[curve] : 0;
     const int64_t n = a.offsets ? a.offsets[curve + 1] - off : a.n_total;
-    const int64_t jl = (tile * kBlock + tid) * (int64_t)K;  // first local frequency of this thread
+    constexpr int FT = kBlock / SPLIT;        // frequency-owning threads per workgroup
+    const int wave = tid >> 6, part = wave % SPLIT;
+    // first local frequency of this thread
+    const int64_t jl = (tile * FT + (wave / SPLIT) * 64 + (tid & 63)) * (int64_t)K;
     // numpy's arange fill rule: start + i*delta, two roundings (no fma)
     const double fb = __dadd_rn(a.f0, __dmul_rn((double)(a.j_begin + jl), a.delta));
 
@@ -211,7 +219,8 @@ __global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
         }
         const int cnt = (int)((n - base) < kChunk ? (n - base) : kChunk);
         const double *recs = reinterpret_cast<const double *>(stage);
-        for (int i = 0; i < cnt; ++i) {
+        const int i_end = cnt < (part + 1) * (kChunk / SPLIT) ? cnt : (part + 1) * (kChunk / SPLIT);
+        for (int i = part * (kChunk / SPLIT); i < i_end; ++i) {
             const double2 r0 = *reinterpret_cast<const double2 *>(recs + i * 6);
             const double2 r1 = *reinterpret_cast<const double2 *>(recs + i * 6 + 2);
             const double2 r2 = *reinterpret_cast<const double2 *>(recs + i * 6 + 4);
@@ -254,6 +263,30 @@ __global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
         }
     }
 
+    if (SPLIT > 1) {
+        // fold the partial sums of parts 1..S-1 into part 0, one frequency at a time, through the
+        // staging buffer (6 doubles per contributing thread)
+        double *xch = reinterpret_cast<double *>(stage);
+        const int slot = ((wave / SPLIT) * (SPLIT - 1) + (part - 1)) * 64 + (tid & 63);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            __syncthreads();
+            if (part > 0) {
+                double *d = xch + slot * 6;
+                d[0] = Sh[k]; d[1] = Ch[k]; d[2] = S[k]; d[3] = C[k]; d[4] = SS[k]; d[5] = SC[k];
+            }
+            __syncthreads();
+            if (part == 0) {
+#pragma unroll
+                for (int q = 0; q < SPLIT - 1; ++q) {
+                    const double *d = xch + (((wave / SPLIT) * (SPLIT - 1) + q) * 64 + (tid & 63)) * 6;
+                    Sh[k] += d[0]; Ch[k] += d[1]; S[k] += d[2]; C[k] += d[3]; SS[k] += d[4]; SC[k] += d[5];
+                }
+            }
+        }
+    }
+    const bool owner = part == 0;  // only part 0 holds complete sums
+
     const double *sc = a.scal + curve * 4;
     if (MODE == MODE_RAW) {
         // undo the t0 shift: sums were taken over t' = t - t0
@@ -261,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int64_t j = jl + k;
-            if (j < a.nf) {
+            if (owner && j < a.nf) {
                 const double f = __dadd_rn(a.f0, __dmul_rn((double)(a.j_begin + j), a.delta));
                 double s0, c0;
                 sincos_cycles(frac_product(f, t0), s0, c0);
@@ -278,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int64_t j = jl + k;
-        if (j < a.nf) {
+        if (owner && j < a.nf) {
             const double p = gls_power<MODE>(Sh[k], Ch[k], S[k], C[k], SS[k], SC[k], YY, Wsum,
                                              Werr, a.psd);
             if (a.power) a.power[curve * a.nf + j] = p;
@@ -345,22 +378,51 @@ __global__ __launch_bounds__(64) void gls_peak_kernel(const double *blk_max, con
     }
 }
 
-int tile_width() {
-    static int k = [] {
-        const char *e = getenv("PDC_GLS_K");
-        int v = e ? atoi(e) : 8;
-        return (v == 4 || v == 8 || v == 12 || v == 16) ? v : 8;
-    }();
-    return k;
+// Tile shape (K frequencies per thread, S waves per frequency tile).  Cost model: a wave executes
+// ~(38 + 9K) VALU instructions per sample; waves beyond one per SIMD share that SIMD's issue
+// slots, so time ~ ceil(waves / 1024) * (38 + 9K) / (K * S) per (sample, frequency) up to a
+// constant; a lone wave per SIMD cannot hide its own LDS/dependency stalls (+10 %).
+// PDC_GLS_K / PDC_GLS_S override for experiments.
+void tile_shape(int64_t n_curves, int64_t nf, int *K_out, int *S_out) {
+    static const int envK = [] { const char *e = getenv("PDC_GLS_K"); return e ? atoi(e) : 0; }();
+    static const int envS = [] { const char *e = getenv("PDC_GLS_S"); return e ? atoi(e) : 0; }();
+    double best = 1e300;
+    int bk = 8, bs = 1;
+    for (int K : {16, 8, 4}) {
+        if (envK && K != envK) continue;
+        for (int S : {1, 2, 4}) {
+            if (envS && S != envS) continue;
+            const double waves = (double)n_curves * (double)((nf + 64 * K - 1) / (64 * K)) * S;
+            const double rounds = __builtin_ceil(waves / 1024.0);
+            double cost = rounds * (38.0 + 9.0 * K) / (K * S);
+            if (waves / 1024.0 <= 1.0) cost *= 1.10;
+            cost *= 1.0 + 0.01 * (S - 1);  // prefer no split on ties
+            if (cost < best) {
+                best = cost;
+                bk = K;
+                bs = S;
+            }
+        }
+    }
+    *K_out = bk;
+    *S_out = bs;
+}
+
+template <int MODE, int S>
+void launch_scan_ks(int K, dim3 grid, hipStream_t st, const GlsArgs &a) {
+    switch (K) {
+        case 4: hipLaunchKernelGGL((gls_scan_kernel<4, MODE, S>), grid, dim3(kBlock), 0, st, a); break;
+        case 16: hipLaunchKernelGGL((gls_scan_kernel<16, MODE, S>), grid, dim3(kBlock), 0, st, a); break;
+        default: hipLaunchKernelGGL((gls_scan_kernel<8, MODE, S>), grid, dim3(kBlock), 0, st, a); break;
+    }
 }
 
 template <int MODE>
-void launch_scan(int K, dim3 grid, hipStream_t st, const GlsArgs &a) {
-    switch (K) {
-        case 4: hipLaunchKernelGGL((gls_scan_kernel<4, MODE>), grid, dim3(kBlock), 0, st, a); break;
-        case 12: hipLaunchKernelGGL((gls_scan_kernel<12, MODE>), grid, dim3(kBlock), 0, st, a); break;
-        case 16: hipLaunchKernelGGL((gls_scan_kernel<16, MODE>), grid, dim3(kBlock), 0, st, a); break;
-        default: hipLaunchKernelGGL((gls_scan_kernel<8, MODE>), grid, dim3(kBlock), 0, st, a); break;
+void launch_scan(int K, int S, dim3 grid, hipStream_t st, const GlsArgs &a) {
+    switch (S) {
+        case 4: launch_scan_ks<MODE, 4>(K, grid, st, a); break;
+        case 2: launch_scan_ks<MODE, 2>(K, grid, st, a); break;
+        default: launch_scan_ks<MODE, 1>(K, grid, st, a); break;
     }
 }
 
@@ -370,7 +432,7 @@ struct WorkLayout {
 
 WorkLayout layout(int64_t n_total, int64_t n_curves, int64_t nf) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
-    const int64_t tiles_max = (nf + kBlock * 4 - 1) / (kBlock * 4);  // smallest K is 4
+    const int64_t tiles_max = (nf + 64 * 4 - 1) / (64 * 4);  // smallest tile: K = 4, S = 4
     WorkLayout w;
     w.rec = 0;
     w.scal = up(n_total * 48);
@@ -389,7 +451,7 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     PDC_REQUIRE(d_t && d_y, "gls: t and y must not be NULL");
     PDC_REQUIRE(n_total >= 0 && n_curves >= 1 && nf >= 0 && j_begin >= 0, "gls: negative size");
     PDC_REQUIRE(n_curves == 1 || d_offsets, "gls: a batch needs offsets");
-    PDC_REQUIRE(n_curves * ((nf + 1023) / 1024 + 1) < (int64_t)1 << 31, "gls: grid too large");
+    PDC_REQUIRE(n_curves * ((nf + 255) / 256 + 1) < (int64_t)1 << 31, "gls: grid too large");
     const WorkLayout w = layout(n_total, n_curves, nf);
     PDC_REQUIRE(work && work_bytes >= w.total, "gls: workspace too small (%lld < %lld bytes)",
                 (long long)work_bytes, (long long)w.total);
@@ -409,17 +471,19 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     p.delta = delta;
     p.rec = reinterpret_cast<double *>(base + w.rec);
     p.scal = reinterpret_cast<double *>(base + w.scal);
-    hipLaunchKernelGGL(gls_prep_kernel, dim3((unsigned)n_curves), dim3(kBlock), 0, st, p);
+    hipLaunchKernelGGL(gls_prep_kernel, dim3((unsigned)n_curves), dim3(kPrepBlock), 0, st, p);
     PDC_HIP(hipGetLastError());
 
-    const int K = tile_width();
+    int K, S;
+    tile_shape(n_curves, nf, &K, &S);
     GlsArgs a;
     a.rec = p.rec;
     a.offsets = d_offsets;
     a.scal = p.scal;
     a.n_total = n_total;
     a.n_curves = n_curves;
-    a.tiles = (nf + (int64_t)kBlock * K - 1) / ((int64_t)kBlock * K);
+    const int64_t tile_freqs = (int64_t)(kBlock / S) * K;
+    a.tiles = (nf + tile_freqs - 1) / tile_freqs;
     a.f0 = f0;
     a.delta = delta;
     a.j_begin = j_begin;
@@ -434,11 +498,11 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     const int64_t G = a.n_curves * a.tiles;
     const dim3 grid((unsigned)(((G + 7) / 8) * 8));
     if (mode == MODE_FIT_MEAN) {
-        launch_scan<MODE_FIT_MEAN>(K, grid, st, a);
+        launch_scan<MODE_FIT_MEAN>(K, S, grid, st, a);
     } else if (mode == MODE_NO_MEAN) {
-        launch_scan<MODE_NO_MEAN>(K, grid, st, a);
+        launch_scan<MODE_NO_MEAN>(K, S, grid, st, a);
     } else {
-        launch_scan<MODE_RAW>(K, grid, st, a);
+        launch_scan<MODE_RAW>(K, S, grid, st, a);
     }
     PDC_HIP(hipGetLastError());
     if (peaks) {

@@ -151,4 +151,17 @@ __device__ __forceinline__ double block_sum_256(double v, double *lds4) {
     return (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
 }
 
+// Deterministic block-wide sum for BLOCK-thread blocks (BLOCK a multiple of 64, <= 1024).
+template <int BLOCK>
+__device__ __forceinline__ double block_sum(double v, double *lds_waves) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds_waves[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) r += lds_waves[w];
+    return r;
+}
+
 }  // namespace pdc

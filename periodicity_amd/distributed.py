@@ -1,0 +1,74 @@
+"""One-process-per-GPU sharding of a scan over the trial-frequency / trial-period grid.
+
+Every trial frequency is independent given the (small, replicated) sample set, so the grid is
+cut into ``world`` contiguous equal slabs, rank r computes slab r, and the only exchange is one
+all-gather of the result array (RCCL over xGMI when the process group's backend is ``nccl``;
+``gloo`` on CPU for the tests).  No sample is ever sharded, so no reduction is needed
+(SURVEY.md §8e).  The reference's own parallelism — ``multiprocessing.Pool.map`` over periods,
+``/root/reference/src/periodicity/phase.py:69-70,185-186`` — has the same shape with pickling
+instead of a collective.
+
+torch is imported lazily and only here: it provides rendezvous and the collective, not compute.
+The single-process alternative (one process driving N devices with RCCL directly) is
+``pdc_gls_scan_multi`` in ``csrc/multi.hip``.
+"""
+import numpy as np
+
+
+def slab_bounds(n_grid, world, rank):
+    """``(begin, end, per)``: rank's half-open slab of ``[0, n_grid)`` and the padded slab length
+    ``per = ceil(n_grid / world)`` every rank contributes to the all-gather."""
+    if world < 1 or not 0 <= rank < world or n_grid < 0:
+        raise ValueError("bad world/rank/grid size")
+    per = -(-n_grid // world) if n_grid else 0
+    begin = min(rank * per, n_grid)
+    end = min(begin + per, n_grid)
+    return begin, end, per
+
+
+def gather_slabs(local, n_grid, group=None):
+    """All-gather the per-rank slabs into the full array on every rank.
+
+    ``local`` is this rank's slab as a 1-D float64 ``torch.Tensor`` (on the GPU for ``nccl``, on
+    the CPU for ``gloo``) of length ``end - begin``; returns a tensor of length ``n_grid``.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    begin, end, per = slab_bounds(n_grid, world, rank)
+    if local.numel() != end - begin:
+        raise ValueError(f"rank {rank}: slab has {local.numel()} entries, expected {end - begin}")
+    if n_grid == 0:
+        return local.new_empty(0)
+    send = local
+    if end - begin < per:  # last rank(s): pad so that all contributions are equal-sized
+        send = local.new_zeros(per)
+        send[:end - begin] = local
+    out = torch.empty(per * world, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, send.contiguous(), group=group)
+    return out[:n_grid]
+
+
+def sharded_scan(compute_slab, n_grid, group=None):
+    """Run ``compute_slab(begin, count) -> torch.Tensor`` for this rank's slab and all-gather."""
+    import torch.distributed as dist
+    begin, end, _ = slab_bounds(n_grid, dist.get_world_size(group), dist.get_rank(group))
+    return gather_slabs(compute_slab(begin, end - begin), n_grid, group)
+
+
+def sharded_gls(t, y, dy, f0, delta, nf, fit_mean=True, psd=False, device=None, group=None):
+    """Generalized Lomb-Scargle power on ``f0 + j*delta``, j < nf, with the grid sharded over the
+    ranks of ``group`` (one GPU per rank, ``cuda:LOCAL_RANK`` unless ``device`` is given)."""
+    import torch
+
+    from . import _cabi
+    if device is None:
+        device = torch.cuda.current_device()
+
+    def compute(begin, count):
+        part = _cabi.gls_scan(t, y, dy, f0, delta, count, fit_mean, psd, j_begin=begin,
+                              device=device)
+        return torch.from_numpy(np.ascontiguousarray(part)).to(f"cuda:{device}")
+
+    return sharded_scan(compute, nf, group).cpu().numpy()
