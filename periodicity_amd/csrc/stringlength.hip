@@ -12,32 +12,46 @@
 // broken by sample index (= stable sort of the time-ordered input).
 //
 // Mapping: one workgroup per trial period (persistent grid, periods strided over workgroups).
-// N (phase, index) pairs do not fit in 160 KB of LDS, so the phase axis is cut into ranges:
-//   1. histogram of phases over 2048 equal buckets (LDS atomics);
-//   2. consecutive buckets are grouped greedily into ranges of <= CAP samples;
-//   3. per range: re-scan the samples (recomputing the fold — an fp64 division is far cheaper than
-//      a round trip through HBM), compact the members into LDS, bitonic-sort them there, and sum
-//      the segments, carrying the last point over to the next range.
-// A single bucket holding more than CAP samples (evenly sampled data folded at a commensurate
-// period: thousands of identical phases) is sorted in this workgroup's global scratch instead.
+// N (phase, index) pairs do not fit in 160 KB of LDS, so the sort is two-level and linear-time:
+//   P1  histogram of the phases over 2048 equal coarse buckets (LDS atomics) + exclusive scan;
+//   P2  re-fold every sample (an fp64 division is cheaper than keeping phases around) and scatter
+//       (phase bits, index) into this workgroup's global scratch, grouped by coarse bucket;
+//   P3  consecutive buckets are grouped into ranges of <= 4096 samples (a contiguous slice of the
+//       scratch).  Per range: load the slice, rank every element inside one of <= 4096 FINE
+//       buckets (LDS atomics; the fine index is a power-of-two refinement of the coarse one, so
+//       both are exact and consistent), exclusive scan, place into LDS in fine-bucket order,
+//       finish each fine bucket (mean occupancy < 1) with an insertion sort on (bits, index),
+//       then sum the segments, carrying the last point over to the next range.
+// Clustered phases (evenly sampled data folded at a commensurate period: thousands of identical
+// phases) defeat the counting sort; a range whose fullest fine bucket holds more than 24 samples
+// is bitonic-sorted instead (in LDS, or in global scratch when one coarse bucket alone exceeds
+// 4096 samples).
 #include "pdc_internal.h"
+
+#include <cstdlib>
 
 using namespace pdc;
 
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kBuckets = 2048;
-constexpr int kCap = 4096;
+constexpr int kBuckets = 2048;  // coarse buckets over [0, 1]
+constexpr int kCap = 4096;      // samples per range (LDS sort capacity)
+constexpr int kFine = 4096;     // fine buckets per range
+constexpr int kPer = kCap / kBlock;
+constexpr int kInsertMax = 24;  // fullest fine bucket the insertion-sort finish accepts
 constexpr int kMaxGrid = 1024;
 
 struct SlArgs {
     const double *t, *m, *periods;
     int64_t n, n_periods;
     double *ell;
-    unsigned long long *gkeys;  // [grid][n_pad]
-    unsigned *gidx;             // [grid][n_pad]
+    unsigned long long *gkeys;   // [grid][n_pad]   partitioned (phase bits)
+    unsigned *gidx;              // [grid][n_pad]   partitioned (sample index)
+    unsigned long long *gkeys2;  // [grid][n_pad]   padded copy for the oversized-bucket sort
+    unsigned *gidx2;             // [grid][n_pad]
     int64_t n_pad;
+    int use_lds;   // 1: all-LDS kernel (16-bit indices), 0: global-scratch kernel
 };
 
 __device__ __forceinline__ double fold_phase(double t, double period) {
@@ -45,23 +59,69 @@ __device__ __forceinline__ double fold_phase(double t, double period) {
     return q - __builtin_floor(q);         // == numpy's float % 1 (exact unless -1 < q < 0)
 }
 
-__device__ __forceinline__ int bucket_of(double phi) {
-    // monotone non-decreasing in phi; NaN and phi == 1.0 land in the last bucket
-    const double u = phi * (double)kBuckets;
-    int b = (u >= 0.0) ? (int)(u < (double)kBuckets ? u : (double)(kBuckets - 1)) : 0;
-    return (phi != phi) ? kBuckets - 1 : b;
+// floor(phi * scale) clamped to [0, last]; scale is a power of two, so the product is exact and
+// every refinement of the coarse index is consistent with it.  NaN goes last.
+__device__ __forceinline__ int scaled_index(double phi, double scale, int last) {
+    const double u = phi * scale;
+    int b = (u >= 0.0) ? (u < (double)last ? (int)u : last) : 0;
+    return (phi != phi) ? last : b;
+}
+
+// Exclusive prefix sum of a[0..L) (L <= kScanPer * BLOCK) in place; returns the total.
+constexpr int kScanPer = kPer + 1;  // the fine array carries one extra slot for the total
+template <int BLOCK>
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned *a, int L, unsigned *wave_tot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (L + BLOCK - 1) / BLOCK;
+    const int beg = tid * per;
+    unsigned local[kScanPer];
+    unsigned sum = 0;
+#pragma unroll
+    for (int e = 0; e < kScanPer; ++e) {
+        if (e < per) {
+            const int i = beg + e;
+            local[e] = i < L ? a[i] : 0u;
+            sum += local[e];
+        }
+    }
+    unsigned incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    __syncthreads();
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        if (w < wave) base += wave_tot[w];
+        total += wave_tot[w];
+    }
+    unsigned run = base + incl - sum;
+#pragma unroll
+    for (int e = 0; e < kScanPer; ++e) {
+        if (e < per) {
+            const int i = beg + e;
+            if (i < L) a[i] = run;
+            run += local[e];
+        }
+    }
+    __syncthreads();
+    return total;
 }
 
 // Ascending bitonic sort of P (power of two) (key, index) pairs by (key, index).
-template <typename KeyPtr, typename IdxPtr>
+template <int BLOCK, typename IdxT, typename KeyPtr, typename IdxPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr K, IdxPtr I, int P) {
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int c = threadIdx.x; c < (P >> 1); c += kBlock) {
+            for (int c = threadIdx.x; c < (P >> 1); c += BLOCK) {
                 const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
                 const int l = i | j;
                 const unsigned long long ka = K[i], kb = K[l];
-                const unsigned ia = I[i], ib = I[l];
+                const IdxT ia = I[i], ib = I[l];
                 const bool up = (i & k) == 0;
                 const bool a_gt_b = ka > kb || (ka == kb && ia > ib);
                 if (a_gt_b == up) {
@@ -76,109 +136,204 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr K, IdxPtr I, int P) {
     }
 }
 
+// Sum of hypot(dm, dphi) over consecutive sorted points j-1 -> j, j in [0, cnt), where point -1
+// is the carry (if any).  Strided over the workgroup; the previous point comes from the
+// neighbouring lane.
+template <int BLOCK, typename KeyPtr, typename IdxPtr>
+__device__ __forceinline__ double segment_sum(KeyPtr K, IdxPtr I, int cnt, const double *m,
+                                              bool have_prev, double prev_phi, double prev_m) {
+    const int lane = threadIdx.x & 63;
+    double total = 0.0;
+    for (int j0 = 0; j0 < cnt; j0 += BLOCK) {
+        const int j = j0 + threadIdx.x;
+        const bool live = j < cnt;
+        double phi = 0.0, mm = 0.0;
+        if (live) {
+            phi = __longlong_as_double((long long)K[j]);
+            mm = m[I[j]];
+        }
+        double pphi = __shfl_up(phi, 1, 64);
+        double pm = __shfl_up(mm, 1, 64);
+        bool ok = live;
+        if (lane == 0 && live) {
+            if (j > 0) {
+                pphi = __longlong_as_double((long long)K[j - 1]);
+                pm = m[I[j - 1]];
+            } else {
+                pphi = prev_phi;
+                pm = prev_m;
+                ok = have_prev;
+            }
+        }
+        if (ok) total += hypot(mm - pm, phi - pphi);
+    }
+    return total;
+}
+
 __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
-    __shared__ unsigned hist[kBuckets];
+    __shared__ unsigned hist[kBuckets];           // coarse counts -> starts -> ends
+    __shared__ unsigned fine[kFine + 1];          // fine counts -> starts (+ total)
     __shared__ unsigned long long keys[kCap];
     __shared__ unsigned idxs[kCap];
-    __shared__ int s_hi, s_cnt;
-    __shared__ unsigned s_fill;
+    __shared__ unsigned wave_tot[kBlock / 64];
+    __shared__ unsigned s_max;
     __shared__ double red[kBlock / 64];
     const int tid = threadIdx.x;
     unsigned long long *gk = a.gkeys + (int64_t)blockIdx.x * a.n_pad;
     unsigned *gi = a.gidx + (int64_t)blockIdx.x * a.n_pad;
+    unsigned long long *gk2 = a.gkeys2 + (int64_t)blockIdx.x * a.n_pad;
+    unsigned *gi2 = a.gidx2 + (int64_t)blockIdx.x * a.n_pad;
 
     for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
         const double period = a.periods[p];
+        // ---- P1: coarse histogram -------------------------------------------------------------
         for (int b = tid; b < kBuckets; b += kBlock) hist[b] = 0u;
         __syncthreads();
         for (int64_t i = tid; i < a.n; i += kBlock)
-            atomicAdd(&hist[bucket_of(fold_phase(a.t[i], period))], 1u);
+            atomicAdd(&hist[scaled_index(fold_phase(a.t[i], period), (double)kBuckets, kBuckets - 1)], 1u);
         __syncthreads();
+        block_exclusive_scan<kBlock>(hist, kBuckets, wave_tot);
+        // ---- P2: scatter into the scratch, grouped by coarse bucket ----------------------------
+        for (int64_t i = tid; i < a.n; i += kBlock) {
+            const double phi = fold_phase(a.t[i], period);
+            const unsigned pos = atomicAdd(&hist[scaled_index(phi, (double)kBuckets, kBuckets - 1)], 1u);
+            gk[pos] = (unsigned long long)__double_as_longlong(phi);
+            gi[pos] = (unsigned)i;
+        }
+        __syncthreads();  // hist[b] is now the END offset of bucket b; scratch writes are visible
 
-        double total = 0.0;                       // this thread's share of the string length
-        bool have_prev = false;                   // carry = last point of the previous range
+        // ---- P3: ranges --------------------------------------------------------------------------
+        double total = 0.0;
+        bool have_prev = false;
         double prev_phi = 0.0, prev_m = 0.0, first_phi = 0.0, first_m = 0.0;
         int lo = 0;
-        while (lo < kBuckets) {
-            if (tid == 0) {
-                int hi = lo;
-                unsigned cnt = 0;
-                do {
-                    cnt += hist[hi];
-                    ++hi;
-                } while (hi < kBuckets && cnt + hist[hi] <= (unsigned)kCap);
-                s_hi = hi;
-                s_cnt = (int)cnt;
-                s_fill = 0u;
+        unsigned beg = 0;  // end offset of bucket lo-1
+        while (lo < kBuckets && (int64_t)beg < a.n) {
+            // largest hi with end(hi-1) - beg <= kCap (uniform binary search); at least lo+1
+            int hi;
+            {
+                int l = lo + 1, r = kBuckets;  // answer in [l, r]
+                while (l < r) {
+                    const int mid = (l + r + 1) >> 1;
+                    if (hist[mid - 1] - beg <= (unsigned)kCap) l = mid; else r = mid - 1;
+                }
+                hi = l;
             }
-            __syncthreads();
-            const int hi = s_hi, cnt = s_cnt;
+            const int cnt = (int)(hist[hi - 1] - beg);
             if (cnt > 0) {
-                int P = 2;
-                while (P < cnt) P <<= 1;
-                const bool in_lds = cnt <= kCap;
-                // compact the members of [lo, hi) (arrival order is irrelevant: the sort key
-                // (phase bits, index) is a total order)
-                for (int64_t i = tid; i < a.n; i += kBlock) {
-                    const double phi = fold_phase(a.t[i], period);
-                    const int b = bucket_of(phi);
-                    if (b >= lo && b < hi) {
-                        const unsigned slot = atomicAdd(&s_fill, 1u);
-                        const unsigned long long bits = (unsigned long long)__double_as_longlong(phi);
-                        if (in_lds) {
-                            keys[slot] = bits;
-                            idxs[slot] = (unsigned)i;
-                        } else {
-                            gk[slot] = bits;
-                            gi[slot] = (unsigned)i;
+                const unsigned long long *sk = gk + beg;
+                const unsigned *si = gi + beg;
+                double part;
+                double k0_phi, k0_m, k1_phi, k1_m;
+                if (cnt > kCap) {
+                    // one coarse bucket alone overflows LDS: padded copy + bitonic sort in scratch
+                    int P = 2;
+                    while (P < cnt) P <<= 1;
+                    for (int s = tid; s < P; s += kBlock) {
+                        gk2[s] = s < cnt ? sk[s] : ~0ull;
+                        gi2[s] = s < cnt ? si[s] : ~0u;
+                    }
+                    __syncthreads();
+                    bitonic_sort<kBlock, unsigned>(gk2, gi2, P);
+                    part = segment_sum<kBlock>(gk2, gi2, cnt, a.m, have_prev, prev_phi, prev_m);
+                    k0_phi = __longlong_as_double((long long)gk2[0]);
+                    k0_m = a.m[gi2[0]];
+                    k1_phi = __longlong_as_double((long long)gk2[cnt - 1]);
+                    k1_m = a.m[gi2[cnt - 1]];
+                } else {
+                    // fine counting sort in LDS
+                    const int nbk = hi - lo;
+                    int g = 1;
+                    while (nbk * (g << 1) <= kFine) g <<= 1;
+                    const int nfine = nbk * g;
+                    const double fscale = (double)kBuckets * (double)g;
+                    const int foff = lo * g;
+                    for (int f = tid; f <= nfine; f += kBlock) fine[f] = 0u;
+                    if (tid == 0) s_max = 0u;
+                    __syncthreads();
+                    unsigned long long ek[kPer];
+                    unsigned ei[kPer], er[kPer];
+                    unsigned mymax = 0;
+#pragma unroll
+                    for (int e = 0; e < kPer; ++e) {
+                        const int s = tid + e * kBlock;
+                        if (s < cnt) {
+                            ek[e] = sk[s];
+                            ei[e] = si[s];
+                            int fb = scaled_index(__longlong_as_double((long long)ek[e]), fscale,
+                                                  foff + nfine - 1) - foff;
+                            fb = fb < 0 ? 0 : fb;
+                            er[e] = atomicAdd(&fine[fb], 1u);
+                            mymax = er[e] + 1 > mymax ? er[e] + 1 : mymax;
                         }
                     }
-                }
-                for (int s = cnt + tid; s < P; s += kBlock) {
-                    if (in_lds) {
-                        keys[s] = ~0ull;
-                        idxs[s] = ~0u;
+                    atomicMax(&s_max, mymax);
+                    __syncthreads();
+                    const unsigned fullest = s_max;
+                    if (fullest <= (unsigned)kInsertMax) {
+                        block_exclusive_scan<kBlock>(fine, nfine + 1, wave_tot);  // fine[nfine] = cnt
+#pragma unroll
+                        for (int e = 0; e < kPer; ++e) {
+                            const int s = tid + e * kBlock;
+                            if (s < cnt) {
+                                int fb = scaled_index(__longlong_as_double((long long)ek[e]), fscale,
+                                                      foff + nfine - 1) - foff;
+                                fb = fb < 0 ? 0 : fb;
+                                const unsigned pos = fine[fb] + er[e];
+                                keys[pos] = ek[e];
+                                idxs[pos] = ei[e];
+                            }
+                        }
+                        __syncthreads();
+                        // finish: order each fine bucket by (bits, index)
+                        for (int f = tid; f < nfine; f += kBlock) {
+                            const int s0 = (int)fine[f], s1 = (int)fine[f + 1];
+                            for (int x = s0 + 1; x < s1; ++x) {
+                                const unsigned long long kx = keys[x];
+                                const unsigned ix = idxs[x];
+                                int y = x - 1;
+                                while (y >= s0 && (keys[y] > kx || (keys[y] == kx && idxs[y] > ix))) {
+                                    keys[y + 1] = keys[y];
+                                    idxs[y + 1] = idxs[y];
+                                    --y;
+                                }
+                                keys[y + 1] = kx;
+                                idxs[y + 1] = ix;
+                            }
+                        }
+                        __syncthreads();
                     } else {
-                        gk[s] = ~0ull;
-                        gi[s] = ~0u;
+                        // clustered phases: bitonic sort of the range in LDS
+                        int P = 2;
+                        while (P < cnt) P <<= 1;
+#pragma unroll
+                        for (int e = 0; e < kPer; ++e) {
+                            const int s = tid + e * kBlock;
+                            if (s < P) {
+                                keys[s] = s < cnt ? ek[e] : ~0ull;
+                                idxs[s] = s < cnt ? ei[e] : ~0u;
+                            }
+                        }
+                        __syncthreads();
+                        bitonic_sort<kBlock, unsigned>(keys, idxs, P);
                     }
+                    part = segment_sum<kBlock>(keys, idxs, cnt, a.m, have_prev, prev_phi, prev_m);
+                    k0_phi = __longlong_as_double((long long)keys[0]);
+                    k0_m = a.m[idxs[0]];
+                    k1_phi = __longlong_as_double((long long)keys[cnt - 1]);
+                    k1_m = a.m[idxs[cnt - 1]];
                 }
-                __syncthreads();
-                if (in_lds) {
-                    bitonic_sort(keys, idxs, P);
-                } else {
-                    bitonic_sort(gk, gi, P);
+                total += part;
+                if (!have_prev) {
+                    first_phi = k0_phi;
+                    first_m = k0_m;
                 }
-                // segments inside the range + the link from the previous range
-                for (int j = tid; j < cnt; j += kBlock) {
-                    const unsigned long long kj = in_lds ? keys[j] : gk[j];
-                    const unsigned ij = in_lds ? idxs[j] : gi[j];
-                    const double phi = __longlong_as_double((long long)kj);
-                    const double mm = a.m[ij];
-                    if (j > 0) {
-                        const unsigned long long kp = in_lds ? keys[j - 1] : gk[j - 1];
-                        const unsigned ip = in_lds ? idxs[j - 1] : gi[j - 1];
-                        total += hypot(mm - a.m[ip], phi - __longlong_as_double((long long)kp));
-                    } else if (have_prev) {
-                        total += hypot(mm - prev_m, phi - prev_phi);
-                    }
-                }
-                // every thread tracks the carry (uniform values)
-                {
-                    const unsigned long long k0 = in_lds ? keys[0] : gk[0];
-                    const unsigned i0 = in_lds ? idxs[0] : gi[0];
-                    const unsigned long long k1 = in_lds ? keys[cnt - 1] : gk[cnt - 1];
-                    const unsigned i1 = in_lds ? idxs[cnt - 1] : gi[cnt - 1];
-                    if (!have_prev) {
-                        first_phi = __longlong_as_double((long long)k0);
-                        first_m = a.m[i0];
-                    }
-                    prev_phi = __longlong_as_double((long long)k1);
-                    prev_m = a.m[i1];
-                    have_prev = true;
-                }
+                prev_phi = k1_phi;
+                prev_m = k1_m;
+                have_prev = true;
+                __syncthreads();  // keys/idxs/fine are reused by the next range
             }
-            __syncthreads();  // keys/idxs/s_* are reused by the next range
+            beg = hist[hi - 1];
             lo = hi;
         }
         // closing segment of np.roll(-1): first minus last, no phase wrap (phase.py:50)
@@ -187,6 +342,222 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
         if ((tid & 63) == 0) red[tid >> 6] = total;
         __syncthreads();
         if (tid == 0) a.ell[p] = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// All-LDS variant for N <= kLdsMaxN: the coarse-bucket permutation is kept in LDS as 16-bit sample
+// indices (<= 126 KB), so nothing but t[] and m[] (L2-resident, shared by every workgroup) is read
+// from global memory and nothing is written but ell[p].  1024 threads = 16 waves per CU (one
+// workgroup per CU).  Coarse buckets are chosen from t * (1/period) with the same guard band as
+// the PDM kernel (exact IEEE division only when the shortcut lands within its own error of a
+// bucket edge), the sort keys themselves always come from the exact fold.
+constexpr int kLBlock = 1024;
+constexpr int kLCap = 2048;    // samples per range
+constexpr int kLFine = 2048;   // fine buckets per range
+constexpr int kLPer = kLCap / kLBlock;
+constexpr int kLdsFixed = kBuckets * 4 + kLCap * 8 + kLCap * 2 + (kLFine + 4) * 4 + 512;
+constexpr int kLdsMaxN = (163840 - kLdsFixed) / 2 - 64;
+
+__device__ __forceinline__ int coarse_bucket(double t, double period, double rp, double thr) {
+    const double q = t * rp;
+    const double u = (q - __builtin_floor(q)) * (double)kBuckets;
+    const int b = (int)u;
+    if (__builtin_fabs((u - (double)b) - 0.5) < thr) return b;
+    return scaled_index(fold_phase(t, period), (double)kBuckets, kBuckets - 1);
+}
+
+__global__ __launch_bounds__(kLBlock) void sl_scan_lds_kernel(SlArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(lds_raw);   // [kLCap]
+    unsigned *hist = reinterpret_cast<unsigned *>(keys + kLCap);                  // [kBuckets]
+    unsigned *fine = hist + kBuckets;                                              // [kLFine + 4]
+    unsigned short *kidx = reinterpret_cast<unsigned short *>(fine + kLFine + 4);  // [kLCap]
+    unsigned short *order = kidx + kLCap;                                          // [n]
+    __shared__ unsigned wave_tot[kLBlock / 64];
+    __shared__ unsigned s_max;
+    __shared__ double red[kLBlock / 64];
+    const int tid = threadIdx.x;
+    const int n = (int)a.n;
+    unsigned long long *gk2 = a.gkeys2 + (int64_t)blockIdx.x * a.n_pad;
+    unsigned *gi2 = a.gidx2 + (int64_t)blockIdx.x * a.n_pad;
+
+    // max |t| once per workgroup (guard band of the bucket shortcut)
+    double tmax = 0.0;
+    for (int i = tid; i < n; i += kLBlock) {
+        const double at = __builtin_fabs(a.t[i]);
+        tmax = at > tmax ? at : tmax;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double u = __shfl_down(tmax, o, 64);
+        tmax = u > tmax ? u : tmax;
+    }
+    if ((tid & 63) == 0) red[tid >> 6] = tmax;
+    __syncthreads();
+    tmax = red[0];
+    for (int w = 1; w < kLBlock / 64; ++w) tmax = red[w] > tmax ? red[w] : tmax;
+    __syncthreads();
+
+    for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
+        const double period = a.periods[p];
+        const double rp = 1.0 / period;
+        const double thr = 0.5 - (double)kBuckets * (8.9e-16 * tmax * __builtin_fabs(rp) + 8.9e-16);
+        // ---- P1: coarse histogram + exclusive scan ------------------------------------------
+        for (int b = tid; b < kBuckets; b += kLBlock) hist[b] = 0u;
+        __syncthreads();
+        for (int i = tid; i < n; i += kLBlock) atomicAdd(&hist[coarse_bucket(a.t[i], period, rp, thr)], 1u);
+        __syncthreads();
+        block_exclusive_scan<kLBlock>(hist, kBuckets, wave_tot);
+        // ---- P2: permutation by coarse bucket, in LDS -------------------------------------------
+        for (int i = tid; i < n; i += kLBlock) {
+            const unsigned pos = atomicAdd(&hist[coarse_bucket(a.t[i], period, rp, thr)], 1u);
+            order[pos] = (unsigned short)i;
+        }
+        __syncthreads();  // hist[b] = END offset of bucket b
+
+        // ---- P3: ranges ---------------------------------------------------------------------------
+        double total = 0.0;
+        bool have_prev = false;
+        double prev_phi = 0.0, prev_m = 0.0, first_phi = 0.0, first_m = 0.0;
+        int lo = 0;
+        unsigned beg = 0;
+        while (lo < kBuckets && (int)beg < n) {
+            int hi;
+            {
+                int l = lo + 1, r = kBuckets;
+                while (l < r) {
+                    const int mid = (l + r + 1) >> 1;
+                    if (hist[mid - 1] - beg <= (unsigned)kLCap) l = mid; else r = mid - 1;
+                }
+                hi = l;
+            }
+            const int cnt = (int)(hist[hi - 1] - beg);
+            if (cnt > 0) {
+                double part, k0_phi, k0_m, k1_phi, k1_m;
+                if (cnt > kLCap) {
+                    // one coarse bucket alone overflows the LDS sort: exact keys into the global
+                    // scratch, padded, bitonic sort there
+                    int P = 2;
+                    while (P < cnt) P <<= 1;
+                    for (int s = tid; s < P; s += kLBlock) {
+                        if (s < cnt) {
+                            const unsigned id = order[beg + s];
+                            gk2[s] = (unsigned long long)__double_as_longlong(fold_phase(a.t[id], period));
+                            gi2[s] = id;
+                        } else {
+                            gk2[s] = ~0ull;
+                            gi2[s] = ~0u;
+                        }
+                    }
+                    __syncthreads();
+                    bitonic_sort<kLBlock, unsigned>(gk2, gi2, P);
+                    part = segment_sum<kLBlock>(gk2, gi2, cnt, a.m, have_prev, prev_phi, prev_m);
+                    k0_phi = __longlong_as_double((long long)gk2[0]);
+                    k0_m = a.m[gi2[0]];
+                    k1_phi = __longlong_as_double((long long)gk2[cnt - 1]);
+                    k1_m = a.m[gi2[cnt - 1]];
+                } else {
+                    const int nbk = hi - lo;
+                    int g = 1;
+                    while (nbk * (g << 1) <= kLFine) g <<= 1;
+                    const int nfine = nbk * g;
+                    const double fscale = (double)kBuckets * (double)g;
+                    const int foff = lo * g;
+                    for (int f = tid; f <= nfine; f += kLBlock) fine[f] = 0u;
+                    if (tid == 0) s_max = 0u;
+                    __syncthreads();
+                    unsigned long long ek[kLPer];
+                    unsigned ei[kLPer], er[kLPer];
+                    int ef[kLPer];
+                    unsigned mymax = 0;
+#pragma unroll
+                    for (int e = 0; e < kLPer; ++e) {
+                        const int s = tid + e * kLBlock;
+                        if (s < cnt) {
+                            ei[e] = order[beg + s];
+                            const double phi = fold_phase(a.t[ei[e]], period);   // exact sort key
+                            ek[e] = (unsigned long long)__double_as_longlong(phi);
+                            int fb = scaled_index(phi, fscale, foff + nfine - 1) - foff;
+                            ef[e] = fb < 0 ? 0 : fb;
+                            er[e] = atomicAdd(&fine[ef[e]], 1u);
+                            mymax = er[e] + 1 > mymax ? er[e] + 1 : mymax;
+                        }
+                    }
+                    atomicMax(&s_max, mymax);
+                    __syncthreads();
+                    const unsigned fullest = s_max;
+                    if (fullest <= (unsigned)kInsertMax) {
+                        block_exclusive_scan<kLBlock>(fine, nfine + 1, wave_tot);  // fine[nfine] = cnt
+#pragma unroll
+                        for (int e = 0; e < kLPer; ++e) {
+                            const int s = tid + e * kLBlock;
+                            if (s < cnt) {
+                                const unsigned pos = fine[ef[e]] + er[e];
+                                keys[pos] = ek[e];
+                                kidx[pos] = (unsigned short)ei[e];
+                            }
+                        }
+                        __syncthreads();
+                        for (int f = tid; f < nfine; f += kLBlock) {
+                            const int s0 = (int)fine[f], s1 = (int)fine[f + 1];
+                            for (int x = s0 + 1; x < s1; ++x) {
+                                const unsigned long long kx = keys[x];
+                                const unsigned short ix = kidx[x];
+                                int y = x - 1;
+                                while (y >= s0 && (keys[y] > kx || (keys[y] == kx && kidx[y] > ix))) {
+                                    keys[y + 1] = keys[y];
+                                    kidx[y + 1] = kidx[y];
+                                    --y;
+                                }
+                                keys[y + 1] = kx;
+                                kidx[y + 1] = ix;
+                            }
+                        }
+                        __syncthreads();
+                    } else {
+                        int P = 2;
+                        while (P < cnt) P <<= 1;
+#pragma unroll
+                        for (int e = 0; e < kLPer; ++e) {
+                            const int s = tid + e * kLBlock;
+                            if (s < P) {
+                                keys[s] = s < cnt ? ek[e] : ~0ull;
+                                kidx[s] = s < cnt ? (unsigned short)ei[e] : (unsigned short)0xffff;
+                            }
+                        }
+                        __syncthreads();
+                        bitonic_sort<kLBlock, unsigned short>(keys, kidx, P);
+                    }
+                    part = segment_sum<kLBlock>(keys, kidx, cnt, a.m, have_prev, prev_phi, prev_m);
+                    k0_phi = __longlong_as_double((long long)keys[0]);
+                    k0_m = a.m[kidx[0]];
+                    k1_phi = __longlong_as_double((long long)keys[cnt - 1]);
+                    k1_m = a.m[kidx[cnt - 1]];
+                }
+                total += part;
+                if (!have_prev) {
+                    first_phi = k0_phi;
+                    first_m = k0_m;
+                }
+                prev_phi = k1_phi;
+                prev_m = k1_m;
+                have_prev = true;
+                __syncthreads();
+            }
+            beg = hist[hi - 1];
+            lo = hi;
+        }
+        if (tid == 0 && have_prev) total += hypot(first_m - prev_m, first_phi - prev_phi);
+        total = wave_sum(total);
+        if ((tid & 63) == 0) red[tid >> 6] = total;
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0;
+            for (int w = 0; w < kLBlock / 64; ++w) sum += red[w];
+            a.ell[p] = sum;
+        }
         __syncthreads();
     }
 }
@@ -205,7 +576,7 @@ extern "C" {
 
 int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) {
     if (n < 0 || n_periods < 0) return -1;
-    return grid_for(n_periods > 0 ? n_periods : 1) * pad_pow2(n) * 12 + 512;
+    return grid_for(n_periods > 0 ? n_periods : 1) * pad_pow2(n) * 24 + 512;
 }
 
 int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
@@ -228,9 +599,22 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
     a.n_periods = n_periods;
     a.ell = d_ell;
     a.n_pad = pad_pow2(n);
+
     a.gkeys = reinterpret_cast<unsigned long long *>(work);
-    a.gidx = reinterpret_cast<unsigned *>(a.gkeys + grid * a.n_pad);
-    hipLaunchKernelGGL(sl_scan_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    a.gkeys2 = a.gkeys + grid * a.n_pad;
+    a.gidx = reinterpret_cast<unsigned *>(a.gkeys2 + grid * a.n_pad);
+    a.gidx2 = a.gidx + grid * a.n_pad;
+    static const int force_scratch = [] { const char *e = getenv("PDC_SL_SCRATCH"); return e ? atoi(e) : 0; }();
+    a.use_lds = (n <= kLdsMaxN && !force_scratch) ? 1 : 0;
+    if (a.use_lds) {
+        const size_t lds = (size_t)kLdsFixed - 512 + (size_t)((n + 7) & ~(int64_t)7) * 2;
+        PDC_HIP(hipFuncSetAttribute((const void *)sl_scan_lds_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(sl_scan_lds_kernel, dim3((unsigned)grid), dim3(kLBlock), lds,
+                           (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(sl_scan_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, a);
+    }
     PDC_HIP(hipGetLastError());
     return PDC_OK;
 }

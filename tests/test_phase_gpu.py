@@ -131,6 +131,20 @@ def test_stringlength_clusters_take_the_scratch_path():
     np.testing.assert_allclose(got[:3], so.stringlength_scan(t, m, periods[:3]), rtol=RTOL)
 
 
+def test_stringlength_large_n_takes_the_scratch_kernel():
+    # N above the all-LDS kernel's limit (63160 samples): partition through global scratch
+    t, y = synth(70_000, 77)
+    m = so.stringlength_scale(y)
+    periods = np.array([0.9, 13.7, 333.3, 9000.0])
+    np.testing.assert_allclose(_cabi.stringlength_scan(t, m, periods),
+                               co.stringlength_scan(t, m, periods), rtol=RTOL)
+    te = np.arange(70_000.0)                                # clusters: one bucket > 4096 samples
+    me = so.stringlength_scale(np.sin(2 * np.pi * te / 12.5) + 0.05 * np.cos(0.37 * te))
+    pe = np.array([1.0, 2.5, 7.3])
+    np.testing.assert_allclose(_cabi.stringlength_scan(te, me, pe),
+                               co.stringlength_scan(te, me, pe), rtol=RTOL)
+
+
 def test_stringlength_edges():
     t, y = synth(700, 2)
     m = so.stringlength_scale(y)
