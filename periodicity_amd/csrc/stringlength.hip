@@ -50,7 +50,9 @@ struct SlArgs {
     unsigned *gidx;              // [grid][n_pad]   partitioned (sample index)
     unsigned long long *gkeys2;  // [grid][n_pad]   padded copy for the oversized-bucket sort
     unsigned *gidx2;             // [grid][n_pad]
-    int64_t n_pad;
+    double *rsum;                // [grid][nr_pad][4]  range summaries (all-LDS kernel)
+    int *rcnt;                   // [grid][nr_pad]
+    int64_t n_pad, nr_pad;
     int use_lds;   // 1: all-LDS kernel (16-bit indices), 0: global-scratch kernel
 };
 
@@ -348,18 +350,34 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
-// All-LDS variant for N <= kLdsMaxN: the coarse-bucket permutation is kept in LDS as 16-bit sample
-// indices (<= 126 KB), so nothing but t[] and m[] (L2-resident, shared by every workgroup) is read
-// from global memory and nothing is written but ell[p].  1024 threads = 16 waves per CU (one
-// workgroup per CU).  Coarse buckets are chosen from t * (1/period) with the same guard band as
-// the PDM kernel (exact IEEE division only when the shortcut lands within its own error of a
-// bucket edge), the sort keys themselves always come from the exact fold.
+// All-LDS variant for N <= kLdsMaxN.  The coarse-bucket permutation is kept in LDS as 16-bit sample
+// indices, so nothing but t[] and m[] (L2-resident, shared by every workgroup) is read from global
+// memory.  1024 threads = 16 waves, one workgroup per CU.
+//   P1/P2  block-wide: coarse histogram, scan, permutation `order[]` (coarse buckets chosen from
+//          t * (1/period) with the same guard band as the PDM kernel: the exact IEEE division runs
+//          only when the shortcut lands within its own error of a bucket edge).
+//   P3a    WAVE-AUTONOMOUS ranges, no workgroup barrier: the sorted positions are cut into windows
+//          of 64; range r = the coarse buckets whose first sorted position falls in window r (a
+//          contiguous slice of order[], ~64-100 samples).  Each wave takes ranges r = wave,
+//          wave+16, ...: exact fold of its <= 192 samples, rank inside <= 256 fine buckets (LDS
+//          atomics, wave-private counters), wave-level exclusive scan, placement, insertion-sort
+//          finish, segment sum, and a 4-double summary (first/last point) of the range.
+//   P3b    ranges a wave cannot take (more than 192 samples, or a fine bucket fuller than 16:
+//          clustered phases) are bitonic-sorted by the whole workgroup (LDS, or global scratch
+//          beyond 2048 samples).
+//   P3c    links between consecutive ranges and the closing segment from the summaries.
 constexpr int kLBlock = 1024;
-constexpr int kLCap = 2048;    // samples per range
-constexpr int kLFine = 2048;   // fine buckets per range
-constexpr int kLPer = kLCap / kLBlock;
-constexpr int kLdsFixed = kBuckets * 4 + kLCap * 8 + kLCap * 2 + (kLFine + 4) * 4 + 512;
-constexpr int kLdsMaxN = (163840 - kLdsFixed) / 2 - 64;
+constexpr int kLWaves = kLBlock / 64;
+constexpr int kWin = 64;
+constexpr int kRCap = 192;
+constexpr int kRPer = kRCap / 64;
+constexpr int kWFine = 256;
+constexpr int kWInsertMax = 16;
+constexpr int kDCap = 2048;
+constexpr int kWaveBytes = 3072;   // keys u64[192] | fine u32[260] | idx u16[192]
+constexpr int kMaxRanges = 1024;
+constexpr int kLdsFixed = kLWaves * kWaveBytes + kBuckets * 4 + (kMaxRanges + 8) * 4 + 128;
+constexpr int kLdsMaxN = (163840 - kLdsFixed - 1024) / 2;
 
 __device__ __forceinline__ int coarse_bucket(double t, double period, double rp, double thr) {
     const double q = t * rp;
@@ -369,20 +387,32 @@ __device__ __forceinline__ int coarse_bucket(double t, double period, double rp,
     return scaled_index(fold_phase(t, period), (double)kBuckets, kBuckets - 1);
 }
 
+// LDS traffic between lanes of ONE wave: order the accesses without a workgroup barrier.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(kLBlock) void sl_scan_lds_kernel(SlArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(lds_raw);   // [kLCap]
-    unsigned *hist = reinterpret_cast<unsigned *>(keys + kLCap);                  // [kBuckets]
-    unsigned *fine = hist + kBuckets;                                              // [kLFine + 4]
-    unsigned short *kidx = reinterpret_cast<unsigned short *>(fine + kLFine + 4);  // [kLCap]
-    unsigned short *order = kidx + kLCap;                                          // [n]
-    __shared__ unsigned wave_tot[kLBlock / 64];
-    __shared__ unsigned s_max;
-    __shared__ double red[kLBlock / 64];
-    const int tid = threadIdx.x;
+    unsigned char *wbuf = lds_raw;                                                  // per-wave scratch
+    unsigned long long *bkeys = reinterpret_cast<unsigned long long *>(lds_raw);    // P3b alias [kDCap]
+    unsigned short *bidx = reinterpret_cast<unsigned short *>(bkeys + kDCap);       // P3b alias [kDCap]
+    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw + kLWaves * kWaveBytes);  // [kBuckets]
+    unsigned short *bndb = reinterpret_cast<unsigned short *>(hist + kBuckets);     // [kMaxRanges + 8]
+    unsigned short *bnds = bndb + kMaxRanges + 8;                                   // [kMaxRanges + 8]
+    unsigned *defer = reinterpret_cast<unsigned *>(bnds + kMaxRanges + 8);          // [32]
+    unsigned short *order = reinterpret_cast<unsigned short *>(defer + 32);         // [n]
+    __shared__ unsigned wave_tot[kLWaves];
+    __shared__ double red[kLWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = (int)a.n;
+    const int nranges = (n + kWin - 1) / kWin;
     unsigned long long *gk2 = a.gkeys2 + (int64_t)blockIdx.x * a.n_pad;
     unsigned *gi2 = a.gidx2 + (int64_t)blockIdx.x * a.n_pad;
+    double *rsum = a.rsum + (int64_t)blockIdx.x * a.nr_pad * 4;
+    int *rcnt = a.rcnt + (int64_t)blockIdx.x * a.nr_pad;
 
     // max |t| once per workgroup (guard band of the bucket shortcut)
     double tmax = 0.0;
@@ -394,11 +424,15 @@ __global__ __launch_bounds__(kLBlock) void sl_scan_lds_kernel(SlArgs a) {
         const double u = __shfl_down(tmax, o, 64);
         tmax = u > tmax ? u : tmax;
     }
-    if ((tid & 63) == 0) red[tid >> 6] = tmax;
+    if (lane == 0) red[wave] = tmax;
     __syncthreads();
     tmax = red[0];
-    for (int w = 1; w < kLBlock / 64; ++w) tmax = red[w] > tmax ? red[w] : tmax;
+    for (int w = 1; w < kLWaves; ++w) tmax = red[w] > tmax ? red[w] : tmax;
     __syncthreads();
+
+    unsigned long long *keys_w = reinterpret_cast<unsigned long long *>(wbuf + wave * kWaveBytes);
+    unsigned *fine_w = reinterpret_cast<unsigned *>(wbuf + wave * kWaveBytes + kRCap * 8);
+    unsigned short *idx_w = reinterpret_cast<unsigned short *>(wbuf + wave * kWaveBytes + kRCap * 8 + (kWFine + 4) * 4);
 
     for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
         const double period = a.periods[p];
@@ -406,6 +440,7 @@ __global__ __launch_bounds__(kLBlock) void sl_scan_lds_kernel(SlArgs a) {
         const double thr = 0.5 - (double)kBuckets * (8.9e-16 * tmax * __builtin_fabs(rp) + 8.9e-16);
         // ---- P1: coarse histogram + exclusive scan ------------------------------------------
         for (int b = tid; b < kBuckets; b += kLBlock) hist[b] = 0u;
+        if (tid < 32) defer[tid] = 0u;
         __syncthreads();
         for (int i = tid; i < n; i += kLBlock) atomicAdd(&hist[coarse_bucket(a.t[i], period, rp, thr)], 1u);
         __syncthreads();
@@ -416,34 +451,192 @@ __global__ __launch_bounds__(kLBlock) void sl_scan_lds_kernel(SlArgs a) {
             order[pos] = (unsigned short)i;
         }
         __syncthreads();  // hist[b] = END offset of bucket b
-
-        // ---- P3: ranges ---------------------------------------------------------------------------
-        double total = 0.0;
-        bool have_prev = false;
-        double prev_phi = 0.0, prev_m = 0.0, first_phi = 0.0, first_m = 0.0;
-        int lo = 0;
-        unsigned beg = 0;
-        while (lo < kBuckets && (int)beg < n) {
-            int hi;
-            {
-                int l = lo + 1, r = kBuckets;
-                while (l < r) {
-                    const int mid = (l + r + 1) >> 1;
-                    if (hist[mid - 1] - beg <= (unsigned)kLCap) l = mid; else r = mid - 1;
+        // range boundaries: range r starts at the first bucket whose start offset is >= r * kWin
+        for (int r = tid; r <= nranges; r += kLBlock) {
+            int b = 0, s0 = 0;
+            if (r > 0) {
+                const unsigned x = (unsigned)r * kWin;
+                int l = 0, h = kBuckets;  // smallest j with hist[j] >= x, kBuckets if none
+                while (l < h) {
+                    const int mid = (l + h) >> 1;
+                    if (hist[mid] >= x) h = mid; else l = mid + 1;
                 }
-                hi = l;
+                b = l < kBuckets ? l + 1 : kBuckets;
+                s0 = l < kBuckets ? (int)hist[l] : n;
             }
-            const int cnt = (int)(hist[hi - 1] - beg);
-            if (cnt > 0) {
-                double part, k0_phi, k0_m, k1_phi, k1_m;
-                if (cnt > kLCap) {
-                    // one coarse bucket alone overflows the LDS sort: exact keys into the global
-                    // scratch, padded, bitonic sort there
-                    int P = 2;
-                    while (P < cnt) P <<= 1;
+            bndb[r] = (unsigned short)b;
+            bnds[r] = (unsigned short)s0;
+        }
+        __syncthreads();
+
+        // ---- P3a: wave-autonomous ranges -------------------------------------------------------
+        double total = 0.0;
+        for (int r = wave; r < nranges; r += kLWaves) {
+            const int lo_b = bndb[r], hi_b = bndb[r + 1];
+            const int s_lo = bnds[r], cnt = (int)bnds[r + 1] - s_lo;
+            if (cnt <= 0) {
+                if (lane == 0) rcnt[r] = 0;
+                continue;
+            }
+            if (cnt > kRCap) {
+                if (lane == 0) atomicOr(&defer[r >> 5], 1u << (r & 31));
+                continue;
+            }
+            // monotone map of the range's phases onto <= kWFine fine buckets
+            const int nbk = hi_b - lo_b;
+            int g = 1, shift = 0;
+            if (nbk <= kWFine) {
+                while (nbk * (g << 1) <= kWFine) g <<= 1;
+            } else {
+                while ((nbk >> shift) + 1 > kWFine) ++shift;
+            }
+            const double fscale = (double)kBuckets * (double)g;
+            const int foff = lo_b * g;
+            const int flast = nbk <= kWFine ? nbk * g - 1 : (nbk >> shift);
+            // zero the counters (260 entries)
+            reinterpret_cast<uint4 *>(fine_w)[lane] = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < 4) fine_w[kWFine + lane] = 0u;
+            wave_sync();
+            unsigned long long ek[kRPer];
+            unsigned ei[kRPer], er[kRPer];
+            int ef[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                const int s = lane + e * 64;
+                if (s < cnt) {
+                    ei[e] = order[s_lo + s];
+                    const double phi = fold_phase(a.t[ei[e]], period);   // exact sort key
+                    ek[e] = (unsigned long long)__double_as_longlong(phi);
+                    int fb;
+                    if (nbk <= kWFine) {
+                        fb = scaled_index(phi, fscale, foff + flast) - foff;
+                    } else {
+                        fb = (scaled_index(phi, (double)kBuckets, kBuckets - 1) - lo_b) >> shift;
+                    }
+                    fb = fb < 0 ? 0 : (fb > flast ? flast : fb);
+                    ef[e] = fb;
+                    er[e] = atomicAdd(&fine_w[fb], 1u);
+                }
+            }
+            wave_sync();
+            // wave-level exclusive scan of the 256 counters (4 per lane) + fullest bucket
+            const uint4 c = reinterpret_cast<uint4 *>(fine_w)[lane];
+            const unsigned mx = max(max(c.x, c.y), max(c.z, c.w));
+            if (__any(mx > (unsigned)kWInsertMax)) {
+                if (lane == 0) atomicOr(&defer[r >> 5], 1u << (r & 31));
+                continue;
+            }
+            const unsigned sum4 = c.x + c.y + c.z + c.w;
+            unsigned incl = sum4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            const unsigned base = incl - sum4;
+            wave_sync();
+            reinterpret_cast<uint4 *>(fine_w)[lane] = make_uint4(base, base + c.x, base + c.x + c.y,
+                                                                 base + c.x + c.y + c.z);
+            if (lane == 63) fine_w[kWFine] = incl;  // == cnt
+            wave_sync();
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                const int s = lane + e * 64;
+                if (s < cnt) {
+                    const unsigned pos = fine_w[ef[e]] + er[e];
+                    keys_w[pos] = ek[e];
+                    idx_w[pos] = (unsigned short)ei[e];
+                }
+            }
+            wave_sync();
+            // finish: each lane orders its 4 fine buckets by (bits, index)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = lane * 4 + q;
+                const int s0 = (int)fine_w[f], s1 = (int)fine_w[f + 1];
+                for (int x = s0 + 1; x < s1; ++x) {
+                    const unsigned long long kx = keys_w[x];
+                    const unsigned short ix = idx_w[x];
+                    int y = x - 1;
+                    while (y >= s0 && (keys_w[y] > kx || (keys_w[y] == kx && idx_w[y] > ix))) {
+                        keys_w[y + 1] = keys_w[y];
+                        idx_w[y + 1] = idx_w[y];
+                        --y;
+                    }
+                    keys_w[y + 1] = kx;
+                    idx_w[y + 1] = ix;
+                }
+            }
+            wave_sync();
+            // segments inside the range
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                const int j = lane + e * 64;
+                const bool live = j < cnt;
+                double phi = 0.0, mm = 0.0;
+                if (live) {
+                    phi = __longlong_as_double((long long)keys_w[j]);
+                    mm = a.m[idx_w[j]];
+                }
+                double pphi = __shfl_up(phi, 1, 64);
+                double pm = __shfl_up(mm, 1, 64);
+                bool ok = live;
+                if (lane == 0 && live) {
+                    if (j > 0) {
+                        pphi = __longlong_as_double((long long)keys_w[j - 1]);
+                        pm = a.m[idx_w[j - 1]];
+                    } else {
+                        ok = false;
+                    }
+                }
+                if (ok) total += hypot(mm - pm, phi - pphi);
+            }
+            if (lane == 0) {
+                rsum[r * 4 + 0] = __longlong_as_double((long long)keys_w[0]);
+                rsum[r * 4 + 1] = a.m[idx_w[0]];
+                rsum[r * 4 + 2] = __longlong_as_double((long long)keys_w[cnt - 1]);
+                rsum[r * 4 + 3] = a.m[idx_w[cnt - 1]];
+                rcnt[r] = cnt;
+            }
+            wave_sync();
+        }
+        __syncthreads();
+
+        // ---- P3b: deferred ranges, whole workgroup ---------------------------------------------
+        for (int w32 = 0; w32 < (nranges + 31) / 32; ++w32) {
+            unsigned bits = defer[w32];
+            while (bits) {
+                const int r = w32 * 32 + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int s_lo = bnds[r], cnt = (int)bnds[r + 1] - s_lo;
+                int P = 2;
+                while (P < cnt) P <<= 1;
+                double part;
+                if (cnt <= kDCap) {
                     for (int s = tid; s < P; s += kLBlock) {
                         if (s < cnt) {
-                            const unsigned id = order[beg + s];
+                            const unsigned id = order[s_lo + s];
+                            bkeys[s] = (unsigned long long)__double_as_longlong(fold_phase(a.t[id], period));
+                            bidx[s] = (unsigned short)id;
+                        } else {
+                            bkeys[s] = ~0ull;
+                            bidx[s] = (unsigned short)0xffff;
+                        }
+                    }
+                    __syncthreads();
+                    bitonic_sort<kLBlock, unsigned short>(bkeys, bidx, P);
+                    part = segment_sum<kLBlock>(bkeys, bidx, cnt, a.m, false, 0.0, 0.0);
+                    if (tid == 0) {
+                        rsum[r * 4 + 0] = __longlong_as_double((long long)bkeys[0]);
+                        rsum[r * 4 + 1] = a.m[bidx[0]];
+                        rsum[r * 4 + 2] = __longlong_as_double((long long)bkeys[cnt - 1]);
+                        rsum[r * 4 + 3] = a.m[bidx[cnt - 1]];
+                        rcnt[r] = cnt;
+                    }
+                } else {
+                    for (int s = tid; s < P; s += kLBlock) {
+                        if (s < cnt) {
+                            const unsigned id = order[s_lo + s];
                             gk2[s] = (unsigned long long)__double_as_longlong(fold_phase(a.t[id], period));
                             gi2[s] = id;
                         } else {
@@ -453,109 +646,44 @@ __global__ __launch_bounds__(kLBlock) void sl_scan_lds_kernel(SlArgs a) {
                     }
                     __syncthreads();
                     bitonic_sort<kLBlock, unsigned>(gk2, gi2, P);
-                    part = segment_sum<kLBlock>(gk2, gi2, cnt, a.m, have_prev, prev_phi, prev_m);
-                    k0_phi = __longlong_as_double((long long)gk2[0]);
-                    k0_m = a.m[gi2[0]];
-                    k1_phi = __longlong_as_double((long long)gk2[cnt - 1]);
-                    k1_m = a.m[gi2[cnt - 1]];
-                } else {
-                    const int nbk = hi - lo;
-                    int g = 1;
-                    while (nbk * (g << 1) <= kLFine) g <<= 1;
-                    const int nfine = nbk * g;
-                    const double fscale = (double)kBuckets * (double)g;
-                    const int foff = lo * g;
-                    for (int f = tid; f <= nfine; f += kLBlock) fine[f] = 0u;
-                    if (tid == 0) s_max = 0u;
-                    __syncthreads();
-                    unsigned long long ek[kLPer];
-                    unsigned ei[kLPer], er[kLPer];
-                    int ef[kLPer];
-                    unsigned mymax = 0;
-#pragma unroll
-                    for (int e = 0; e < kLPer; ++e) {
-                        const int s = tid + e * kLBlock;
-                        if (s < cnt) {
-                            ei[e] = order[beg + s];
-                            const double phi = fold_phase(a.t[ei[e]], period);   // exact sort key
-                            ek[e] = (unsigned long long)__double_as_longlong(phi);
-                            int fb = scaled_index(phi, fscale, foff + nfine - 1) - foff;
-                            ef[e] = fb < 0 ? 0 : fb;
-                            er[e] = atomicAdd(&fine[ef[e]], 1u);
-                            mymax = er[e] + 1 > mymax ? er[e] + 1 : mymax;
-                        }
+                    part = segment_sum<kLBlock>(gk2, gi2, cnt, a.m, false, 0.0, 0.0);
+                    if (tid == 0) {
+                        rsum[r * 4 + 0] = __longlong_as_double((long long)gk2[0]);
+                        rsum[r * 4 + 1] = a.m[gi2[0]];
+                        rsum[r * 4 + 2] = __longlong_as_double((long long)gk2[cnt - 1]);
+                        rsum[r * 4 + 3] = a.m[gi2[cnt - 1]];
+                        rcnt[r] = cnt;
                     }
-                    atomicMax(&s_max, mymax);
-                    __syncthreads();
-                    const unsigned fullest = s_max;
-                    if (fullest <= (unsigned)kInsertMax) {
-                        block_exclusive_scan<kLBlock>(fine, nfine + 1, wave_tot);  // fine[nfine] = cnt
-#pragma unroll
-                        for (int e = 0; e < kLPer; ++e) {
-                            const int s = tid + e * kLBlock;
-                            if (s < cnt) {
-                                const unsigned pos = fine[ef[e]] + er[e];
-                                keys[pos] = ek[e];
-                                kidx[pos] = (unsigned short)ei[e];
-                            }
-                        }
-                        __syncthreads();
-                        for (int f = tid; f < nfine; f += kLBlock) {
-                            const int s0 = (int)fine[f], s1 = (int)fine[f + 1];
-                            for (int x = s0 + 1; x < s1; ++x) {
-                                const unsigned long long kx = keys[x];
-                                const unsigned short ix = kidx[x];
-                                int y = x - 1;
-                                while (y >= s0 && (keys[y] > kx || (keys[y] == kx && kidx[y] > ix))) {
-                                    keys[y + 1] = keys[y];
-                                    kidx[y + 1] = kidx[y];
-                                    --y;
-                                }
-                                keys[y + 1] = kx;
-                                kidx[y + 1] = ix;
-                            }
-                        }
-                        __syncthreads();
-                    } else {
-                        int P = 2;
-                        while (P < cnt) P <<= 1;
-#pragma unroll
-                        for (int e = 0; e < kLPer; ++e) {
-                            const int s = tid + e * kLBlock;
-                            if (s < P) {
-                                keys[s] = s < cnt ? ek[e] : ~0ull;
-                                kidx[s] = s < cnt ? (unsigned short)ei[e] : (unsigned short)0xffff;
-                            }
-                        }
-                        __syncthreads();
-                        bitonic_sort<kLBlock, unsigned short>(keys, kidx, P);
-                    }
-                    part = segment_sum<kLBlock>(keys, kidx, cnt, a.m, have_prev, prev_phi, prev_m);
-                    k0_phi = __longlong_as_double((long long)keys[0]);
-                    k0_m = a.m[kidx[0]];
-                    k1_phi = __longlong_as_double((long long)keys[cnt - 1]);
-                    k1_m = a.m[kidx[cnt - 1]];
                 }
                 total += part;
-                if (!have_prev) {
-                    first_phi = k0_phi;
-                    first_m = k0_m;
-                }
-                prev_phi = k1_phi;
-                prev_m = k1_m;
-                have_prev = true;
                 __syncthreads();
             }
-            beg = hist[hi - 1];
-            lo = hi;
         }
-        if (tid == 0 && have_prev) total += hypot(first_m - prev_m, first_phi - prev_phi);
+        __syncthreads();  // summaries (global, this workgroup's) are visible
+
+        // ---- P3c: links between consecutive non-empty ranges + the closing segment ----------------
+        for (int r = tid; r < nranges; r += kLBlock) {
+            if (rcnt[r] > 0) {
+                int q = r - 1;
+                while (q >= 0 && rcnt[q] == 0) --q;
+                if (q >= 0)
+                    total += hypot(rsum[r * 4 + 1] - rsum[q * 4 + 3], rsum[r * 4 + 0] - rsum[q * 4 + 2]);
+            }
+        }
+        if (tid == 0 && nranges > 0) {
+            int f0 = 0, l0 = nranges - 1;
+            while (f0 < nranges && rcnt[f0] == 0) ++f0;
+            while (l0 >= 0 && rcnt[l0] == 0) --l0;
+            // closing segment of np.roll(-1): first minus last, no phase wrap (phase.py:50)
+            if (f0 < nranges && l0 >= 0)
+                total += hypot(rsum[f0 * 4 + 1] - rsum[l0 * 4 + 3], rsum[f0 * 4 + 0] - rsum[l0 * 4 + 2]);
+        }
         total = wave_sum(total);
-        if ((tid & 63) == 0) red[tid >> 6] = total;
+        if (lane == 0) red[wave] = total;
         __syncthreads();
         if (tid == 0) {
             double sum = 0.0;
-            for (int w = 0; w < kLBlock / 64; ++w) sum += red[w];
+            for (int w = 0; w < kLWaves; ++w) sum += red[w];
             a.ell[p] = sum;
         }
         __syncthreads();
@@ -576,7 +704,8 @@ extern "C" {
 
 int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) {
     if (n < 0 || n_periods < 0) return -1;
-    return grid_for(n_periods > 0 ? n_periods : 1) * pad_pow2(n) * 24 + 512;
+    const int64_t nr = (n + 63) / 64 + 8;
+    return grid_for(n_periods > 0 ? n_periods : 1) * (pad_pow2(n) * 24 + nr * 40) + 512;
 }
 
 int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
@@ -604,10 +733,15 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
     a.gkeys2 = a.gkeys + grid * a.n_pad;
     a.gidx = reinterpret_cast<unsigned *>(a.gkeys2 + grid * a.n_pad);
     a.gidx2 = a.gidx + grid * a.n_pad;
+    a.nr_pad = (n + 63) / 64 + 8;
+    a.rsum = reinterpret_cast<double *>(a.gkeys2 + grid * a.n_pad);  // placed after the 8-byte arrays
+    a.gidx = reinterpret_cast<unsigned *>(a.rsum + grid * a.nr_pad * 4);
+    a.gidx2 = a.gidx + grid * a.n_pad;
+    a.rcnt = reinterpret_cast<int *>(a.gidx2 + grid * a.n_pad);
     static const int force_scratch = [] { const char *e = getenv("PDC_SL_SCRATCH"); return e ? atoi(e) : 0; }();
     a.use_lds = (n <= kLdsMaxN && !force_scratch) ? 1 : 0;
     if (a.use_lds) {
-        const size_t lds = (size_t)kLdsFixed - 512 + (size_t)((n + 7) & ~(int64_t)7) * 2;
+        const size_t lds = (size_t)kLdsFixed + (size_t)((n + 7) & ~(int64_t)7) * 2;
         PDC_HIP(hipFuncSetAttribute((const void *)sl_scan_lds_kernel,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(sl_scan_lds_kernel, dim3((unsigned)grid), dim3(kLBlock), lds,
