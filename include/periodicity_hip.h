@@ -110,6 +110,23 @@ int pdc_gls_scan_dev(int device, void *stream,
                      double *d_power, double *d_amax, int64_t *d_argmax,
                      void *work, int64_t work_bytes);
 
+/* ---- generalized Lomb-Scargle by the reference's own algorithm ("Tier F") ------
+ * Same inputs/outputs as pdc_gls_scan, but the three _trig_sum calls (spectral.py:109-112) are
+ * evaluated the way the reference evaluates them: Press-Rybicki extirpolation onto a grid of
+ * nfft = 2^ceil(log2(5 nf)) points + inverse FFT (spectral.py:18-39), all on the device.  It takes
+ * the reference's own scalars: fmin and df (spectral.py:88-96), not the np.arange grid.  Result:
+ * the reference's `power` including its approximation error (O(N + nfft log nfft) work).
+ * pdc_trig_sums_fft is the seam: _trig_sum(t, h, df, nf, fmin) itself. */
+int64_t pdc_gls_fft_work_bytes(int64_t n, int64_t nf);
+int pdc_gls_scan_fft(const double *t, const double *y, const double *dy, int64_t n,
+                     double fmin, double df, int64_t nf, int fit_mean, int psd,
+                     double *power_out, int device);
+int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const double *d_y,
+                         const double *d_dy, int64_t n, double fmin, double df, int64_t nf,
+                         int fit_mean, int psd, double *d_power, void *work, int64_t work_bytes);
+int pdc_trig_sums_fft(const double *t, const double *h, int64_t n, double df, int64_t nf,
+                      double fmin, double *S_out, double *C_out, int device);
+
 /* ---- Phase Dispersion Minimization -----------------------------------------------------------
  * Replaces pool.map(PDM._pdm, periods) (phase.py:128-149, 185-187): theta_out[p] for every trial
  * period, bins phi in [k/m0, (k+nc)/m0) U [0, (k+nc-m0)/m0), m0 = nb*nc, phi = (t/period) % 1

@@ -48,6 +48,10 @@ PROTOTYPES = {
     "pdc_gls_work_bytes": (_L, [_L, _L, _L]),
     "pdc_gls_scan_dev": (_I, [_I, _VP, _VP, _VP, _VP, _VP, _L, _L, _I, _D, _D, _L, _L, _I, _I,
                               _VP, _VP, _VP, _VP, _L]),
+    "pdc_gls_fft_work_bytes": (_L, [_L, _L]),
+    "pdc_gls_scan_fft": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _I, _I, _VP, _I]),
+    "pdc_gls_scan_fft_dev": (_I, [_I, _VP, _VP, _VP, _VP, _L, _D, _D, _L, _I, _I, _VP, _VP, _L]),
+    "pdc_trig_sums_fft": (_I, [_VP, _VP, _L, _D, _L, _D, _VP, _VP, _I]),
     "pdc_pdm_scan": (_I, [_VP, _VP, _L, _VP, _L, _I, _I, _D, _VP, _I]),
     "pdc_pdm_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _I, _I, _D, _VP]),
     "pdc_stringlength_scan": (_I, [_VP, _VP, _L, _VP, _L, _VP, _I]),
@@ -180,6 +184,31 @@ def trig_sums(t, w, f0, delta, nf, device=None):
     S, Cc = np.empty(nf), np.empty(nf)
     dev = default_device() if device is None else device
     check(lib().pdc_trig_sums(_ptr(t), _ptr(w), t.size, f0, delta, nf, _ptr(S), _ptr(Cc), dev))
+    return S, Cc
+
+
+def gls_scan_fft(t, y, dy, fmin, df, nf, fit_mean=True, psd=False, device=None):
+    """The reference's own FFT/extirpolation algorithm on the device (Tier F)."""
+    t, y = _f64(t, "t"), _f64(y, "y")
+    dy = None if dy is None else _f64(dy, "dy")
+    if y.size != t.size or (dy is not None and dy.size != t.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    out = np.empty(nf, dtype=np.float64)
+    dev = default_device() if device is None else device
+    check(lib().pdc_gls_scan_fft(_ptr(t), _ptr(y), _ptr(dy), t.size, float(fmin), float(df), nf,
+                                 int(bool(fit_mean)), int(bool(psd)), _ptr(out), dev))
+    return out
+
+
+def trig_sums_fft(t, h, df, nf, fmin, device=None):
+    """``_trig_sum(t, h, df, nf, fmin)`` (spectral.py:11-40) on the device."""
+    t, h = _f64(t, "t"), _f64(h, "h")
+    if h.size != t.size:
+        raise ValueError("Input arrays have incompatible lengths.")
+    S, Cc = np.empty(nf), np.empty(nf)
+    dev = default_device() if device is None else device
+    check(lib().pdc_trig_sums_fft(_ptr(t), _ptr(h), t.size, float(df), nf, float(fmin), _ptr(S),
+                                  _ptr(Cc), dev))
     return S, Cc
 
 

@@ -23,6 +23,7 @@
 // No MFMA: with one weight vector per curve the accumulation is a matrix-vector product and the
 // cost is the transcendental/rotation work on the vector ALU.
 #include "pdc_internal.h"
+#include "gls_epilogue.h"
 
 #include <cstdlib>
 
@@ -122,43 +123,15 @@ __global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
     }
 }
 
-// ---- epilogue: spectral.py:113-132, written in the reference's own operation order ------------------
+// ---- epilogue: spectral.py:113-132 (gls_epilogue.h); the 2-omega sums come from the double-angle
+// identities sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a ------------------------------------------
 template <int MODE>
 __device__ __forceinline__ double gls_power(double Sh, double Ch, double S, double C, double SS,
                                             double SC, double YY, double Wsum, double Werr,
                                             int psd) {
     const double S2 = 2.0 * SC;            // sum w sin(2 omega t)
     const double C2 = Wsum - 2.0 * SS;     // sum w cos(2 omega t)
-    double tan2;
-    if (MODE == MODE_FIT_MEAN) {
-        tan2 = (S2 - 2.0 * S * C) / (C2 - (C * C - S * S));
-    } else {
-        tan2 = S2 / C2;
-    }
-    const double nrm = __builtin_sqrt(1.0 + tan2 * tan2);
-    const double S2w = tan2 / nrm;
-    const double C2w = 1.0 / nrm;
-    const double rh = __builtin_sqrt(0.5);
-    const double Cw = rh * __builtin_sqrt(1.0 + C2w);
-    const double sgn = (S2w != S2w) ? S2w : (double)((S2w > 0.0) - (S2w < 0.0));  // np.sign
-    const double Sw = rh * sgn * __builtin_sqrt(1.0 - C2w);
-    const double YC = Ch * Cw + Sh * Sw;
-    const double YS = Sh * Cw - Ch * Sw;
-    double CC = 0.5 * (1.0 + C2 * C2w + S2 * S2w);
-    double SSw = 0.5 * (1.0 - C2 * C2w - S2 * S2w);
-    if (MODE == MODE_FIT_MEAN) {
-        const double a = C * Cw + S * Sw;
-        const double b = S * Cw - C * Sw;
-        CC -= a * a;
-        SSw -= b * b;
-    }
-    double power = YC * YC / CC + YS * YS / SSw;
-    if (psd) {
-        power *= 0.5 * Werr;
-    } else {
-        power /= YY;
-    }
-    return power;
+    return gls_power_from_sums<MODE == MODE_FIT_MEAN>(Sh, Ch, S, C, S2, C2, YY, Werr, psd);
 }
 
 // ---- the scan ------------------------------------------------------------------------------------------

@@ -1,0 +1,493 @@
+// Generalized Lomb-Scargle by the reference's OWN algorithm on the device (SURVEY.md §8 f1,
+// "Tier F"): Press-Rybicki extirpolation + inverse FFT, exactly as
+// /root/reference/src/periodicity/spectral.py:11-40 (`_trig_sum`) does it on the CPU, followed by
+// the same epilogue (spectral.py:113-132).  O(N + nfft log nfft) instead of O(N nf); it inherits
+// the reference's approximation error (median ~1e-3 relative vs the exact sums) and therefore
+// reproduces `power_ref` itself, where the direct-sum kernel (gls.hip) reproduces the exact sums.
+//
+// Pipeline (all on one stream, nothing but power[nf] leaves the device):
+//   glsfft_prep_kernel     weights, centring, YY, tmin                      (spectral.py:99-108,120)
+//   glsfft_spread_kernel   one thread per sample: weights pre-rotated to fmin about tmin (:19-20),
+//                          grid position (:21), whole hits deposited (:22-24), the rest spread over
+//                          four neighbours with cubic Lagrange weights (:25-33) — fp64 global
+//                          atomics into 2 or 3 complex grids (w*y @ df, w @ 2df, w @ df)
+//   fft_pass_kernel<R>     Stockham autosort radix-16/8/4/2 passes, out of place, ping-pong between
+//                          the grid and one scratch buffer; every pass streams the array once
+//                          (HBM-bound: 32 B per point per pass), twiddles from the cycle-domain
+//                          sincos (no tables, no recurrences)                               (:34)
+//   glsfft_epilogue_kernel undo the tmin shift (:35-37), scale by nfft (:38-39), epilogue
+#include "pdc_internal.h"
+#include "gls_epilogue.h"
+
+using namespace pdc;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kPrepBlock = 1024;
+
+struct cplx {
+    double re, im;
+};
+__device__ __forceinline__ cplx operator+(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cplx operator-(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+
+// ---- in-register DFT of R = 2^m points, e^{+2 pi i jk/R} (inverse direction), natural order -------
+template <int R, int K>
+__device__ __forceinline__ cplx twiddle_const() {
+    // exp(+2 pi i K / R) for R <= 16, K < R/2
+    constexpr int q = K * (16 / R);  // sixteenths of a turn, 0..7
+    constexpr double c[8] = {1.0, 0.92387953251128675613, 0.70710678118654752440,
+                             0.38268343236508977173, 0.0, -0.38268343236508977173,
+                             -0.70710678118654752440, -0.92387953251128675613};
+    constexpr double s[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440,
+                             0.92387953251128675613, 1.0, 0.92387953251128675613,
+                             0.70710678118654752440, 0.38268343236508977173};
+    return {c[q], s[q]};
+}
+
+template <int R>
+struct Dft {
+    template <int K>
+    static __device__ __forceinline__ void combine(cplx *x, const cplx *e, const cplx *o) {
+        if constexpr (K < R / 2) {
+            cplx t;
+            if constexpr (K == 0) {
+                t = o[0];
+            } else if constexpr (4 * K == R) {
+                t = {-o[K].im, o[K].re};  // times +i
+            } else {
+                t = cmul(twiddle_const<R, K>(), o[K]);
+            }
+            x[K] = e[K] + t;
+            x[K + R / 2] = e[K] - t;
+            combine<K + 1>(x, e, o);
+        }
+    }
+    static __device__ __forceinline__ void run(cplx *x) {
+        cplx e[R / 2], o[R / 2];
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+            e[i] = x[2 * i];
+            o[i] = x[2 * i + 1];
+        }
+        Dft<R / 2>::run(e);
+        Dft<R / 2>::run(o);
+        combine<0>(x, e, o);
+    }
+};
+template <>
+struct Dft<1> {
+    static __device__ __forceinline__ void run(cplx *) {}
+};
+
+// One Stockham pass: N points, sub-transforms of length Ns become length Ns*R.
+template <int R>
+__global__ __launch_bounds__(kBlock) void fft_pass_kernel(const cplx *__restrict__ in,
+                                                          cplx *__restrict__ out, int64_t N,
+                                                          int64_t Ns) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t T = N / R;
+    if (j >= T) return;
+    const int64_t k = j & (Ns - 1);
+    cplx v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = in[j + r * T];
+    const double inv = 1.0 / (double)(Ns * R);  // power of two: exact
+#pragma unroll
+    for (int r = 1; r < R; ++r) {
+        double s, c;
+        sincos_cycles((double)(r * k) * inv, s, c);  // e^{+2 pi i r k / (Ns R)}
+        v[r] = cmul(v[r], cplx{c, s});
+    }
+    Dft<R>::run(v);
+    const int64_t j0 = (j - k) * R + k;
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[j0 + r * Ns] = v[r];
+}
+
+// ---- prologue ----------------------------------------------------------------------------------------
+struct FftPrepArgs {
+    const double *t, *y, *dy;
+    int64_t n;
+    int fit_mean;
+    double *wy, *w, *scal;  // scal = {YY, Werr, tmin}
+};
+
+__global__ __launch_bounds__(kPrepBlock) void glsfft_prep_kernel(FftPrepArgs a) {
+    __shared__ double red[kPrepBlock / 64];
+    const int tid = threadIdx.x;
+    double acc = 0.0, tmin = __builtin_inf();
+    for (int64_t i = tid; i < a.n; i += kPrepBlock) {
+        const double e = a.dy ? a.dy[i] : 1.0;
+        acc += 1.0 / (e * e);
+        tmin = a.t[i] < tmin ? a.t[i] : tmin;
+    }
+    const double W = block_sum<kPrepBlock>(acc, red);
+    for (int o = 32; o > 0; o >>= 1) {
+        const double u = __shfl_down(tmin, o, 64);
+        tmin = u < tmin ? u : tmin;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = tmin;
+    __syncthreads();
+    tmin = red[0];
+    for (int w = 1; w < kPrepBlock / 64; ++w) tmin = red[w] < tmin ? red[w] : tmin;
+    double ybar = 0.0;
+    if (a.fit_mean) {
+        acc = 0.0;
+        for (int64_t i = tid; i < a.n; i += kPrepBlock) {
+            const double e = a.dy ? a.dy[i] : 1.0;
+            acc += (1.0 / (e * e)) / W * a.y[i];
+        }
+        ybar = block_sum<kPrepBlock>(acc, red);
+    }
+    double yy = 0.0;
+    for (int64_t i = tid; i < a.n; i += kPrepBlock) {
+        const double e = a.dy ? a.dy[i] : 1.0;
+        const double w = (1.0 / (e * e)) / W;
+        const double yc = a.y[i] - ybar;
+        a.w[i] = w;
+        a.wy[i] = w * yc;
+        yy += w * yc * yc;
+    }
+    yy = block_sum<kPrepBlock>(yy, red);
+    if (tid == 0) {
+        a.scal[0] = yy;
+        a.scal[1] = W;
+        a.scal[2] = tmin;
+    }
+}
+
+// ---- extirpolation: spectral.py:18-33 ---------------------------------------------------------------
+struct SpreadArgs {
+    const double *t, *h;   // h = weights of this transform
+    const double *scal;    // scal[2] = tmin (nullptr -> tmin_value)
+    double tmin_value;
+    int64_t n, nfft;
+    double df, fmin;
+    double *grid;          // [nfft] complex, zeroed
+};
+
+__device__ __forceinline__ void grid_add(double *grid, int64_t idx, double re, double im) {
+    unsafeAtomicAdd(grid + 2 * idx, re);
+    unsafeAtomicAdd(grid + 2 * idx + 1, im);
+}
+
+__global__ __launch_bounds__(kBlock) void glsfft_spread_kernel(SpreadArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const double tmin = a.scal ? a.scal[2] : a.tmin_value;
+    const double dt = a.t[i] - tmin;
+    // w * np.exp(2j * np.pi * fmin * (t - tmin)): the phase is fl(fl(2 pi fmin) * dt) radians
+    const double ang = (6.283185307179586 * a.fmin) * dt;
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    const double hre = a.h[i] * cs, him = a.h[i] * sn;
+    // tnorm = ((t - tmin) * nfft * df) % nfft
+    const double nfftd = (double)a.nfft;
+    double tn = fmod((dt * nfftd) * a.df, nfftd);
+    if (tn != 0.0 && tn < 0.0) tn += nfftd;
+    if (tn - __builtin_floor(tn) == 0.0) {  // tnorm % 1 == 0: deposit whole
+        grid_add(a.grid, (int64_t)tn, hre, him);
+        return;
+    }
+    int64_t ilo = (int64_t)(tn - 2.0);  // astype(int): truncation toward zero
+    ilo = ilo < 0 ? 0 : (ilo > a.nfft - 4 ? a.nfft - 4 : ilo);
+    const double x = tn - (double)ilo;
+    const double prod = ((x * (x - 1.0)) * (x - 2.0)) * (x - 3.0);
+    const double nre = hre * prod, nim = him * prod;
+    const double den[4] = {6.0, -2.0, 2.0, -6.0};  // the reference's running denominator
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t ind = ilo + (3 - j);
+        const double d = den[j] * (tn - (double)ind);
+        grid_add(a.grid, ind, nre / d, nim / d);
+    }
+}
+
+// ---- epilogue: spectral.py:34-39 then :113-132 ----------------------------------------------------------
+struct FftEpiArgs {
+    const cplx *gh, *g2, *g1;  // transforms of (w y @ df), (w @ 2 df), (w @ df, may be null)
+    const double *scal;
+    int64_t nfft, nf;
+    double df, fmin;
+    int fit_mean, psd;
+    double *power;             // or raw outputs
+    double *raw_s, *raw_c;
+    double tmin_value;
+    int raw;
+};
+
+// fftgrid *= exp(2j pi tmin f), f = fmin + df*arange(nf); C = nfft*re, S = nfft*im
+__device__ __forceinline__ void finish_sum(cplx z, double tmin, double f, double nfftd, double &S,
+                                           double &C) {
+    if (tmin != 0.0) {
+        const double ang = (6.283185307179586 * tmin) * f;
+        double sn, cs;
+        sincos(ang, &sn, &cs);
+        z = cmul(z, cplx{cs, sn});
+    }
+    C = nfftd * z.re;
+    S = nfftd * z.im;
+}
+
+__global__ __launch_bounds__(kBlock) void glsfft_epilogue_kernel(FftEpiArgs a) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= a.nf) return;
+    const double nfftd = (double)a.nfft;
+    // pocketfft's ifft divides by nfft and the reference multiplies it back: do both so that the
+    // roundings match
+    const double scale = 1.0 / nfftd;
+    if (a.raw) {
+        const double tmin = a.tmin_value;
+        cplx z = a.gh[j];
+        z.re *= scale;
+        z.im *= scale;
+        double S, C;
+        finish_sum(z, tmin, a.fmin + a.df * (double)j, nfftd, S, C);
+        a.raw_s[j] = S;
+        a.raw_c[j] = C;
+        return;
+    }
+    const double tmin = a.scal[2];
+    const double f = a.fmin + a.df * (double)j;
+    double Sh, Ch, S2, C2, S = 0.0, C = 0.0;
+    cplx z = a.gh[j];
+    z.re *= scale;
+    z.im *= scale;
+    finish_sum(z, tmin, f, nfftd, Sh, Ch);
+    z = a.g2[j];
+    z.re *= scale;
+    z.im *= scale;
+    finish_sum(z, tmin, 2.0 * a.fmin + (2.0 * a.df) * (double)j, nfftd, S2, C2);
+    double p;
+    if (a.fit_mean) {
+        z = a.g1[j];
+        z.re *= scale;
+        z.im *= scale;
+        finish_sum(z, tmin, f, nfftd, S, C);
+        p = gls_power_from_sums<true>(Sh, Ch, S, C, S2, C2, a.scal[0], a.scal[1], a.psd);
+    } else {
+        p = gls_power_from_sums<false>(Sh, Ch, S, C, S2, C2, a.scal[0], a.scal[1], a.psd);
+    }
+    a.power[j] = p;
+}
+
+// ---- host side -----------------------------------------------------------------------------------------
+int64_t fft_length(int64_t nf) {
+    // 1 << int(nf * 5 - 1).bit_length()                                         (spectral.py:18)
+    int64_t v = nf * 5 - 1, bits = 0;
+    while (v > 0) {
+        ++bits;
+        v >>= 1;
+    }
+    return (int64_t)1 << bits;
+}
+
+template <int R>
+void launch_pass(hipStream_t st, const cplx *in, cplx *out, int64_t N, int64_t Ns) {
+    const int64_t T = N / R;
+    hipLaunchKernelGGL(fft_pass_kernel<R>, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock),
+                       0, st, in, out, N, Ns);
+}
+
+// Unnormalised inverse FFT of `a` (N = 2^bits points) using `b` as the other half of the ping-pong;
+// returns the buffer that holds the result.
+cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N) {
+    int bits = 0;
+    while (((int64_t)1 << bits) < N) ++bits;
+    int64_t Ns = 1;
+    cplx *src = a, *dst = b;
+    while (bits > 0) {
+        int r = bits >= 4 ? 4 : bits;
+        if (bits == 5) r = 3;  // 5 = 3 + 2 rather than 4 + 1
+        switch (r) {
+            case 4: launch_pass<16>(st, src, dst, N, Ns); break;
+            case 3: launch_pass<8>(st, src, dst, N, Ns); break;
+            case 2: launch_pass<4>(st, src, dst, N, Ns); break;
+            default: launch_pass<2>(st, src, dst, N, Ns); break;
+        }
+        Ns <<= r;
+        bits -= r;
+        cplx *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    return src;
+}
+
+struct FftLayout {
+    int64_t wy, w, scal, grid[3], scratch, total;
+};
+
+FftLayout fft_layout(int64_t n, int64_t nfft) {
+    auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+    FftLayout L;
+    L.wy = 0;
+    L.w = up(n * 8);
+    L.scal = L.w + up(n * 8);
+    int64_t off = L.scal + 256;
+    for (int g = 0; g < 3; ++g) {
+        L.grid[g] = off;
+        off += up(nfft * 16);
+    }
+    L.scratch = off;
+    L.total = off + up(nfft * 16);
+    return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t pdc_gls_fft_work_bytes(int64_t n, int64_t nf) {
+    if (n < 0 || nf < 0) return -1;
+    return fft_layout(n, fft_length(nf > 0 ? nf : 1)).total;
+}
+
+int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const double *d_y,
+                         const double *d_dy, int64_t n, double fmin, double df, int64_t nf,
+                         int fit_mean, int psd, double *d_power, void *work, int64_t work_bytes) {
+    PDC_REQUIRE(d_t && d_y && (d_power || nf == 0), "gls_fft: NULL argument");
+    PDC_REQUIRE(n >= 0 && nf >= 0 && nf < ((int64_t)1 << 40), "gls_fft: bad size");
+    if (nf == 0) return PDC_OK;
+    const int64_t nfft = fft_length(nf);
+    const FftLayout L = fft_layout(n, nfft);
+    PDC_REQUIRE(work && work_bytes >= L.total, "gls_fft: workspace too small (%lld < %lld bytes)",
+                (long long)work_bytes, (long long)L.total);
+    PDC_TRY(use_device(device));
+    hipStream_t st = (hipStream_t)stream;
+    char *base = static_cast<char *>(work);
+    double *wy = reinterpret_cast<double *>(base + L.wy);
+    double *w = reinterpret_cast<double *>(base + L.w);
+    double *scal = reinterpret_cast<double *>(base + L.scal);
+    cplx *grid[3], *scratch = reinterpret_cast<cplx *>(base + L.scratch);
+    for (int g = 0; g < 3; ++g) grid[g] = reinterpret_cast<cplx *>(base + L.grid[g]);
+
+    FftPrepArgs p{d_t, d_y, d_dy, n, fit_mean, wy, w, scal};
+    hipLaunchKernelGGL(glsfft_prep_kernel, dim3(1), dim3(kPrepBlock), 0, st, p);
+    PDC_HIP(hipGetLastError());
+
+    const int ngrid = fit_mean ? 3 : 2;
+    cplx *result[3] = {nullptr, nullptr, nullptr};
+    for (int g = 0; g < ngrid; ++g) {
+        PDC_HIP(hipMemsetAsync(grid[g], 0, (size_t)nfft * 16, st));
+        SpreadArgs s;
+        s.t = d_t;
+        s.h = g == 0 ? wy : w;
+        s.scal = scal;
+        s.tmin_value = 0.0;
+        s.n = n;
+        s.nfft = nfft;
+        s.df = g == 1 ? 2.0 * df : df;      // _trig_sum(t, w, 2 * df, nf, 2 * fmin)   (:110)
+        s.fmin = g == 1 ? 2.0 * fmin : fmin;
+        s.grid = reinterpret_cast<double *>(grid[g]);
+        if (n > 0) {
+            hipLaunchKernelGGL(glsfft_spread_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
+                               dim3(kBlock), 0, st, s);
+            PDC_HIP(hipGetLastError());
+        }
+        result[g] = inverse_fft(st, grid[g], scratch, nfft);
+        PDC_HIP(hipGetLastError());
+        if (result[g] == scratch) {
+            // keep the result in this grid's own buffer so the scratch is free for the next one
+            PDC_HIP(hipMemcpyAsync(grid[g], scratch, (size_t)nf * 16, hipMemcpyDeviceToDevice, st));
+            result[g] = grid[g];
+        }
+    }
+    FftEpiArgs e;
+    e.gh = result[0];
+    e.g2 = result[1];
+    e.g1 = result[2];
+    e.scal = scal;
+    e.nfft = nfft;
+    e.nf = nf;
+    e.df = df;
+    e.fmin = fmin;
+    e.fit_mean = fit_mean;
+    e.psd = psd;
+    e.power = d_power;
+    e.raw_s = e.raw_c = nullptr;
+    e.tmin_value = 0.0;
+    e.raw = 0;
+    hipLaunchKernelGGL(glsfft_epilogue_kernel, dim3((unsigned)((nf + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, st, e);
+    PDC_HIP(hipGetLastError());
+    return PDC_OK;
+}
+
+int pdc_gls_scan_fft(const double *t, const double *y, const double *dy, int64_t n, double fmin,
+                     double df, int64_t nf, int fit_mean, int psd, double *power_out, int device) {
+    PDC_REQUIRE(t && y && (power_out || nf == 0), "gls_fft: NULL argument");
+    PDC_REQUIRE(n >= 0 && nf >= 0, "gls_fft: negative size");
+    PDC_TRY(use_device(device));
+    DeviceLock lock(device);
+    const int64_t wb = pdc_gls_fft_work_bytes(n, nf);
+    void *d_t, *d_y, *d_dy = nullptr, *d_pow, *d_work;
+    PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
+    PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_y));
+    if (dy) PDC_TRY(cached(device, SLOT_IN2, n * 8, &d_dy));
+    PDC_TRY(cached(device, SLOT_OUT0, nf * 8, &d_pow));
+    PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
+    hipStream_t st = nullptr;
+    PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
+    if (dy) PDC_HIP(hipMemcpyAsync(d_dy, dy, n * 8, hipMemcpyHostToDevice, st));
+    PDC_TRY(pdc_gls_scan_fft_dev(device, st, (double *)d_t, (double *)d_y, (double *)d_dy, n, fmin, df,
+                                 nf, fit_mean, psd, (double *)d_pow, d_work, wb));
+    PDC_HIP(hipMemcpyAsync(power_out, d_pow, nf * 8, hipMemcpyDeviceToHost, st));
+    PDC_HIP(hipStreamSynchronize(st));
+    return PDC_OK;
+}
+
+int pdc_trig_sums_fft(const double *t, const double *h, int64_t n, double df, int64_t nf,
+                      double fmin, double *S_out, double *C_out, int device) {
+    PDC_REQUIRE(t && h && S_out && C_out, "trig_sums_fft: NULL argument");
+    PDC_REQUIRE(n >= 1 && nf >= 1, "trig_sums_fft: need at least one sample and one frequency");
+    PDC_TRY(use_device(device));
+    DeviceLock lock(device);
+    const int64_t nfft = fft_length(nf);
+    double tmin = t[0];
+    for (int64_t i = 1; i < n; ++i) tmin = t[i] < tmin ? t[i] : tmin;
+    void *d_t, *d_h, *d_s, *d_c, *d_work;
+    PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
+    PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_h));
+    PDC_TRY(cached(device, SLOT_OUT0, nf * 8, &d_s));
+    PDC_TRY(cached(device, SLOT_OUT1, nf * 8, &d_c));
+    PDC_TRY(cached(device, SLOT_WORK, nfft * 32 + 512, &d_work));
+    hipStream_t st = nullptr;
+    cplx *grid = reinterpret_cast<cplx *>(d_work), *scratch = grid + nfft;
+    PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemcpyAsync(d_h, h, n * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemsetAsync(grid, 0, (size_t)nfft * 16, st));
+    SpreadArgs s{(double *)d_t, (double *)d_h, nullptr, tmin, n, nfft, df, fmin,
+                 reinterpret_cast<double *>(grid)};
+    hipLaunchKernelGGL(glsfft_spread_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock),
+                       0, st, s);
+    PDC_HIP(hipGetLastError());
+    cplx *res = inverse_fft(st, grid, scratch, nfft);
+    PDC_HIP(hipGetLastError());
+    FftEpiArgs e{};
+    e.gh = res;
+    e.nfft = nfft;
+    e.nf = nf;
+    e.df = df;
+    e.fmin = fmin;
+    e.raw_s = (double *)d_s;
+    e.raw_c = (double *)d_c;
+    e.tmin_value = tmin;
+    e.raw = 1;
+    hipLaunchKernelGGL(glsfft_epilogue_kernel, dim3((unsigned)((nf + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, st, e);
+    PDC_HIP(hipGetLastError());
+    PDC_HIP(hipMemcpyAsync(S_out, d_s, nf * 8, hipMemcpyDeviceToHost, st));
+    PDC_HIP(hipMemcpyAsync(C_out, d_c, nf * 8, hipMemcpyDeviceToHost, st));
+    PDC_HIP(hipStreamSynchronize(st));
+    return PDC_OK;
+}
+
+}  // extern "C"

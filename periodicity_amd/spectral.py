@@ -42,26 +42,39 @@ class GLS(object):
         Samples per peak (default 5): grid spacing is ``1 / baseline / n``.
     psd: bool, optional
         Leave the periodogram un-normalised.
+    method: {"direct", "fft"}, keyword-only, optional
+        ``"direct"`` (default): exact direct summation of the trig sums (``spectral.py:13-15``).
+        ``"fft"``: the reference's own Press-Rybicki extirpolation + FFT (``spectral.py:18-39``)
+        on the device — reproduces upstream's values including their approximation error.
     device: int, keyword-only, optional
         GPU ordinal (default ``$PERIODICITY_AMD_DEVICE`` or 0).
     devices: sequence of int, keyword-only, optional
         Shard the frequency grid over these GPUs of one node (RCCL all-gather of the power array).
     """
 
-    def __init__(self, fmin=None, fmax=None, n=5, psd=False, *, device=None, devices=None):
+    def __init__(self, fmin=None, fmax=None, n=5, psd=False, *, method="direct", device=None,
+                 devices=None):
+        if method not in ("direct", "fft"):
+            raise ValueError("method must be 'direct' or 'fft'")
         self.fmin = fmin
         self.fmax = fmax
         self.n = n
         self.psd = psd
+        self.method = method
         self.device = device
         self.devices = None if devices is None else tuple(devices)
+
+    def _grid_scalars(self, signal):
+        """``df``, ``fmin``, ``fmax`` of ``spectral.py:88-96``."""
+        df = 1.0 / signal.baseline / self.n
+        fmin = 0.5 * df if self.fmin is None else self.fmin
+        fmax = 0.5 / signal.median_dt if self.fmax is None else self.fmax
+        return df, fmin, fmax
 
     def _grid(self, signal):
         """Uniform frequency grid of ``spectral.py:88-98`` — built by ``np.arange`` itself so its
         length and values carry numpy's rounding; the kernel reproduces ``start + j*step``."""
-        df = 1.0 / signal.baseline / self.n
-        fmin = 0.5 * df if self.fmin is None else self.fmin
-        fmax = 0.5 / signal.median_dt if self.fmax is None else self.fmax
+        df, fmin, fmax = self._grid_scalars(signal)
         return np.arange(fmin, fmax + df, df)
 
     def __call__(self, signal, err=None, fit_mean=True):
@@ -84,7 +97,12 @@ class GLS(object):
         dy = np.asarray(err, dtype=float) if have_err else None
         t = np.asarray(signal.time, dtype=float)
         y = np.asarray(signal.values, dtype=float)
-        if self.devices is not None and len(self.devices) > 1:
+        if self.method == "fft":
+            # the reference's own extirpolation + FFT evaluation of the trig sums, on the device
+            df, fmin, _ = self._grid_scalars(signal)
+            dev = self.device if self.devices is None else self.devices[0]
+            power = _cabi.gls_scan_fft(t, y, dy, fmin, df, nf, fit_mean, self.psd, device=dev)
+        elif self.devices is not None and len(self.devices) > 1:
             power = _cabi.gls_scan_multi(t, y, dy, f0, delta, nf, fit_mean, self.psd,
                                          self.devices)
         else:

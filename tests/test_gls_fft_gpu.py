@@ -1,0 +1,134 @@
+"""Tier F: the device FFT-extirpolation path (GLS(method="fft"), pdc_gls_scan_fft,
+pdc_trig_sums_fft) reproduces the UNMODIFIED reference — `power_ref` goldens and the numpy
+restatement of spectral.py:11-40 — including its approximation error.
+
+Gate: |d| <= 1e-9 |ref| + 1e-12 max|ref| (the FFT path computes every bin with an absolute error
+of a few ulps of the largest one, so tiny bins carry no relative accuracy in the reference
+either)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import scan_oracle as so
+from periodicity_amd import _cabi
+from periodicity_amd.core import TSeries
+from periodicity_amd.spectral import GLS
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def assert_tier_f(got, ref, rtol=1e-9, afloor=1e-12):
+    ref = np.asarray(ref)
+    ok = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), ok)
+    scale = np.max(np.abs(ref[ok]))
+    err = np.abs(got[ok] - ref[ok])
+    bound = rtol * np.abs(ref[ok]) + afloor * scale
+    assert np.all(err <= bound), (np.max(err / bound), int(np.argmax(err / bound)))
+
+
+def synth(n, seed, t_offset=0.0):
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(0, float(n), n)) + t_offset
+    dy = rng.uniform(0.05, 0.2, n)
+    y = 1.0 + 0.5 * np.sin(2 * np.pi * t / 37.3) + dy * rng.standard_normal(n)
+    return t, y, dy
+
+
+@pytest.mark.parametrize("n", [1000, 5000])
+def test_trig_sum_seam_matches_reference_fft(golden_dir, n):
+    g = load(golden_dir, f"g4_synth{n}")
+    t, y, dy, f = g["t"], g["y"], g["dy"], g["frequency"]
+    df, fmin = float(g["df"]), float(g["fmin"])
+    w, yc, _ = so.gls_weights(y, dy, True)
+    for h, d, f0, sname, cname in ((w * yc, df, fmin, "Sh_fft", "Ch_fft"),
+                                   (w, 2 * df, 2 * fmin, "S2_fft", "C2_fft"),
+                                   (w, df, fmin, "S_fft", "C_fft")):
+        S, C = _cabi.trig_sums_fft(t, h, d, f.size, f0)
+        amp = np.max(np.hypot(g[sname], g[cname]))
+        assert np.max(np.abs(S - g[sname])) <= 1e-13 * amp * np.sqrt(n)
+        assert np.max(np.abs(C - g[cname])) <= 1e-13 * amp * np.sqrt(n)
+
+
+def test_reference_known_answers_through_the_fft_path(golden_dir):
+    g = load(golden_dir, "g2_sine100")
+    ls = GLS(method="fft")(TSeries(values=g["values"]))
+    assert np.array_equal(ls.frequency, g["frequency"])
+    assert ls.period_at_highest_peak == 10.0 and ls.argmax() == 49
+    ok = np.abs(g["power_ref"]) > 1e-9        # bins 148/247: exact zero / Nyquist singularity
+    assert_tier_f(ls.values[ok], g["power_ref"][ok], afloor=1e-11)
+    # the >1 maximum of the reference (extirpolation error made visible) is reproduced
+    assert abs(ls.values.max() - g["power_ref"].max()) < 1e-12
+
+
+@pytest.mark.parametrize("fit_mean", [True, False])
+@pytest.mark.parametrize("psd", [False, True])
+def test_spotted_star_power_ref(golden_dir, fit_mean, psd):
+    g = load(golden_dir, "g3_spotted_star")
+    ls = GLS(psd=psd, method="fft")(TSeries(g["t"], g["y"]), err=g["dy"], fit_mean=fit_mean)
+    ref = g[f"power_ref_fm{int(fit_mean)}_psd{int(psd)}"]
+    assert_tier_f(ls.values, ref)
+    assert ls.argmax() == int(np.nanargmax(ref))
+
+
+def test_spotted_star_without_errors_and_window(golden_dir):
+    g = load(golden_dir, "g3_spotted_star")
+    ls = GLS(method="fft")(TSeries(g["t"], g["y"]))
+    assert_tier_f(ls.values, g["power_ref_noerr"])
+    g = load(golden_dir, "g5_window")
+    gls = GLS(method="fft")
+    gls(TSeries(g["t"], g["y"]), err=g["dy"])
+    assert_tier_f(gls.window().values, g["power_ref"], afloor=1e-11)
+
+
+@pytest.mark.parametrize("n", [1000, 5000])
+def test_synthetic_power_ref(golden_dir, n):
+    g = load(golden_dir, f"g4_synth{n}")
+    ls = GLS(method="fft")(TSeries(g["t"], g["y"]), err=g["dy"])
+    assert_tier_f(ls.values, g["power_ref"])
+    # and it differs from the exact sums by the reference's own approximation error
+    assert 1e-7 < np.max(np.abs(ls.values - g["power_exact"])) < 1e-3
+
+
+@pytest.mark.parametrize("kw", [dict(n=1), dict(n=3.3), dict(fmin=0.01, fmax=0.4),
+                                dict(fmin=0.2, fmax=0.2004)])
+def test_grids_and_time_offsets_vs_numpy_restatement(kw):
+    for off in (0.0, 2454953.5, -321.25):
+        t, y, dy = synth(700, 3, t_offset=off)
+        freq, power = so.gls(t, y, dy, **kw)
+        ls = GLS(method="fft", **kw)(TSeries(t, y), err=dy)
+        assert np.array_equal(ls.frequency, freq)
+        assert_tier_f(ls.values, power, rtol=1e-8, afloor=1e-10)
+
+
+def test_fft_sizes_cover_every_radix_combination():
+    # nfft = 2^k for k = 3 .. 21: every mix of radix-16/8/4/2 passes and both ping-pong parities
+    t, y, dy = synth(300, 8)
+    w, yc, _ = so.gls_weights(y, dy, True)
+    for k in range(3, 22):
+        nf = max(1, (1 << k) // 5)
+        assert 1 << int(nf * 5 - 1).bit_length() == 1 << k
+        df, fmin = 0.37 / (1 << k), 0.11 / (1 << k)
+        S, C = _cabi.trig_sums_fft(t, w * yc, df, nf, fmin)
+        Sr, Cr = so.trig_sum_fft(t, w * yc, df, nf, fmin)
+        amp = np.max(np.hypot(Sr, Cr))
+        assert np.max(np.abs(S - Sr)) <= 1e-12 * amp and np.max(np.abs(C - Cr)) <= 1e-12 * amp, k
+
+
+def test_full_size_c2_matches_cpu_reference_path():
+    n, nf = 100_000, 1_000_000
+    t, y, dy = synth(n, 20241010)
+    df = 1.0 / (t[-1] - t[0]) / 5
+    fmin = 0.5 * df
+    got = _cabi.gls_scan_fft(t, y, dy, fmin, df, nf)
+    freq = fmin + df * np.arange(nf)
+    want = so.gls_power(t, y, dy, freq, df, fmin, sums="fft")
+    assert_tier_f(got, want, rtol=1e-8, afloor=1e-11)
+    assert int(np.argmax(got)) == int(np.argmax(want))
+    direct = _cabi.gls_scan(t, y, dy, fmin, df, nf)
+    assert int(np.argmax(direct)) == int(np.argmax(got))      # tier R, the other way round

@@ -94,7 +94,7 @@ def run_gls(tm, name, t, y, dy, offsets, nb, f0, delta, nf, reps, shared_t=0, pe
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--only", default="c1,c2,c3,c3peaks,c3shared,c5pdm,c5sl")
+    ap.add_argument("--only", default="c1,c2,c2fft,c3,c3peaks,c3shared,c5pdm,c5sl")
     args = ap.parse_args()
     only = set(args.only.split(","))
     tm = Timer()
@@ -105,6 +105,24 @@ def main():
     if "c2" in only:
         t, y, dy = synth(100_000, 2)
         out.append(run_gls(tm, "C2 GLS 1e5 x 1e6", t, y, dy, None, 1, *grid(t, 1_000_000), args.reps))
+    for tag, n_s, nf_s in (("c2fft", 100_000, 1_000_000), ("c4fft", 1_000_000, 10_000_000)):
+        if tag in only:
+            t, y, dy = synth(n_s, 2)
+            f0, delta, nf = grid(t, nf_s)
+            df = 1.0 / (t[-1] - t[0]) / 5
+            bt, by, bdy = dbuf(t), dbuf(y), dbuf(dy)
+            wb = lib.pdc_gls_fft_work_bytes(n_s, nf)
+            work = _cabi.DeviceBuffer(wb, DEV)
+            power = _cabi.DeviceBuffer(nf * 8, DEV)
+            med, best = tm.time(lambda: _cabi.check(lib.pdc_gls_scan_fft_dev(
+                DEV, tm.stream, bt.ptr, by.ptr, bdy.ptr, n_s, 0.5 * df, df, nf, 1, 0, power.ptr,
+                work.ptr, wb)), args.reps)
+            out.append({"config": f"{tag.upper()} GLS FFT-extirpolation path N={n_s} nf={nf} (Tier F)",
+                        "pairs": float(n_s) * nf, "ms_median": round(med, 4), "ms_min": round(best, 4),
+                        "effective_Gpair_per_s": round(n_s * nf / med / 1e6, 1),
+                        "work_MiB": round(wb / 2**20, 1)})
+            for b in (bt, by, bdy, work, power):
+                b.free()
     if only & {"c3", "c3peaks", "c3shared"}:
         B, n, nf = 4096, 2000, 50_000
         rng = np.random.default_rng(20241008 + 3)
