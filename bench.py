@@ -237,6 +237,28 @@ def main():
                                  "the direct-evaluation roofline"},
             "peak_bin": int(np.nanargmax(got)),
         }
+        if world == 1 and not dist_mode:
+            # informational: the reference's own algorithm on the device (Tier F), same workload
+            wb = lib.pdc_gls_fft_work_bytes(n, nf_total)
+            fwork = _cabi.DeviceBuffer(wb, dev)
+            ev = (new_event(), new_event())
+            fms = []
+            for _ in range(6):
+                _cabi.check(lib.pdc_event_record(dev, ev[0], stream))
+                _cabi.check(lib.pdc_gls_scan_fft_dev(dev, stream, d_t, d_y, d_dy, n, fmin, df,
+                                                     nf_total, 1, 0, d_power_slab, fwork.ptr, wb))
+                _cabi.check(lib.pdc_event_record(dev, ev[1], stream))
+                ms = C.c_float()
+                _cabi.check(lib.pdc_event_elapsed_ms(dev, ev[0], ev[1], C.byref(ms)))
+                fms.append(ms.value)
+            fft_power = power_buf.to_array(np.float64, nf_total)
+            out["fft_path"] = {"ms": round(float(np.median(fms[1:])), 4),
+                               "effective_Gpair_per_s": round(pairs_per_step / np.median(fms[1:]) / 1e6, 1),
+                               "peak_bin": int(np.nanargmax(fft_power)),
+                               "note": "pdc_gls_scan_fft_dev: the reference's extirpolation + FFT "
+                                       "algorithm on the device (approximate, like upstream); not "
+                                       "the headline metric, which counts exact pair evaluations"}
+            fwork.free()
         if not args.no_cpu_baseline and world == 1:
             base, p_fft = cpu_baseline(t, y, dy, freq, df, fmin)
             out["cpu_baseline"] = base

@@ -6,7 +6,7 @@
 // reproduces `power_ref` itself, where the direct-sum kernel (gls.hip) reproduces the exact sums.
 //
 // Pipeline (all on one stream, nothing but power[nf] leaves the device):
-//   glsfft_prep_kernel     weights, centring, YY, tmin                      (spectral.py:99-108,120)
+//   glsfft_prep_{a,c}      weights, centring, YY, tmin (grid-wide, fixed-order partials)  (:99-108,120)
 //   glsfft_spread_kernel   one thread per sample: weights pre-rotated to fmin about tmin (:19-20),
 //                          grid position (:21), whole hits deposited (:22-24), the rest spread over
 //                          four neighbours with cubic Lagrange weights (:25-33) — fp64 global
@@ -24,7 +24,6 @@ using namespace pdc;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kPrepBlock = 1024;
 
 struct cplx {
     double re, im;
@@ -109,44 +108,74 @@ __global__ __launch_bounds__(kBlock) void fft_pass_kernel(const cplx *__restrict
     for (int r = 0; r < R; ++r) out[j0 + r * Ns] = v[r];
 }
 
-// ---- prologue ----------------------------------------------------------------------------------------
+// ---- prologue: spectral.py:99-108, 120 -- two grid-wide kernels, deterministic partials ------------
+// A: per-workgroup partial sums of err^-2 and err^-2 * y and the partial minimum of t.
+// C: every workgroup re-reduces A's partials (<= kMaxPart, fixed order -> identical in all of them),
+//    writes w and w*y and its partial of YY = sum w y^2.  Consumers reduce the YY partials the same way.
+constexpr int kMaxPart = 512;
+
 struct FftPrepArgs {
     const double *t, *y, *dy;
     int64_t n;
-    int fit_mean;
-    double *wy, *w, *scal;  // scal = {YY, Werr, tmin}
+    int fit_mean, nparts;
+    double *wy, *w;
+    double *part;   // [3][kMaxPart]: sum err^-2 | sum err^-2 y | min t
+    double *ypart;  // [kMaxPart]: partial YY
+    double *scal;   // {YY (filled by the epilogue's reduction), Werr, tmin}
 };
 
-__global__ __launch_bounds__(kPrepBlock) void glsfft_prep_kernel(FftPrepArgs a) {
-    __shared__ double red[kPrepBlock / 64];
-    const int tid = threadIdx.x;
-    double acc = 0.0, tmin = __builtin_inf();
-    for (int64_t i = tid; i < a.n; i += kPrepBlock) {
+__device__ __forceinline__ double block_min_256(double v, double *red) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const double u = __shfl_down(v, o, 64);
+        v = u < v ? u : v;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int w = 1; w < kBlock / 64; ++w) r = red[w] < r ? red[w] : r;
+    return r;
+}
+
+__global__ __launch_bounds__(kBlock) void glsfft_prep_a_kernel(FftPrepArgs a) {
+    __shared__ double red[kBlock / 64];
+    double sw = 0.0, swy = 0.0, tmin = __builtin_inf();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
         const double e = a.dy ? a.dy[i] : 1.0;
-        acc += 1.0 / (e * e);
+        const double wr = 1.0 / (e * e);
+        sw += wr;
+        swy += wr * a.y[i];
         tmin = a.t[i] < tmin ? a.t[i] : tmin;
     }
-    const double W = block_sum<kPrepBlock>(acc, red);
-    for (int o = 32; o > 0; o >>= 1) {
-        const double u = __shfl_down(tmin, o, 64);
+    sw = block_sum<kBlock>(sw, red);
+    swy = block_sum<kBlock>(swy, red);
+    tmin = block_min_256(tmin, red);
+    if (threadIdx.x == 0) {
+        a.part[blockIdx.x] = sw;
+        a.part[kMaxPart + blockIdx.x] = swy;
+        a.part[2 * kMaxPart + blockIdx.x] = tmin;
+    }
+}
+
+// fixed-order reduction of `count` partials by one workgroup (identical result in every workgroup)
+__device__ __forceinline__ double reduce_partials(const double *p, int count, double *red) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < count; i += kBlock) v += p[i];
+    return block_sum<kBlock>(v, red);
+}
+
+__global__ __launch_bounds__(kBlock) void glsfft_prep_c_kernel(FftPrepArgs a) {
+    __shared__ double red[kBlock / 64];
+    const double W = reduce_partials(a.part, a.nparts, red);
+    const double ybar = a.fit_mean ? reduce_partials(a.part + kMaxPart, a.nparts, red) / W : 0.0;
+    double tmin = __builtin_inf();
+    for (int i = threadIdx.x; i < a.nparts; i += kBlock) {
+        const double u = a.part[2 * kMaxPart + i];
         tmin = u < tmin ? u : tmin;
     }
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = tmin;
-    __syncthreads();
-    tmin = red[0];
-    for (int w = 1; w < kPrepBlock / 64; ++w) tmin = red[w] < tmin ? red[w] : tmin;
-    double ybar = 0.0;
-    if (a.fit_mean) {
-        acc = 0.0;
-        for (int64_t i = tid; i < a.n; i += kPrepBlock) {
-            const double e = a.dy ? a.dy[i] : 1.0;
-            acc += (1.0 / (e * e)) / W * a.y[i];
-        }
-        ybar = block_sum<kPrepBlock>(acc, red);
-    }
+    tmin = block_min_256(tmin, red);
     double yy = 0.0;
-    for (int64_t i = tid; i < a.n; i += kPrepBlock) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
         const double e = a.dy ? a.dy[i] : 1.0;
         const double w = (1.0 / (e * e)) / W;
         const double yc = a.y[i] - ybar;
@@ -154,11 +183,13 @@ __global__ __launch_bounds__(kPrepBlock) void glsfft_prep_kernel(FftPrepArgs a) 
         a.wy[i] = w * yc;
         yy += w * yc * yc;
     }
-    yy = block_sum<kPrepBlock>(yy, red);
-    if (tid == 0) {
-        a.scal[0] = yy;
-        a.scal[1] = W;
-        a.scal[2] = tmin;
+    yy = block_sum<kBlock>(yy, red);
+    if (threadIdx.x == 0) {
+        a.ypart[blockIdx.x] = yy;
+        if (blockIdx.x == 0) {
+            a.scal[1] = W;
+            a.scal[2] = tmin;
+        }
     }
 }
 
@@ -213,6 +244,8 @@ __global__ __launch_bounds__(kBlock) void glsfft_spread_kernel(SpreadArgs a) {
 struct FftEpiArgs {
     const cplx *gh, *g2, *g1;  // transforms of (w y @ df), (w @ 2 df), (w @ df, may be null)
     const double *scal;
+    const double *ypart;       // partial YY sums (nparts of them)
+    int nparts;
     int64_t nfft, nf;
     double df, fmin;
     int fit_mean, psd;
@@ -236,6 +269,8 @@ __device__ __forceinline__ void finish_sum(cplx z, double tmin, double f, double
 }
 
 __global__ __launch_bounds__(kBlock) void glsfft_epilogue_kernel(FftEpiArgs a) {
+    __shared__ double red[kBlock / 64];
+    const double YY = a.raw ? 0.0 : reduce_partials(a.ypart, a.nparts, red);
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= a.nf) return;
     const double nfftd = (double)a.nfft;
@@ -270,9 +305,9 @@ __global__ __launch_bounds__(kBlock) void glsfft_epilogue_kernel(FftEpiArgs a) {
         z.re *= scale;
         z.im *= scale;
         finish_sum(z, tmin, f, nfftd, S, C);
-        p = gls_power_from_sums<true>(Sh, Ch, S, C, S2, C2, a.scal[0], a.scal[1], a.psd);
+        p = gls_power_from_sums<true>(Sh, Ch, S, C, S2, C2, YY, a.scal[1], a.psd);
     } else {
-        p = gls_power_from_sums<false>(Sh, Ch, S, C, S2, C2, a.scal[0], a.scal[1], a.psd);
+        p = gls_power_from_sums<false>(Sh, Ch, S, C, S2, C2, YY, a.scal[1], a.psd);
     }
     a.power[j] = p;
 }
@@ -330,7 +365,7 @@ FftLayout fft_layout(int64_t n, int64_t nfft) {
     L.wy = 0;
     L.w = up(n * 8);
     L.scal = L.w + up(n * 8);
-    int64_t off = L.scal + 256;
+    int64_t off = L.scal + up((4 * kMaxPart + 8) * 8);  // scal[8] | part[3][kMaxPart] | ypart[kMaxPart]
     for (int g = 0; g < 3; ++g) {
         L.grid[g] = off;
         off += up(nfft * 16);
@@ -368,8 +403,11 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
     cplx *grid[3], *scratch = reinterpret_cast<cplx *>(base + L.scratch);
     for (int g = 0; g < 3; ++g) grid[g] = reinterpret_cast<cplx *>(base + L.grid[g]);
 
-    FftPrepArgs p{d_t, d_y, d_dy, n, fit_mean, wy, w, scal};
-    hipLaunchKernelGGL(glsfft_prep_kernel, dim3(1), dim3(kPrepBlock), 0, st, p);
+    int nparts = (int)((n + 4 * kBlock - 1) / (4 * kBlock));
+    nparts = nparts < 1 ? 1 : (nparts > kMaxPart ? kMaxPart : nparts);
+    FftPrepArgs p{d_t, d_y, d_dy, n, fit_mean, nparts, wy, w, scal + 8, scal + 8 + 3 * kMaxPart, scal};
+    hipLaunchKernelGGL(glsfft_prep_a_kernel, dim3(nparts), dim3(kBlock), 0, st, p);
+    hipLaunchKernelGGL(glsfft_prep_c_kernel, dim3(nparts), dim3(kBlock), 0, st, p);
     PDC_HIP(hipGetLastError());
 
     const int ngrid = fit_mean ? 3 : 2;
@@ -404,6 +442,8 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
     e.g2 = result[1];
     e.g1 = result[2];
     e.scal = scal;
+    e.ypart = p.ypart;
+    e.nparts = nparts;
     e.nfft = nfft;
     e.nf = nf;
     e.df = df;
