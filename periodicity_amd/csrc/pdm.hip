@@ -49,7 +49,12 @@ __device__ __forceinline__ double block_reduce(double v, double *red, bool take_
     return r;
 }
 
-template <int BLOCK>
+// SPLIT waves of a workgroup share one group of 64 trial periods (lane = period) and split every
+// staged chunk of samples between them, so that a grid of ~1e5 periods still puts several waves on
+// every SIMD (the loop is a chain of LDS read -> ALU -> LDS atomic: it needs wave-level parallelism
+// to hide latency).  Each thread keeps its own private histogram; the SPLIT partial histograms of
+// a period are summed in a fixed order at the end.
+template <int BLOCK, int SPLIT>
 __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int m0 = a.nb * a.nc;
@@ -83,7 +88,10 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     }
     const double q_total = block_reduce<BLOCK>(acc, red, false);
 
-    const int64_t pidx = (int64_t)blockIdx.x * BLOCK + tid;
+    constexpr int PERIODS = BLOCK / SPLIT;       // trial periods per workgroup
+    const int wave = tid >> 6, part = wave % SPLIT;
+    const int slot = (wave / SPLIT) * 64 + (tid & 63);  // period slot inside the workgroup
+    const int64_t pidx = (int64_t)blockIdx.x * PERIODS + slot;
     const double period = pidx < a.n_periods ? a.periods[pidx] : 1.0;
     const double rp = 1.0 / period;
     const double dm0 = (double)m0;
@@ -102,30 +110,68 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         }
         __syncthreads();
         const int cnt = (int)((a.n - base) < kChunk ? (a.n - base) : kChunk);
-        for (int i = 0; i < cnt; ++i) {
-            const double2 tx = stage[i];
+        const int i_end = cnt < (part + 1) * (kChunk / SPLIT) ? cnt : (part + 1) * (kChunk / SPLIT);
+        // two samples per trip: two independent read -> bin -> atomic chains in flight per wave
+        auto bin_of = [&](const double2 tx, int &k) -> bool {
             const double q = tx.x * rp;
             const double fr = q - __builtin_floor(q);
             const double u = fr * dm0;
-            int k = (int)u;
+            k = (int)u;
             const double g = u - (double)k;
-            if (!(__builtin_fabs(g - 0.5) < thr)) {
-                // exact path: numpy's float remainder of the IEEE quotient, explicit edges
-                const double qe = tx.x / period;
-                double phi = qe - __builtin_floor(qe);  // == fmod-based Python % for divisor 1
-                if (phi != phi) continue;               // NaN phase belongs to no bin
-                k = (int)(phi * dm0);
-                k = k < 0 ? 0 : (k > m0 ? m0 : k);
-                while (k > 0 && phi < edge[k]) --k;
-                while (k < m0 && phi >= edge[k + 1]) ++k;
-                if (k == m0) q_over += tx.y * tx.y;
+            if (__builtin_fabs(g - 0.5) < thr) return true;
+            // exact path: numpy's float remainder of the IEEE quotient, explicit edges
+            const double qe = tx.x / period;
+            const double phi = qe - __builtin_floor(qe);  // == fmod-based Python % for divisor 1
+            if (phi != phi) return false;                 // NaN phase belongs to no bin
+            k = (int)(phi * dm0);
+            k = k < 0 ? 0 : (k > m0 ? m0 : k);
+            while (k > 0 && phi < edge[k]) --k;
+            while (k < m0 && phi >= edge[k + 1]) ++k;
+            if (k == m0) q_over += tx.y * tx.y;
+            return true;
+        };
+        int i = part * (kChunk / SPLIT);
+        for (; i + 1 < i_end; i += 2) {
+            const double2 ta = stage[i], tb = stage[i + 1];
+            int ka, kb;
+            const bool oa = bin_of(ta, ka), ob = bin_of(tb, kb);
+            if (oa) {
+                atomicAdd(&hsum[ka * BLOCK + tid], ta.y);
+                atomicAdd(&hcnt[ka * BLOCK + tid], 1u);
             }
-            atomicAdd(&hsum[k * BLOCK + tid], tx.y);
-            atomicAdd(&hcnt[k * BLOCK + tid], 1u);
+            if (ob) {
+                atomicAdd(&hsum[kb * BLOCK + tid], tb.y);
+                atomicAdd(&hcnt[kb * BLOCK + tid], 1u);
+            }
+        }
+        if (i < i_end) {
+            const double2 ta = stage[i];
+            int ka;
+            if (bin_of(ta, ka)) {
+                atomicAdd(&hsum[ka * BLOCK + tid], ta.y);
+                atomicAdd(&hcnt[ka * BLOCK + tid], 1u);
+            }
         }
     }
 
-    if (pidx >= a.n_periods) return;
+    if (SPLIT > 1) {
+        // fold the partial histograms of parts 1..SPLIT-1 into part 0 (threads tid + 64*q)
+        __syncthreads();
+        double *qx = reinterpret_cast<double *>(stage);  // q_over exchange, [BLOCK]
+        qx[tid] = q_over;
+        __syncthreads();
+        if (part == 0) {
+            for (int q = 1; q < SPLIT; ++q) {
+                const int other = tid + 64 * q;
+                for (int k = 0; k < nbins; ++k) {
+                    hsum[k * BLOCK + tid] += hsum[k * BLOCK + other];
+                    hcnt[k * BLOCK + tid] += hcnt[k * BLOCK + other];
+                }
+                q_over += qx[other];
+            }
+        }
+    }
+    if (part != 0 || pidx >= a.n_periods) return;
     // covers: phase.py:137-147
     double num = (double)a.nc * q_total - q_over;
     long long n_sum = 0;
@@ -180,15 +226,28 @@ int pdc_pdm_scan_dev(int device, void *stream, const double *d_t, const double *
     hipStream_t st = (hipStream_t)stream;
     if (lds_bytes(m0, 256) <= 150 * 1024) {
         const size_t lds = lds_bytes(m0, 256);
-        PDC_HIP(hipFuncSetAttribute((const void *)pdm_scan_kernel<256>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(pdm_scan_kernel<256>, dim3((unsigned)((n_periods + 255) / 256)), dim3(256),
-                           lds, st, a);
+        // waves = ceil(P/64) * SPLIT; aim at >= 4 waves per SIMD (4096 on the chip)
+        const int64_t groups = (n_periods + 63) / 64;
+        const int split = groups >= 4096 ? 1 : (groups >= 2048 ? 2 : 4);
+        auto launch = [&](auto kernel, int periods_per_block) -> int {
+            PDC_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+            hipLaunchKernelGGL(kernel, dim3((unsigned)((n_periods + periods_per_block - 1) / periods_per_block)),
+                               dim3(256), lds, st, a);
+            return PDC_OK;
+        };
+        if (split == 4) {
+            PDC_TRY(launch(pdm_scan_kernel<256, 4>, 64));
+        } else if (split == 2) {
+            PDC_TRY(launch(pdm_scan_kernel<256, 2>, 128));
+        } else {
+            PDC_TRY(launch(pdm_scan_kernel<256, 1>, 256));
+        }
     } else {
         const size_t lds = lds_bytes(m0, 64);
-        PDC_HIP(hipFuncSetAttribute((const void *)pdm_scan_kernel<64>,
+        PDC_HIP(hipFuncSetAttribute((const void *)pdm_scan_kernel<64, 1>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(pdm_scan_kernel<64>, dim3((unsigned)((n_periods + 63) / 64)), dim3(64), lds,
+        hipLaunchKernelGGL((pdm_scan_kernel<64, 1>), dim3((unsigned)((n_periods + 63) / 64)), dim3(64), lds,
                            st, a);
     }
     PDC_HIP(hipGetLastError());
