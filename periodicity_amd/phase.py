@@ -1,12 +1,16 @@
 """Phase-folding period scans with the reference's callable API, computed on MI355X.
 
 Drop-in for ``periodicity.phase`` (``/root/reference/src/periodicity/phase.py``):
-``StringLength(dphi, n_periods, cores)(signal) -> FSeries`` and
-``PDM(nb, nc, p_min, p_max, n_periods, oversample, do_subharmonic, cores)(signal) -> FSeries``
-with the same positional order, defaults and attribute side effects.  The reference maps one
-Python task per trial period over a ``multiprocessing.Pool`` (``phase.py:69-70,185-186``); here
-the whole period grid is one kernel launch (``csrc/stringlength.hip``, ``csrc/pdm.hip``), so
-``cores`` is accepted for compatibility and ignored.  Nothing here computes a scan on the CPU.
+
+* ``StringLength(dphi, n_periods, cores)(signal) -> FSeries``   (``phase.py:18-72``)
+* ``PDM(nb, nc, p_min, p_max, n_periods, oversample, do_subharmonic, cores)(signal) -> FSeries``
+  (``phase.py:75-195``)
+
+Positional order, defaults and the attributes each call leaves behind (``.signal .m
+.periodogram`` / ``.signal .t .x .sigma .periods .periodogram``) are the reference's.  Upstream maps
+one Python task per trial period over a ``multiprocessing.Pool`` (``phase.py:69-70,185-186``);
+here a whole period grid is ONE kernel launch (``csrc/stringlength.hip``, ``csrc/pdm.hip``), so
+``cores`` is kept only for signature compatibility.  No scan is ever computed on the CPU.
 """
 from multiprocessing import cpu_count
 
@@ -20,127 +24,146 @@ MAX_CORES = cpu_count()
 __all__ = ["StringLength", "PDM"]
 
 
-def _as_tseries(signal):
-    if isinstance(signal, TSeries) or (hasattr(signal, "time") and hasattr(signal, "values")
-                                       and hasattr(signal, "baseline")):
-        return signal
-    return TSeries(values=signal)
+# ---- host-side grid / scaling rules (O(N) or O(n_periods) numpy, as upstream) -----------------------
+def _coerce(signal):
+    """Raw array-likes become ``TSeries(values=...)`` (``phase.py:62-63,160-161``); anything that
+    already looks like a time series (ours or the reference's xarray-backed one) passes through."""
+    looks_like_series = all(hasattr(signal, name) for name in ("time", "values", "baseline"))
+    return signal if isinstance(signal, TSeries) or looks_like_series else TSeries(values=signal)
+
+
+def _quarter_scaled(values):
+    """Map the signal onto [-0.25, +0.25] — the intent stated at ``phase.py:65-66`` (NaN-aware
+    extrema, ``core.py:202-240``)."""
+    top, bottom = np.nanmax(values), np.nanmin(values)
+    return (values - top) / (2 * (top - bottom)) + 0.25
+
+
+def _string_periods(baseline, dphi, count):
+    """``count`` trial periods equally spaced in FREQUENCY, from ``baseline / (dphi * count)`` up
+    to ``baseline / dphi`` (``phase.py:67-68``)."""
+    step = dphi / baseline
+    return 1 / np.linspace(count * step, step, count)
+
+
+def _pdm_periods(signal, p_min, p_max, count, oversample):
+    """Trial periods equally spaced in PERIOD (``phase.py:167-180``) and the limits used."""
+    span = signal.baseline
+    shortest = 2 * signal.median_dt if p_min is None else p_min
+    longest = oversample * span if p_max is None else p_max
+    if count is None:
+        count = int((1 / shortest - 1 / longest) * oversample * span + 1)
+    return np.linspace(shortest, longest, count), shortest, longest
+
+
+def _average_with_double_period(thetas, periods, n_samples, shortest, longest):
+    """Sub-harmonic averaging (``phase.py:166,181,188-193``): wherever theta is significant
+    (below ``1 - 11 / N**0.8``) and the doubled period is still on the grid, replace theta by the
+    mean of itself and the value at twice the period.  All reads use the pre-update values."""
+    significant = 1.0 - 11.0 / n_samples ** 0.8
+    spacing = periods[1] - periods[0]
+    (here,) = np.where((thetas < significant) & (periods <= longest / 2))
+    doubled = np.round(2 * here + shortest / spacing).astype(int)
+    thetas[here] = (thetas[here] + thetas[doubled]) / 2
+    return thetas
 
 
 class StringLength(object):
-    """String Length (Dworetsky 1983).
+    """String Length period search (Dworetsky 1983, MNRAS 203, 917).
 
-    Parameters (``phase.py:19-43``)
-    ----------
-    dphi: float, optional
-        Factor multiplying ``1 / baseline`` to get the frequency separation (default 0.1).
-    n_periods: int, optional
-        Number of trial periods (default 1000).
+    dphi: float
+        Frequency step in units of ``1 / baseline`` (0.1 by default).
+    n_periods: int
+        How many trial periods (1000 by default).
     cores: int, optional
-        Accepted for compatibility with the reference's process pool; unused on the GPU.
-    device: int, keyword-only, optional
+        Ignored on the GPU; clamped to the host's core count exactly like upstream
+        (``phase.py:41-43``) so that code reading ``.cores`` keeps working.
+    device: int, keyword-only
         GPU ordinal.
     """
 
     def __init__(self, dphi=0.1, n_periods=1000, cores=None, *, device=None):
         self.dphi = dphi
         self.n_periods = n_periods
-        if cores is None or cores > MAX_CORES:
-            cores = MAX_CORES
-        self.cores = cores
+        self.cores = MAX_CORES if cores is None or cores > MAX_CORES else cores
         self.device = device
 
     def _stringlength(self, period):
-        """String length for a single trial period (the seam of ``phase.py:45-51``)."""
-        ell = _cabi.stringlength_scan(self.m.time, self.m.values, [period], device=self.device)
-        return float(ell[0])
+        """Length of the closed (phase, magnitude) polygon at one trial period — the seam of
+        ``phase.py:45-51`` — evaluated by the same kernel as the full scan."""
+        lengths = _cabi.stringlength_scan(self.m.time, self.m.values, [period], device=self.device)
+        return float(lengths[0])
 
     def __call__(self, signal):
-        """String length on ``n_periods`` trial periods uniform in frequency between
-        ``baseline / (dphi * n_periods)`` and ``baseline / dphi`` (``phase.py:53-72``).
+        """Scan ``n_periods`` trial periods (``phase.py:53-72``).
 
-        The upstream call is broken at HEAD (it hands a list to ``FSeries`` and subtracts
-        misaligned one-element series); this implements what its comments state: scale the signal
-        to [-0.25, +0.25] (``phase.py:65-66``), fold, sort by phase, sum the closed polygon.
+        The upstream call cannot run at HEAD (it hands a list to ``FSeries`` and subtracts
+        misaligned one-element series — SURVEY.md fact 4); this does what its comments say:
+        scale the signal to [-0.25, +0.25], fold at each period, sort by phase, sum the closed
+        polygon.  Returned on ascending frequency like every ``FSeries``.
         """
-        signal = _as_tseries(signal)
+        signal = _coerce(signal)
         self.signal = signal
-        values = np.asarray(signal.values, dtype=float)
-        vmax, vmin = np.nanmax(values), np.nanmin(values)
-        self.m = TSeries(signal.time, (values - vmax) / (2 * (vmax - vmin)) + 0.25,
+        times = np.asarray(signal.time, dtype=float)
+        self.m = TSeries(times, _quarter_scaled(np.asarray(signal.values, dtype=float)),
                          assume_sorted=True)
-        df = self.dphi / signal.baseline
-        periods = 1 / np.linspace(self.n_periods * df, df, self.n_periods)
-        ell = _cabi.stringlength_scan(np.asarray(signal.time, dtype=float), self.m.values, periods,
-                                      device=self.device)
-        self.periodogram = FSeries(1 / periods, ell)
+        periods = _string_periods(signal.baseline, self.dphi, self.n_periods)
+        lengths = _cabi.stringlength_scan(times, self.m.values, periods, device=self.device)
+        self.periodogram = FSeries(1 / periods, lengths)
         return self.periodogram
 
 
 class PDM(object):
-    """Phase Dispersion Minimization (Stellingwerf 1978).
+    """Phase Dispersion Minimization (Stellingwerf 1978, ApJ 224, 953; Stellingwerf 2011).
 
-    Parameters (``phase.py:75-126``)
-    ----------
-    nb: int, optional
-        Number of phase bins (default 5).
-    nc: int, optional
-        Number of covers per bin (default 2).
+    nb, nc: int
+        Bins per cover and number of covers (5 and 2 by default): every sample falls in ``nc``
+        overlapping bins of width ``1 / nb``.
     p_min, p_max: float, optional
-        Minimum / maximum trial period (defaults ``2 * median_dt`` and ``oversample * baseline``).
-    n_periods: int, optional
-        Number of trial periods (default 1000); ``None`` derives it from the frequency range.
-    oversample: scalar, optional
-        Baseline multiplier used when ``p_max`` is omitted.
-    do_subharmonic: bool, optional
-        Average theta at each significant period with theta at its double.
+        Shortest / longest trial period; by default twice the median sampling step and
+        ``oversample`` times the baseline.
+    n_periods: int or None
+        Number of trial periods (1000 by default; ``None`` derives it from the frequency range).
+    oversample: scalar
+        See ``p_max``.
+    do_subharmonic: bool
+        Average theta at each significant period with theta at twice that period: a real
+        variation shows at both, noise does not.
     cores: int, optional
-        Accepted for compatibility with the reference's process pool; unused on the GPU.
-    device: int, keyword-only, optional
+        Stored but unused on the GPU.
+    device: int, keyword-only
         GPU ordinal.
     """
 
     def __init__(self, nb=5, nc=2, p_min=None, p_max=None, n_periods=1000, oversample=1,
                  do_subharmonic=False, cores=None, *, device=None):
-        self.nb = nb
-        self.nc = nc
-        self.p_min = p_min
-        self.p_max = p_max
+        self.nb, self.nc = nb, nc
+        self.p_min, self.p_max = p_min, p_max
         self.n_periods = n_periods
         self.oversample = oversample
         self.do_subharmonic = do_subharmonic
         self.cores = cores
         self.device = device
 
+    def _scan(self, periods):
+        return _cabi.pdm_scan(self.t, self.x, periods, self.nb, self.nc, self.sigma,
+                              device=self.device)
+
     def _pdm(self, period):
-        """theta for a single trial period (the seam of ``phase.py:128-149``)."""
-        theta = _cabi.pdm_scan(self.t, self.x, [period], self.nb, self.nc, self.sigma,
-                               device=self.device)
-        return float(theta[0])
+        """Stellingwerf's theta at one trial period — the seam of ``phase.py:128-149``."""
+        return float(self._scan([period])[0])
 
     def __call__(self, signal):
-        """theta statistic on ``n_periods`` trial periods uniform in period
-        (``phase.py:151-195``); returned on ascending frequency like every ``FSeries``."""
-        signal = _as_tseries(signal)
+        """theta (Eq. 3 of the 1978 paper) on the trial-period grid (``phase.py:151-195``)."""
+        signal = _coerce(signal)
         self.signal = signal
         self.t = np.asarray(signal.time, dtype=float)
         self.x = np.asarray(signal.values, dtype=float)
         self.sigma = np.var(signal.values, ddof=1)
-        theta_crit = 1.0 - 11.0 / signal.size ** 0.8
-        t0 = signal.baseline
-        p_min = 2 * signal.median_dt if self.p_min is None else self.p_min
-        p_max = self.oversample * t0 if self.p_max is None else self.p_max
-        if self.n_periods is None:
-            n_periods = int((1 / p_min - 1 / p_max) * self.oversample * t0 + 1)
-        else:
-            n_periods = self.n_periods
-        self.periods = np.linspace(p_min, p_max, n_periods)
-        thetas = _cabi.pdm_scan(self.t, self.x, self.periods, self.nb, self.nc, self.sigma,
-                                device=self.device)
+        self.periods, shortest, longest = _pdm_periods(signal, self.p_min, self.p_max,
+                                                       self.n_periods, self.oversample)
+        thetas = self._scan(self.periods)
         if self.do_subharmonic:
-            dp = self.periods[1] - self.periods[0]
-            (can_average,) = np.where((thetas < theta_crit) & (self.periods <= p_max / 2))
-            sub_indices = np.round(2 * can_average + p_min / dp).astype(int)
-            thetas[can_average] = (thetas[can_average] + thetas[sub_indices]) / 2
+            thetas = _average_with_double_period(thetas, self.periods, signal.size, shortest, longest)
         self.periodogram = FSeries(1 / self.periods, thetas)
         return self.periodogram
