@@ -352,10 +352,10 @@ __global__ __launch_bounds__(64) void gls_peak_kernel(const double *blk_max, con
 }
 
 // Tile shape (K frequencies per thread, S waves per frequency tile).  Cost model: a wave executes
-// ~(38 + 9K) VALU instructions per sample; waves beyond one per SIMD share that SIMD's issue
-// slots, so time ~ ceil(waves / 1024) * (38 + 9K) / (K * S) per (sample, frequency) up to a
-// constant; a lone wave per SIMD cannot hide its own LDS/dependency stalls (+10 %).
-// PDC_GLS_K / PDC_GLS_S override for experiments.
+// ~(38 + 9K) VALU instructions per sample and handles 1/S of the samples; the waves on one SIMD
+// share its issue slots, so time ~ ceil(waves / 1024) * (38 + 9K) / S (up to a constant): few large
+// tiles when the grid fills the chip, many small ones when it does not.  A lone wave per SIMD cannot
+// hide its own LDS/dependency stalls (+10 %).  PDC_GLS_K / PDC_GLS_S override for experiments.
 void tile_shape(int64_t n_curves, int64_t nf, int *K_out, int *S_out) {
     static const int envK = [] { const char *e = getenv("PDC_GLS_K"); return e ? atoi(e) : 0; }();
     static const int envS = [] { const char *e = getenv("PDC_GLS_S"); return e ? atoi(e) : 0; }();
@@ -367,7 +367,7 @@ void tile_shape(int64_t n_curves, int64_t nf, int *K_out, int *S_out) {
             if (envS && S != envS) continue;
             const double waves = (double)n_curves * (double)((nf + 64 * K - 1) / (64 * K)) * S;
             const double rounds = __builtin_ceil(waves / 1024.0);
-            double cost = rounds * (38.0 + 9.0 * K) / (K * S);
+            double cost = rounds * (38.0 + 9.0 * K) / S;
             if (waves / 1024.0 <= 1.0) cost *= 1.10;
             cost *= 1.0 + 0.01 * (S - 1);  // prefer no split on ties
             if (cost < best) {

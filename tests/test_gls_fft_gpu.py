@@ -86,6 +86,16 @@ def test_spotted_star_without_errors_and_window(golden_dir):
     assert_tier_f(gls.window().values, g["power_ref"], afloor=1e-11)
 
 
+def test_bootstrap_through_the_fft_path_reproduces_reference_replicates(golden_dir):
+    g = load(golden_dir, "g6_bootstrap")
+    gls = GLS(method="fft")
+    gls(TSeries(g["t"], g["y"]), err=g["dy"])
+    reps = gls.bootstrap(20, random_seed=42)
+    np.testing.assert_allclose(reps, g["replicates_ref"], rtol=1e-9)
+    assert gls.fap(0.3) == float(g["fap_at_0p3_ref"])
+    np.testing.assert_allclose(gls.fal(0.1), float(g["fal_at_0p1_ref"]), rtol=1e-9)
+
+
 @pytest.mark.parametrize("n", [1000, 5000])
 def test_synthetic_power_ref(golden_dir, n):
     g = load(golden_dir, f"g4_synth{n}")

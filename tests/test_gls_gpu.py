@@ -192,7 +192,7 @@ def test_slabs_tile_the_grid_bitwise():
     stitched = np.concatenate(parts)
     # a slab starts its rotation recurrence at its own first frequency, so agreement is to
     # rounding, not bitwise; the first bin of each slab is seeded directly in both runs
-    np.testing.assert_allclose(stitched, full, rtol=1e-10)
+    np.testing.assert_allclose(stitched, full, rtol=1e-9, atol=1e-15)
     multi = _cabi.gls_scan_multi(t, y, dy, f0, delta, nf, devices=(0,))
     assert np.array_equal(multi, full)
     ls = GLS(fmin=freq[0], fmax=freq[-1], n=1 / ((t[-1] - t[0]) * 0.00011), devices=(0,))
@@ -258,4 +258,5 @@ def test_full_size_c2_properties():
     np.testing.assert_allclose(again, power, rtol=1e-7, atol=1e-14)
     # a slab cut out of the middle reproduces the same bins
     part = _cabi.gls_scan(t, y, dy, f0, delta, 4096, j_begin=500_000)
-    np.testing.assert_allclose(part, power[500_000:504_096], rtol=1e-9)
+    # (a short slab picks a different tile shape, so agreement is to rounding, not bitwise)
+    np.testing.assert_allclose(part, power[500_000:504_096], rtol=1e-8, atol=1e-15)
