@@ -140,8 +140,8 @@ __device__ __forceinline__ double gls_power(double Sh, double Ch, double S, doub
 // still puts >= 2 waves on every SIMD; their partial sums are combined through LDS in a fixed
 // order before the epilogue, so results do not depend on timing.
 template <int K, int MODE, int SPLIT>
-__global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
-    __shared__ double2 stage[kChunk * 3];
+__global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(GlsArgs a) {
+    __shared__ double2 stage[kChunk * 3 + 3];  // + one record of padding for the read-ahead
     __shared__ double red_v[4];
     __shared__ long long red_i[4];
     const int tid = threadIdx.x;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
     const int64_t off = a.offsets ? a.offsets[curve] : 0;
     const int64_t n = a.offsets ? a.offsets[curve + 1] - off : a.n_total;
     constexpr int FT = kBlock / SPLIT;        // frequency-owning threads per workgroup
-    const int wave = tid >> 6, part = wave % SPLIT;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), part = wave % SPLIT;
     // first local frequency of this thread
     const int64_t jl = (tile * FT + (wave / SPLIT) * 64 + (tid & 63)) * (int64_t)K;
     // numpy's arange fill rule: start + i*delta, two roundings (no fma)
@@ -193,10 +193,18 @@ __global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
         const int cnt = (int)((n - base) < kChunk ? (n - base) : kChunk);
         const double *recs = reinterpret_cast<const double *>(stage);
         const int i_end = cnt < (part + 1) * (kChunk / SPLIT) ? cnt : (part + 1) * (kChunk / SPLIT);
-        for (int i = part * (kChunk / SPLIT); i < i_end; ++i) {
-            const double2 r0 = *reinterpret_cast<const double2 *>(recs + i * 6);
-            const double2 r1 = *reinterpret_cast<const double2 *>(recs + i * 6 + 2);
+        // software pipeline: the record of sample i+1 is read from LDS while sample i is processed
+        // (the stage buffer is padded by one record so the last read needs no branch)
+        const int i_beg = part * (kChunk / SPLIT);
+        // {t, wy} and {w, cos} are read ahead; {sin, 2cos} is only needed after the seed sincos, whose
+        // ~130 cycles cover its latency, so it is read in place (keeps the K = 16 tile at 256 VGPRs)
+        double2 q0 = *reinterpret_cast<const double2 *>(recs + i_beg * 6);
+        double2 q1 = *reinterpret_cast<const double2 *>(recs + i_beg * 6 + 2);
+        for (int i = i_beg; i < i_end; ++i) {
+            const double2 r0 = q0, r1 = q1;
             const double2 r2 = *reinterpret_cast<const double2 *>(recs + i * 6 + 4);
+            q0 = *reinterpret_cast<const double2 *>(recs + (i + 1) * 6);
+            q1 = *reinterpret_cast<const double2 *>(recs + (i + 1) * 6 + 2);
             const double t = r0.x, wy = r0.y, w = r1.x, cd = r1.y, sd = r2.x, cd2 = r2.y;
             // k = 0: one software sincos at this thread's first frequency
             double s, c;
@@ -233,6 +241,9 @@ __global__ __launch_bounds__(kBlock) void gls_scan_kernel(GlsArgs a) {
                     s = sn;
                 }
             }
+            // keep the read-ahead in registers until here: without this the compiler re-issues the
+            // loads at the top of the next trip and waits for them on the spot
+            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q1.x), "+v"(q1.y));
         }
     }
 
@@ -369,7 +380,7 @@ void tile_shape(int64_t n_curves, int64_t nf, int *K_out, int *S_out) {
             const double rounds = __builtin_ceil(waves / 1024.0);
             double cost = rounds * (38.0 + 9.0 * K) / S;
             if (waves / 1024.0 <= 1.0) cost *= 1.10;
-            cost *= 1.0 + 0.01 * (S - 1);  // prefer no split on ties
+            cost *= 1.0 + 0.02 * (S > 2 ? S - 2 : 2 - S);  // measured: two waves per tile is the sweet spot
             if (cost < best) {
                 best = cost;
                 bk = K;
