@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR = 50.0          # algorithmic fp64 flop per (sample, frequency) pair
 PEAK_FP64_VECTOR_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz (MI355X, spec)
+VALU_INSTR_PER_PAIR = 11.5      # gls_scan_kernel<16,*,2>: 184 VALU instr per sample per wave / 16
+FP64_ISSUE_CEILING_NS = 1.93    # tools/ubench/fp64_rate.hip: ns per wave-instr per SIMD, 2 waves/SIMD
 N_SAMPLES = 100_000
 NF_PER_GPU = 1_000_000
 
@@ -230,11 +232,22 @@ def main():
                          "frac": round(achieved / PEAK_FP64_VECTOR_TFLOPS, 4), "traffic": traffic,
                          "kernel": "gls_scan_kernel (+ gls_prep_kernel, <0.1%)",
                          "kernel_ms": round(kernel_s * 1e3, 4),
-                         "note": "fp64 vector-ALU bound (software sincos + rotations; no fp64 "
+                         "valu_issue": {
+                             "instr_per_pair": VALU_INSTR_PER_PAIR,
+                             "ns_per_wave_instr_per_simd": round(
+                                 kernel_s * 1e9 * 1024 / (launch_pairs / 64 * VALU_INSTR_PER_PAIR), 3),
+                             "ceiling_ns": FP64_ISSUE_CEILING_NS,
+                             "frac_of_ceiling": round(
+                                 FP64_ISSUE_CEILING_NS / (kernel_s * 1e9 * 1024 /
+                                                          (launch_pairs / 64 * VALU_INSTR_PER_PAIR)), 3)},
+                         "note": "fp64 vector-ALU bound (software sincos + recurrences; no fp64 "
                                  "transcendental unit, not a contraction): achieved = 50 "
-                                 "algorithmic flop/pair x pairs per launch / HIP-event time; the "
-                                 "rotation recurrence executes ~27 flop/pair, so frac may exceed "
-                                 "the direct-evaluation roofline"},
+                                 "algorithmic flop/pair (SURVEY 8d) x pairs per launch / HIP-event "
+                                 "time. The recurrence kernel EXECUTES 11.5 VALU instr/pair "
+                                 "(static count of the K=16 loop, = SQ_INSTS_VALU in "
+                                 "profiles/), so frac exceeds the direct-evaluation roofline; "
+                                 "valu_issue compares its issue rate with the measured v_fma_f64 "
+                                 "ceiling at 2 waves/SIMD (profiles/r01_ubench_fp64_rate.txt)"},
             "peak_bin": int(np.nanargmax(got)),
         }
         if world == 1 and not dist_mode:

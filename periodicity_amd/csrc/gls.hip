@@ -35,7 +35,11 @@ constexpr int kBlock = 256;
 constexpr int kChunk = 256;  // samples staged in LDS per step (12 KiB)
 constexpr int kPrepBlock = 1024;
 
-enum Mode { MODE_FIT_MEAN = 0, MODE_NO_MEAN = 1, MODE_RAW = 2 };
+// *_U: all weights equal (err=None upstream, spectral.py:99-100): the weight factors out of four of
+// the six sums, which saves one multiply per (sample, frequency).
+enum Mode { MODE_FIT_MEAN = 0, MODE_NO_MEAN = 1, MODE_RAW = 2, MODE_FIT_MEAN_U = 3, MODE_NO_MEAN_U = 4 };
+constexpr bool mode_fits_mean(int m) { return m == MODE_FIT_MEAN || m == MODE_FIT_MEAN_U; }
+constexpr bool mode_uniform(int m) { return m == MODE_FIT_MEAN_U || m == MODE_NO_MEAN_U; }
 
 struct GlsArgs {
     const double *rec;       // [n_total][6]
@@ -131,7 +135,7 @@ __device__ __forceinline__ double gls_power(double Sh, double Ch, double S, doub
                                             int psd) {
     const double S2 = 2.0 * SC;            // sum w sin(2 omega t)
     const double C2 = Wsum - 2.0 * SS;     // sum w cos(2 omega t)
-    return gls_power_from_sums<MODE == MODE_FIT_MEAN>(Sh, Ch, S, C, S2, C2, YY, Werr, psd);
+    return gls_power_from_sums<mode_fits_mean(MODE)>(Sh, Ch, S, C, S2, C2, YY, Werr, psd);
 }
 
 // ---- the scan ------------------------------------------------------------------------------------------
@@ -214,7 +218,15 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
             for (int k = 0; k < K; ++k) {
                 Sh[k] = __builtin_fma(wy, s, Sh[k]);
                 Ch[k] = __builtin_fma(wy, c, Ch[k]);
-                if (MODE != MODE_RAW) {
+                if (mode_uniform(MODE)) {
+                    // equal weights: accumulate the bare trig sums, scale once in the epilogue
+                    if (mode_fits_mean(MODE)) {
+                        S[k] += s;
+                        C[k] += c;
+                    }
+                    SS[k] = __builtin_fma(s, s, SS[k]);
+                    SC[k] = __builtin_fma(s, c, SC[k]);
+                } else if (MODE != MODE_RAW) {
                     const double ws = w * s;
                     if (MODE == MODE_FIT_MEAN) {
                         S[k] += ws;
@@ -296,6 +308,13 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     for (int k = 0; k < K; ++k) {
         const int64_t j = jl + k;
         if (owner && j < a.nf) {
+            if (mode_uniform(MODE)) {  // w = (1/1)/W for every sample
+                const double w0 = 1.0 / Werr;
+                S[k] *= w0;
+                C[k] *= w0;
+                SS[k] *= w0;
+                SC[k] *= w0;
+            }
             const double p = gls_power<MODE>(Sh[k], Ch[k], S[k], C[k], SS[k], SC[k], YY, Wsum,
                                              Werr, a.psd);
             if (a.power) a.power[curve * a.nf + j] = p;
@@ -482,9 +501,11 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     const int64_t G = a.n_curves * a.tiles;
     const dim3 grid((unsigned)(((G + 7) / 8) * 8));
     if (mode == MODE_FIT_MEAN) {
-        launch_scan<MODE_FIT_MEAN>(K, S, grid, st, a);
+        if (d_dy) launch_scan<MODE_FIT_MEAN>(K, S, grid, st, a);
+        else launch_scan<MODE_FIT_MEAN_U>(K, S, grid, st, a);
     } else if (mode == MODE_NO_MEAN) {
-        launch_scan<MODE_NO_MEAN>(K, S, grid, st, a);
+        if (d_dy) launch_scan<MODE_NO_MEAN>(K, S, grid, st, a);
+        else launch_scan<MODE_NO_MEAN_U>(K, S, grid, st, a);
     } else {
         launch_scan<MODE_RAW>(K, S, grid, st, a);
     }

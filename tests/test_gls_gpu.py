@@ -234,6 +234,30 @@ def test_edge_cases():
     assert one.shape == (4,)
 
 
+def test_entry_points_are_reentrant_across_python_threads():
+    # ctypes drops the GIL during a call; calls on one device serialise on its workspace lock
+    import threading
+    cases = [synth(800 + 37 * i, 50 + i) for i in range(6)]
+    freq = np.arange(0.002, 0.45, 0.0007)
+    f0, delta, nf = _cabi.grid_params(freq)
+    want = [_cabi.gls_scan(t, y, dy, f0, delta, nf) for t, y, dy in cases]
+    got = [None] * len(cases)
+
+    def work(i):
+        for _ in range(5):
+            t, y, dy = cases[i]
+            got[i] = _cabi.gls_scan(t, y, dy, f0, delta, nf)
+            _cabi.pdm_scan(t, y, np.linspace(1.0, 30.0, 70), 5, 2, np.var(y, ddof=1))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
 def test_full_size_c2_properties():
     """BASELINE configs[1] at full size (1e11 pairs): a random subset of bins against the exact
     oracle, plus invariances the domain offers (amplitude scaling, slab consistency)."""

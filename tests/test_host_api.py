@@ -54,6 +54,30 @@ def test_fseries_sorts_and_finds_peaks():
         assert np.isinf(FSeries([0.0, 1.0], [1.0, 2.0]).period[0])
 
 
+def test_fseries_peak_pickers_follow_scipy():
+    from scipy.signal import find_peaks
+    rng = np.random.default_rng(0)
+    f = np.linspace(0.01, 2.0, 400)
+    v = np.exp(-0.5 * ((f - 0.5) / 0.03) ** 2) + 0.6 * np.exp(-0.5 * ((f - 1.2) / 0.05) ** 2)
+    v += 0.01 * rng.standard_normal(f.size)
+    fs = FSeries(f, v)
+    idx, props = find_peaks(v, prominence=0.0)
+    peaks = fs.find_peaks()
+    assert np.array_equal(peaks.attrs["indices"], idx)
+    assert np.array_equal(peaks.attrs["prominences"], props["prominences"])
+    assert fs.period_at_highest_peak == 1 / f[idx[np.argmax(v[idx])]]
+    assert fs.period_at_highest_prominence == 1 / f[idx[np.argmax(props["prominences"])]]
+    assert np.array_equal(fs.psort_by_peak(), (1 / f[idx])[np.argsort(v[idx])[::-1]])
+    assert np.array_equal(fs.psort_by_prominence(), (1 / f[idx])[np.argsort(props["prominences"])[::-1]])
+    lower, upper = fs.periods_at_half_max()
+    assert lower < 1 / 0.5 < upper and upper - lower < 0.5
+    with_edges = fs.find_peaks(include_edges=True)
+    assert with_edges.attrs["indices"][0] == 0 and with_edges.attrs["indices"][-1] == -1
+    dips = (-fs).find_peaks()
+    assert np.array_equal(fs.find_dips().attrs["indices"], dips.attrs["indices"])
+    assert fs.median_df == np.median(np.diff(f)) and abs(fs.df - fs.median_df) < 1e-12
+
+
 # ---- callables with the C ABI swapped for the oracle -------------------------------------------------
 @pytest.fixture
 def oracle_backend(monkeypatch):

@@ -67,7 +67,7 @@ def dbuf(a):
 
 def run_gls(tm, name, t, y, dy, offsets, nb, f0, delta, nf, reps, shared_t=0, peaks_only=False):
     n_total = y.size
-    bt, by, bdy = dbuf(t), dbuf(y), dbuf(dy)
+    bt, by, bdy = dbuf(t), dbuf(y), (dbuf(dy) if dy is not None else None)
     boff = dbuf(offsets) if offsets is not None else None
     wb = lib.pdc_gls_work_bytes(n_total, nb, nf)
     work = _cabi.DeviceBuffer(wb, DEV)
@@ -76,7 +76,7 @@ def run_gls(tm, name, t, y, dy, offsets, nb, f0, delta, nf, reps, shared_t=0, pe
     arg = _cabi.DeviceBuffer(nb * 8, DEV) if peaks_only else None
 
     def fn():
-        _cabi.check(lib.pdc_gls_scan_dev(DEV, tm.stream, bt.ptr, by.ptr, bdy.ptr,
+        _cabi.check(lib.pdc_gls_scan_dev(DEV, tm.stream, bt.ptr, by.ptr, bdy.ptr if bdy else None,
                                          boff.ptr if boff else None, n_total, nb, shared_t, f0,
                                          delta, 0, nf, 1, 0, power.ptr if power else None,
                                          amax.ptr if amax else None, arg.ptr if arg else None,
@@ -105,6 +105,10 @@ def main():
     if "c2" in only:
         t, y, dy = synth(100_000, 2)
         out.append(run_gls(tm, "C2 GLS 1e5 x 1e6", t, y, dy, None, 1, *grid(t, 1_000_000), args.reps))
+    if "c2noerr" in only:
+        t, y, dy = synth(100_000, 2)
+        out.append(run_gls(tm, "C2 GLS 1e5 x 1e6, err=None (equal weights)", t, y, None, None, 1,
+                           *grid(t, 1_000_000), args.reps))
     for tag, n_s, nf_s in (("c2fft", 100_000, 1_000_000), ("c4fft", 1_000_000, 10_000_000)):
         if tag in only:
             t, y, dy = synth(n_s, 2)
