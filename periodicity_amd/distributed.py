@@ -50,6 +50,15 @@ def gather_slabs(local, n_grid, group=None):
     return out[:n_grid]
 
 
+def _place(array, device, group=None):
+    """A float64 numpy array as a tensor where the group's backend wants it: on the rank's GPU for
+    ``nccl`` (RCCL), on the host for ``gloo`` (the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    tensor = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64))
+    return tensor if dist.get_backend(group) == "gloo" else tensor.to(f"cuda:{device}")
+
+
 def sharded_scan(compute_slab, n_grid, group=None):
     """Run ``compute_slab(begin, count) -> torch.Tensor`` for this rank's slab and all-gather."""
     import torch.distributed as dist
@@ -69,6 +78,38 @@ def sharded_gls(t, y, dy, f0, delta, nf, fit_mean=True, psd=False, device=None, 
     def compute(begin, count):
         part = _cabi.gls_scan(t, y, dy, f0, delta, count, fit_mean, psd, j_begin=begin,
                               device=device)
-        return torch.from_numpy(np.ascontiguousarray(part)).to(f"cuda:{device}")
+        return _place(part, device, group)
 
     return sharded_scan(compute, nf, group).cpu().numpy()
+
+
+def sharded_periods(scan, periods, device=None, group=None):
+    """Shard a trial-period sweep: ``scan(periods_slab, device) -> ndarray`` is run on this rank's
+    contiguous slab of ``periods`` and the slabs are all-gathered.  Used for PDM / StringLength,
+    whose per-period work is independent exactly like the frequency grid of the periodogram
+    (the reference fans these out with ``Pool.map``, ``phase.py:69-70,185-186``)."""
+    import torch
+    import torch.distributed as dist
+    periods = np.ascontiguousarray(periods, dtype=np.float64)
+    if device is None and dist.get_backend(group) != "gloo":
+        device = torch.cuda.current_device()
+
+    def compute(begin, count):
+        return _place(scan(periods[begin:begin + count], device), device, group)
+
+    return sharded_scan(compute, periods.size, group).cpu().numpy()
+
+
+def sharded_pdm(t, x, periods, nb=5, nc=2, sigma=None, device=None, group=None):
+    """theta for every trial period, period grid sharded over the ranks of ``group``."""
+    from . import _cabi
+    sigma = np.var(x, ddof=1) if sigma is None else sigma
+    return sharded_periods(lambda p, dev: _cabi.pdm_scan(t, x, p, nb, nc, sigma, device=dev),
+                           periods, device, group)
+
+
+def sharded_stringlength(t, m, periods, device=None, group=None):
+    """String length for every trial period, period grid sharded over the ranks of ``group``."""
+    from . import _cabi
+    return sharded_periods(lambda p, dev: _cabi.stringlength_scan(t, m, p, device=dev),
+                           periods, device, group)

@@ -58,6 +58,13 @@ def _worker(rank, world, port, n_grid, out_dir):
         return torch.from_numpy(part)
 
     full = sharded_scan(compute, n_grid).numpy()
+    # the period-sweep wrapper (PDM / StringLength shape) with the oracle as the per-slab scan
+    from periodicity_amd.distributed import sharded_periods
+    periods = np.linspace(1.0, 40.0, n_grid)
+    theta = sharded_periods(lambda p, dev: so.pdm_scan(t, y, p, 5, 2), periods)
+    np.save(os.path.join(out_dir, f"theta{rank}.npy"), theta)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "theta_want.npy"), so.pdm_scan(t, y, periods, 5, 2))
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), full)
     np.save(os.path.join(out_dir, f"calls{rank}.npy"), np.array(calls))
     if rank == 0:
@@ -79,3 +86,4 @@ def test_two_rank_gloo_allgather_reassembles_the_spectrum(tmp_path, n_grid):
         np.testing.assert_allclose(got, want, rtol=1e-12)      # every rank holds the whole array
         b, e, _ = slab_bounds(n_grid, world, rank)
         assert np.load(tmp_path / f"calls{rank}.npy").tolist() == [[b, e - b]]
+        assert np.array_equal(np.load(tmp_path / f"theta{rank}.npy"), np.load(tmp_path / "theta_want.npy"))
