@@ -127,6 +127,23 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
 int pdc_trig_sums_fft(const double *t, const double *h, int64_t n, double df, int64_t nf,
                       double fmin, double *S_out, double *C_out, int device);
 
+/* ---- peak picking on the device --------------------------------------------------
+ * Highest local maximum of each of n_curves spectra of nf bins, as
+ * FSeries.period_at_highest_peak finds it (core.py:952-955 -> find_peaks :283-317 ->
+ * scipy.signal.find_peaks(prominence=0.0) -> NaN-aware max :202-220): strict local maxima, flat
+ * tops resolved to their midpoint, first/last bin never a peak, NaN never part of one, ties ->
+ * lowest index.  idx_out[b] = -1 (val NaN) when spectrum b has no peak.
+ * pdc_gls_batch_highest_peak runs the batched periodogram and the reduction back to back so the
+ * spectra never leave HBM (4096 x 5e4 bins = 1.6 GB stay on the device, 64 KB come back). */
+int pdc_highest_peak(const double *power, int64_t n_curves, int64_t nf,
+                     int64_t *idx_out, double *val_out, int device);
+int pdc_highest_peak_dev(int device, void *stream, const double *d_power, int64_t n_curves,
+                         int64_t nf, int64_t *d_idx, double *d_val);
+int pdc_gls_batch_highest_peak(const double *t, const double *y, const double *dy,
+                               const int64_t *offsets, int64_t n_curves, int shared_t,
+                               double f0, double delta, int64_t nf, int fit_mean, int psd,
+                               int64_t *idx_out, double *val_out, int device);
+
 /* ---- Phase Dispersion Minimization -----------------------------------------------------------
  * Replaces pool.map(PDM._pdm, periods) (phase.py:128-149, 185-187): theta_out[p] for every trial
  * period, bins phi in [k/m0, (k+nc)/m0) U [0, (k+nc-m0)/m0), m0 = nb*nc, phi = (t/period) % 1

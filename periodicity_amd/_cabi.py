@@ -52,6 +52,9 @@ PROTOTYPES = {
     "pdc_gls_scan_fft": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _I, _I, _VP, _I]),
     "pdc_gls_scan_fft_dev": (_I, [_I, _VP, _VP, _VP, _VP, _L, _D, _D, _L, _I, _I, _VP, _VP, _L]),
     "pdc_trig_sums_fft": (_I, [_VP, _VP, _L, _D, _L, _D, _VP, _VP, _I]),
+    "pdc_highest_peak": (_I, [_VP, _L, _L, _VP, _VP, _I]),
+    "pdc_highest_peak_dev": (_I, [_I, _VP, _VP, _L, _L, _VP, _VP]),
+    "pdc_gls_batch_highest_peak": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _I, _I, _VP, _VP, _I]),
     "pdc_pdm_scan": (_I, [_VP, _VP, _L, _VP, _L, _I, _I, _D, _VP, _I]),
     "pdc_pdm_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _I, _I, _D, _VP]),
     "pdc_stringlength_scan": (_I, [_VP, _VP, _L, _VP, _L, _VP, _I]),
@@ -210,6 +213,37 @@ def trig_sums_fft(t, h, df, nf, fmin, device=None):
     check(lib().pdc_trig_sums_fft(_ptr(t), _ptr(h), t.size, float(df), nf, float(fmin), _ptr(S),
                                   _ptr(Cc), dev))
     return S, Cc
+
+
+def highest_peak(power, device=None):
+    """(index, value) of the highest ``find_peaks`` local maximum of each row of ``power``."""
+    power = np.ascontiguousarray(power, dtype=np.float64)
+    rows = power.reshape(1, -1) if power.ndim == 1 else power
+    idx = np.empty(rows.shape[0], dtype=np.int64)
+    val = np.empty(rows.shape[0], dtype=np.float64)
+    dev = default_device() if device is None else device
+    check(lib().pdc_highest_peak(_ptr(rows), rows.shape[0], rows.shape[1], _ptr(idx), _ptr(val), dev))
+    return (int(idx[0]), float(val[0])) if power.ndim == 1 else (idx, val)
+
+
+def gls_batch_highest_peak(t, y, dy, offsets, f0, delta, nf, fit_mean=True, psd=False,
+                           shared_t=False, device=None):
+    """Batched periodograms reduced on the device to each curve's highest peak (index, power)."""
+    t, y = _f64(t, "t"), _f64(y, "y")
+    dy = None if dy is None else _f64(dy, "dy")
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    nb = offsets.size - 1
+    if nb < 1 or offsets[-1] != y.size or (dy is not None and dy.size != y.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    if (shared_t and t.size != offsets[1]) or (not shared_t and t.size != y.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    idx = np.empty(nb, dtype=np.int64)
+    val = np.empty(nb, dtype=np.float64)
+    dev = default_device() if device is None else device
+    check(lib().pdc_gls_batch_highest_peak(_ptr(t), _ptr(y), _ptr(dy), _ptr(offsets), nb,
+                                           int(shared_t), f0, delta, nf, int(bool(fit_mean)),
+                                           int(bool(psd)), _ptr(idx), _ptr(val), dev))
+    return idx, val
 
 
 def pdm_scan(t, x, periods, nb, nc, sigma, device=None):
