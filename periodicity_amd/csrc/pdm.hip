@@ -199,7 +199,9 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
             num -= s * s;  // a singleton contributes x^2 - x^2 = 0 and is not a "good" bin
         }
     }
-    a.theta[pidx] = (num / (double)(n_sum - good)) / a.sigma;
+    // no cover with two or more members: the reference divides an empty sum by zero -> NaN
+    // (phase.py:147); here `num` would only hold the rounding residue of the singletons
+    a.theta[pidx] = good == 0 ? __builtin_nan("") : (num / (double)(n_sum - good)) / a.sigma;
 }
 
 size_t lds_bytes(int m0, int block) {

@@ -1,0 +1,131 @@
+"""Seeded randomised sweeps of all scans against the oracles: odd sizes, ragged batches, time
+offsets, tied phases, extreme periods — the corners the hand-written cases might miss."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import scan_oracle as so
+from periodicity_amd import _cabi
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_close_spectrum(got, want, rtol, afloor, singular_ok=0.0):
+    """Bins where either side is non-finite are 0/0 singularities of the epilogue (CC or SS -> 0,
+    e.g. two samples, or integer times at Nyquist); allow a fraction ``singular_ok`` of them."""
+    want = np.asarray(want)
+    fin = np.isfinite(want) & np.isfinite(got)
+    assert np.mean(np.isfinite(want) != np.isfinite(got)) <= singular_ok
+    if fin.any():
+        scale = np.max(np.abs(want[fin]))
+        assert np.all(np.abs(got[fin] - want[fin]) <= rtol * np.abs(want[fin]) + afloor * scale)
+
+
+def random_curve(rng, n):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        t = np.sort(rng.uniform(0, 50.0, n))
+    elif kind == 1:
+        t = np.arange(n, dtype=float) * rng.choice([1.0, 0.25, 3.0])          # evenly sampled
+    elif kind == 2:
+        t = np.sort(rng.uniform(0, 30.0, n)) + rng.choice([2454953.5, -1000.25, 1e5])
+    else:
+        t = np.sort(np.round(rng.uniform(0, 40.0, n), 1))                     # repeated times
+    y = np.sin(2 * np.pi * t / rng.uniform(2.0, 9.0)) + 0.3 * rng.standard_normal(n) + rng.uniform(-5, 5)
+    dy = rng.uniform(0.05, 0.5, n)
+    return t, y, dy
+
+
+def test_gls_direct_random_cases():
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        n = int(rng.choice([3, 5, 17, 64, 255, 256, 257, 300, 513, 777]))
+        t, y, dy = random_curve(rng, n)
+        nf = int(rng.choice([1, 2, 63, 64, 65, 255, 257, 1000, 1025, 2049]))
+        span = max(t[-1] - t[0], 1.0)
+        f0, delta = rng.uniform(0.05, 2.0) / span, rng.uniform(0.01, 0.3) / span
+        freq = f0 + delta * np.arange(nf)
+        fit_mean, psd = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        err = dy if rng.integers(0, 3) else None
+        got = _cabi.gls_scan(t, y, err, f0, delta, nf, fit_mean, psd)
+        want = co.gls_power_exact(t, y, err, freq, fit_mean, psd)
+        # tiny-N spectra have genuinely singular bins (CC or SS -> 0): compare where the oracle's own
+        # conditioning allows, i.e. relative to the spectrum scale
+        assert_close_spectrum(got, want, 1e-6, 1e-9), case
+
+
+def test_gls_batch_random_ragged():
+    rng = np.random.default_rng(7)
+    for case in range(8):
+        lens = rng.integers(1, 700, size=int(rng.integers(2, 12)))
+        curves = [random_curve(rng, int(n)) for n in lens]
+        offsets = np.concatenate([[0], np.cumsum(lens)])
+        t, y, dy = (np.concatenate([c[i] for c in curves]) for i in range(3))
+        nf = int(rng.choice([10, 300, 1500]))
+        f0, delta = 0.01, 0.003
+        power, amax, argmax = _cabi.gls_scan_batch(t, y, dy, offsets, f0, delta, nf, want_peaks=True)
+        for b, (tb, yb, dyb) in enumerate(curves):
+            single = _cabi.gls_scan(tb, yb, dyb, f0, delta, nf)
+            assert np.array_equal(single, power[b], equal_nan=True)
+            if np.any(np.isfinite(single)):
+                assert argmax[b] == np.nanargmax(single)
+
+
+def test_gls_fft_random_cases():
+    rng = np.random.default_rng(99)
+    for case in range(40):
+        n = int(rng.choice([9, 30, 100, 333, 1000]))   # (2-3 samples: every bin is a 0/0 singularity)
+        t, y, dy = random_curve(rng, n)
+        if t[-1] == t[0]:
+            continue
+        kw = dict(n=float(rng.choice([1, 2.5, 5])))
+        if rng.integers(0, 2):
+            span = t[-1] - t[0]
+            kw.update(fmin=rng.uniform(0.1, 1.0) / span, fmax=rng.uniform(5.0, 40.0) / span)
+        fit_mean = bool(rng.integers(0, 2))
+        err = dy if rng.integers(0, 2) else None
+        dt_med = np.median(np.diff(t))
+        if "fmax" not in kw and (dt_med <= 0 or (t[-1] - t[0]) / dt_med * kw["n"] > 2e5):
+            continue                                   # repeated times: upstream's Nyquist is infinite
+        with np.errstate(all="ignore"):
+            freq, want = so.gls(t, y, err, fit_mean=fit_mean, **kw)
+        if freq.size == 0:
+            continue
+        df = 1.0 / (t[-1] - t[0]) / kw["n"]
+        fmin = kw.get("fmin", 0.5 * df)
+        got = _cabi.gls_scan_fft(t, y, err, fmin, df, freq.size, fit_mean)
+        assert_close_spectrum(got, want, 1e-7, 1e-9, singular_ok=0.02), case
+
+
+def test_pdm_random_cases():
+    rng = np.random.default_rng(11)
+    for case in range(60):
+        n = int(rng.choice([2, 3, 10, 100, 511, 512, 513, 1500]))
+        t, y, _ = random_curve(rng, n)
+        if rng.integers(0, 3) == 0:
+            t = t - t.mean()                                                    # negative times
+        nb, nc = int(rng.integers(1, 12)), int(rng.integers(1, 6))
+        n_per = int(rng.choice([1, 7, 64, 65, 200]))
+        periods = rng.uniform(0.05, 80.0, n_per)
+        periods[: min(3, n_per)] = [1.0, 0.25, 3.0][: min(3, n_per)]          # commensurate
+        sigma = np.var(y, ddof=1)
+        got = _cabi.pdm_scan(t, y, periods, nb, nc, sigma)
+        with np.errstate(all="ignore"):
+            want = so.pdm_scan(t, y, periods, nb, nc)
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=str(case))
+
+
+def test_stringlength_random_cases():
+    rng = np.random.default_rng(13)
+    for case in range(50):
+        n = int(rng.choice([1, 2, 3, 63, 64, 65, 191, 193, 1000, 4097, 6000]))
+        t, y, _ = random_curve(rng, n)
+        if rng.integers(0, 3) == 0:
+            t = t - t.mean()
+        m = so.stringlength_scale(y) if np.ptp(y) > 0 else np.zeros_like(y)
+        n_per = int(rng.choice([1, 5, 33]))
+        periods = rng.uniform(0.05, 80.0, n_per)
+        periods[: min(3, n_per)] = [1.0, 0.25, 3.0][: min(3, n_per)]
+        got = _cabi.stringlength_scan(t, m, periods)
+        want = so.stringlength_scan(t, m, periods)
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12, err_msg=str(case))
