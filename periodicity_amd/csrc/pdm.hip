@@ -101,6 +101,7 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     const double eps = dm0 * (8.9e-16 * tmax * __builtin_fabs(rp) + 8.9e-16);
     const double thr = 0.5 - eps;  // accept when |g - 0.5| < thr
     double q_over = 0.0;           // sum x'^2 of samples in the overflow bin
+    double q_nan = 0.0;            // sum x'^2 of samples whose phase is NaN (they are in no cover)
 
     for (int64_t base = 0; base < a.n; base += kChunk) {
         __syncthreads();
@@ -122,7 +123,10 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
             // exact path: numpy's float remainder of the IEEE quotient, explicit edges
             const double qe = tx.x / period;
             const double phi = qe - __builtin_floor(qe);  // == fmod-based Python % for divisor 1
-            if (phi != phi) return false;                 // NaN phase belongs to no bin
+            if (phi != phi) {                             // NaN phase belongs to no bin
+                q_nan += tx.y * tx.y;
+                return false;
+            }
             k = (int)(phi * dm0);
             k = k < 0 ? 0 : (k > m0 ? m0 : k);
             while (k > 0 && phi < edge[k]) --k;
@@ -157,8 +161,9 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     if (SPLIT > 1) {
         // fold the partial histograms of parts 1..SPLIT-1 into part 0 (threads tid + 64*q)
         __syncthreads();
-        double *qx = reinterpret_cast<double *>(stage);  // q_over exchange, [BLOCK]
+        double *qx = reinterpret_cast<double *>(stage);  // q_over / q_nan exchange, [2][BLOCK]
         qx[tid] = q_over;
+        qx[BLOCK + tid] = q_nan;
         __syncthreads();
         if (part == 0) {
             for (int q = 1; q < SPLIT; ++q) {
@@ -168,12 +173,13 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
                     hcnt[k * BLOCK + tid] += hcnt[k * BLOCK + other];
                 }
                 q_over += qx[other];
+                q_nan += qx[BLOCK + other];
             }
         }
     }
     if (part != 0 || pidx >= a.n_periods) return;
     // covers: phase.py:137-147
-    double num = (double)a.nc * q_total - q_over;
+    double num = (double)a.nc * (q_total - q_nan) - q_over;
     long long n_sum = 0;
     int good = 0;
     for (int k = 0; k < m0; ++k) {

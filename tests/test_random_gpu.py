@@ -129,3 +129,34 @@ def test_stringlength_random_cases():
         got = _cabi.stringlength_scan(t, m, periods)
         want = so.stringlength_scan(t, m, periods)
         np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12, err_msg=str(case))
+
+
+def test_nan_and_inf_inputs_propagate_like_numpy():
+    rng = np.random.default_rng(3)
+    t, y, dy = random_curve(rng, 200)
+    t = np.sort(rng.uniform(0, 50.0, 200))
+    periods = np.array([0.7, 3.0, 11.0])
+    m = so.stringlength_scale(y)
+    for where in ("y", "t"):
+        tt, yy, mm = t.copy(), y.copy(), m.copy()
+        if where == "y":
+            yy[17] = np.nan
+            mm[17] = np.nan
+        else:
+            tt[17] = np.nan
+        with np.errstate(all="ignore"):
+            want_pdm = so.pdm_scan(tt, yy, periods, 5, 2)
+            want_sl = so.stringlength_scan(tt, mm, periods)
+            sigma = np.var(yy, ddof=1)
+        got_pdm = _cabi.pdm_scan(tt, yy, periods, 5, 2, sigma)
+        got_sl = _cabi.stringlength_scan(tt, mm, periods)
+        np.testing.assert_allclose(got_pdm, want_pdm, rtol=1e-9, equal_nan=True)
+        np.testing.assert_allclose(got_sl, want_sl, rtol=1e-9, equal_nan=True)
+        got = _cabi.gls_scan(tt, yy, dy, 0.01, 0.003, 50)
+        assert np.all(np.isnan(got))
+    with np.errstate(all="ignore"):
+        odd = np.array([np.inf, np.nan, 0.0, -2.5])
+        np.testing.assert_allclose(_cabi.pdm_scan(t, y, odd, 5, 2, np.var(y, ddof=1)),
+                                   so.pdm_scan(t, y, odd, 5, 2), rtol=1e-9, equal_nan=True)
+        np.testing.assert_allclose(_cabi.stringlength_scan(t, m, odd),
+                                   so.stringlength_scan(t, m, odd), rtol=1e-9, equal_nan=True)
