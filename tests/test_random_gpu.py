@@ -160,3 +160,41 @@ def test_nan_and_inf_inputs_propagate_like_numpy():
                                    so.pdm_scan(t, y, odd, 5, 2), rtol=1e-9, equal_nan=True)
         np.testing.assert_allclose(_cabi.stringlength_scan(t, m, odd),
                                    so.stringlength_scan(t, m, odd), rtol=1e-9, equal_nan=True)
+
+
+def test_class_level_calls_random():
+    """The three callables end to end (grids, ordering, attributes) against the restated calls."""
+    from periodicity_amd.core import TSeries
+    from periodicity_amd.phase import PDM, StringLength
+    from periodicity_amd.spectral import GLS
+    rng = np.random.default_rng(21)
+    for case in range(12):
+        n = int(rng.choice([40, 150, 600]))
+        t = np.sort(rng.uniform(0, 3.0 * n, n))
+        dy = rng.uniform(0.05, 0.4, n)
+        y = np.sin(2 * np.pi * t / rng.uniform(5.0, 25.0)) + dy * rng.standard_normal(n)
+        sig = TSeries(t, y)
+        kw = dict(n=float(rng.choice([2, 5])), psd=bool(rng.integers(0, 2)))
+        fit_mean = bool(rng.integers(0, 2))
+        freq, ref = so.gls(t, y, dy, fit_mean=fit_mean, **kw)
+        fft = GLS(method="fft", **kw)(sig, err=dy, fit_mean=fit_mean)
+        assert np.array_equal(fft.frequency, freq)
+        assert_close_spectrum(fft.values, ref, 1e-7, 1e-10)
+        direct = GLS(**kw)(sig, err=dy, fit_mean=fit_mean)
+        exact = co.gls_power_exact(t, y, dy, freq, fit_mean, kw["psd"])
+        assert_close_spectrum(direct.values, exact, 1e-6, 1e-11)
+        assert direct.argmax() == int(np.nanargmax(ref))                       # tier R
+
+        nper = int(rng.choice([33, 200]))
+        sub = bool(rng.integers(0, 2))
+        pdm = PDM(nb=int(rng.integers(3, 8)), nc=int(rng.integers(1, 4)), n_periods=nper,
+                  do_subharmonic=sub)
+        got = pdm(sig)
+        f_ref, th_ref = so.pdm(t, y, pdm.nb, pdm.nc, n_periods=nper, do_subharmonic=sub)
+        assert np.array_equal(got.frequency, f_ref)
+        np.testing.assert_allclose(got.values, th_ref, rtol=1e-9)
+        dphi = float(rng.choice([0.1, 0.05]))
+        sl = StringLength(dphi=dphi, n_periods=nper)(sig)
+        f_ref, ell_ref = so.stringlength(t, y, dphi=dphi, n_periods=nper)
+        assert np.array_equal(sl.frequency, f_ref)
+        np.testing.assert_allclose(sl.values, ell_ref, rtol=1e-9)
