@@ -357,26 +357,28 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
 //          t * (1/period) with the same guard band as the PDM kernel: the exact IEEE division runs
 //          only when the shortcut lands within its own error of a bucket edge).
 //   P3a    WAVE-AUTONOMOUS ranges, no workgroup barrier: the sorted positions are cut into windows
-//          of 64; range r = the coarse buckets whose first sorted position falls in window r (a
-//          contiguous slice of order[], ~64-100 samples).  Each wave takes ranges r = wave,
-//          wave+16, ...: exact fold of its <= 192 samples, rank inside <= 256 fine buckets (LDS
+//          of 192; range r = the coarse buckets whose first sorted position falls in window r (a
+//          contiguous slice of order[], ~192-230 samples).  Each wave takes ranges r = wave,
+//          wave+16, ...: exact fold of its <= 256 samples, rank inside <= 256 fine buckets (LDS
 //          atomics, wave-private counters), wave-level exclusive scan, placement, insertion-sort
 //          finish, segment sum, and a 4-double summary (first/last point) of the range.
-//   P3b    ranges a wave cannot take (more than 192 samples, or a fine bucket fuller than 16:
+//   P3b    ranges a wave cannot take (more than 256 samples, or a fine bucket fuller than 16:
 //          clustered phases) are bitonic-sorted by the whole workgroup (LDS, or global scratch
 //          beyond 2048 samples).
 //   P3c    links between consecutive ranges and the closing segment from the summaries.
 constexpr int kLBlock = 1024;
 constexpr int kLWaves = kLBlock / 64;
-constexpr int kWin = 64;
-constexpr int kRCap = 192;
+constexpr int kWin = 192;
+constexpr int kRCap = 256;
 constexpr int kRPer = kRCap / 64;
 constexpr int kWFine = 256;
 constexpr int kWInsertMax = 16;
 constexpr int kDCap = 2048;
-constexpr int kWaveBytes = 3072;   // keys u64[192] | fine u32[260] | idx u16[192]
+constexpr int kWaveBytes = 3616;   // keys u64[256] | fine u32[260] | idx u16[256]
 constexpr int kMaxRanges = 1024;
-constexpr int kLdsFixed = kLWaves * kWaveBytes + kBuckets * 4 + (kMaxRanges + 8) * 4 + 128;
+// the coarse histogram is only alive in P1/P2 and the per-wave scratch only in P3: they share LDS
+constexpr int kLdsFixed = kLWaves * kWaveBytes + (kMaxRanges + 8) * 4 + 128;
+static_assert(kLWaves * kWaveBytes >= kBuckets * 4, "histogram must fit in the per-wave scratch");
 constexpr int kLdsMaxN = (163840 - kLdsFixed - 1024) / 2;
 
 __device__ __forceinline__ int coarse_bucket(double t, double period, double rp, double thr) {
@@ -399,8 +401,8 @@ __global__ __launch_bounds__(kLBlock) void sl_scan_lds_kernel(SlArgs a) {
     unsigned char *wbuf = lds_raw;                                                  // per-wave scratch
     unsigned long long *bkeys = reinterpret_cast<unsigned long long *>(lds_raw);    // P3b alias [kDCap]
     unsigned short *bidx = reinterpret_cast<unsigned short *>(bkeys + kDCap);       // P3b alias [kDCap]
-    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw + kLWaves * kWaveBytes);  // [kBuckets]
-    unsigned short *bndb = reinterpret_cast<unsigned short *>(hist + kBuckets);     // [kMaxRanges + 8]
+    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw);                         // P1/P2 alias [kBuckets]
+    unsigned short *bndb = reinterpret_cast<unsigned short *>(lds_raw + kLWaves * kWaveBytes);  // [kMaxRanges + 8]
     unsigned short *bnds = bndb + kMaxRanges + 8;                                   // [kMaxRanges + 8]
     unsigned *defer = reinterpret_cast<unsigned *>(bnds + kMaxRanges + 8);          // [32]
     unsigned short *order = reinterpret_cast<unsigned short *>(defer + 32);         // [n]
@@ -704,7 +706,7 @@ extern "C" {
 
 int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) {
     if (n < 0 || n_periods < 0) return -1;
-    const int64_t nr = (n + 63) / 64 + 8;
+    const int64_t nr = (n + 63) / 64 + 8;  // sized for the smallest window
     return grid_for(n_periods > 0 ? n_periods : 1) * (pad_pow2(n) * 24 + nr * 40) + 512;
 }
 
