@@ -6,6 +6,7 @@
 // (/root/reference/src/periodicity/phase.py:69-70,185-186) is not reproduced.
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -83,7 +84,9 @@ int scan_multi(const double *t, const double *y, const double *dy, int64_t n, do
                                      fit_mean, psd, (double *)pd[d].pow + j0, nullptr, nullptr,
                                      pd[d].work, wb));
     }
-    if (n_devices > 1) {
+    // PDC_FORCE_RCCL=1 runs the collective even for one device (exercises the RCCL path on 1-GPU boxes)
+    static const bool force_rccl = [] { const char *e = getenv("PDC_FORCE_RCCL"); return e && e[0] == '1'; }();
+    if (n_devices > 1 || force_rccl) {
         ncclComm_t *comms;
         PDC_TRY(get_comms(devices, n_devices, &comms));
         PDC_NCCL(ncclGroupStart());

@@ -199,6 +199,18 @@ def test_slabs_tile_the_grid_bitwise():
     assert ls(TSeries(t, y), err=dy).size > 0
 
 
+def test_rccl_all_gather_path_on_one_device():
+    # the collective of pdc_gls_scan_multi (ncclCommInitAll + grouped in-place all-gather) is
+    # normally skipped for a single device; force it in a child process (the switch is read once)
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PDC_FORCE_RCCL="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_single_device_check.py")],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert "all-gather equal: True" in out.stdout, out.stdout[-400:] + out.stderr[-400:]
+
+
 def test_large_time_offset_is_harmless():
     # Kepler-style barycentric dates: f*t spans ~1e7 cycles, the phase must not lose bits
     t, y, dy = synth(2000, 33)
