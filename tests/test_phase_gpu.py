@@ -131,9 +131,15 @@ def test_stringlength_clusters_take_the_scratch_path():
     np.testing.assert_allclose(got[:3], so.stringlength_scan(t, m, periods[:3]), rtol=RTOL)
 
 
-def test_stringlength_large_n_takes_the_scratch_kernel():
-    # N above the all-LDS kernel's limit (63160 samples): partition through global scratch
-    t, y = synth(70_000, 77)
+def test_stringlength_large_n_runs_in_phase_slices():
+    # more samples than one LDS slice holds (50480 16-bit / 23192 32-bit indices): the kernel
+    # repeats histogram + permutation + sort per slice of the phase axis
+    t6, y6 = synth(60_000, 78)                              # 16-bit indices, two slices
+    m6 = so.stringlength_scale(y6)
+    p6 = np.array([0.9, 13.7, 4000.0])
+    np.testing.assert_allclose(_cabi.stringlength_scan(t6, m6, p6),
+                               co.stringlength_scan(t6, m6, p6), rtol=RTOL)
+    t, y = synth(70_000, 77)                                # 32-bit indices, four slices
     m = so.stringlength_scale(y)
     periods = np.array([0.9, 13.7, 333.3, 9000.0])
     np.testing.assert_allclose(_cabi.stringlength_scan(t, m, periods),
