@@ -127,6 +127,85 @@ __global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
     }
 }
 
+// ---- the same prologue, grid-wide, for ONE long light curve (three short launches instead of one
+// 1024-thread workgroup walking the whole curve): A = partial sums of err^-2 and err^-2*y;
+// B = every workgroup re-reduces A's partials in a fixed order (identical W and ybar everywhere),
+// writes its records and its partials of YY and sum w; C = one workgroup folds those into scal.
+constexpr int kPrepParts = 512;
+
+struct WidePrepArgs {
+    PrepArgs p;
+    int nparts;
+    double *part;  // [4][kPrepParts]: sum err^-2 | sum err^-2 y | YY | sum w
+};
+
+__global__ __launch_bounds__(kBlock) void gls_prep_wide_a(WidePrepArgs a) {
+    __shared__ double red[kBlock / 64];
+    double sw = 0.0, swy = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.p.n_total;
+         i += (int64_t)gridDim.x * kBlock) {
+        const double e = a.p.dy ? a.p.dy[i] : 1.0;
+        const double wr = 1.0 / (e * e);
+        sw += wr;
+        swy += wr * a.p.y[i];
+    }
+    sw = block_sum<kBlock>(sw, red);
+    swy = block_sum<kBlock>(swy, red);
+    if (threadIdx.x == 0) {
+        a.part[blockIdx.x] = sw;
+        a.part[kPrepParts + blockIdx.x] = swy;
+    }
+}
+
+__device__ __forceinline__ double fold_partials(const double *p, int count, double *red) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < count; i += kBlock) v += p[i];
+    return block_sum<kBlock>(v, red);
+}
+
+__global__ __launch_bounds__(kBlock) void gls_prep_wide_b(WidePrepArgs a) {
+    __shared__ double red[kBlock / 64];
+    const double W = fold_partials(a.part, a.nparts, red);
+    const double ybar = a.p.fit_mean ? fold_partials(a.part + kPrepParts, a.nparts, red) / W : 0.0;
+    const double t0 = a.p.t[0];
+    double yy = 0.0, wsum = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.p.n_total;
+         i += (int64_t)gridDim.x * kBlock) {
+        const double tp = a.p.t[i] - t0;
+        const double e = a.p.dy ? a.p.dy[i] : 1.0;
+        const double w = (1.0 / (e * e)) / W;
+        const double yc = a.p.y[i] - ybar;
+        const double wy = w * yc;
+        yy += wy * yc;
+        wsum += w;
+        double sd, cd;
+        sincos_cycles(frac_product(a.p.delta, tp), sd, cd);
+        double2 *r = reinterpret_cast<double2 *>(a.p.rec + i * 6);
+        r[0] = make_double2(tp, wy);
+        r[1] = make_double2(w, cd);
+        r[2] = make_double2(sd, cd + cd);
+    }
+    yy = block_sum<kBlock>(yy, red);
+    wsum = block_sum<kBlock>(wsum, red);
+    if (threadIdx.x == 0) {
+        a.part[2 * kPrepParts + blockIdx.x] = yy;
+        a.part[3 * kPrepParts + blockIdx.x] = wsum;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gls_prep_wide_c(WidePrepArgs a) {
+    __shared__ double red[kBlock / 64];
+    const double W = fold_partials(a.part, a.nparts, red);
+    const double yy = fold_partials(a.part + 2 * kPrepParts, a.nparts, red);
+    const double wsum = fold_partials(a.part + 3 * kPrepParts, a.nparts, red);
+    if (threadIdx.x == 0) {
+        a.p.scal[0] = yy;
+        a.p.scal[1] = wsum;
+        a.p.scal[2] = W;
+        a.p.scal[3] = a.p.t[0];
+    }
+}
+
 // ---- epilogue: spectral.py:113-132 (gls_epilogue.h); the 2-omega sums come from the double-angle
 // identities sin 2a = 2 sin a cos a, cos 2a = 1 - 2 sin^2 a ------------------------------------------
 template <int MODE>
@@ -430,7 +509,7 @@ void launch_scan(int K, int S, dim3 grid, hipStream_t st, const GlsArgs &a) {
 }
 
 struct WorkLayout {
-    int64_t rec, scal, blk_max, blk_arg, total;
+    int64_t rec, scal, parts, blk_max, blk_arg, total;
 };
 
 WorkLayout layout(int64_t n_total, int64_t n_curves, int64_t nf) {
@@ -439,7 +518,8 @@ WorkLayout layout(int64_t n_total, int64_t n_curves, int64_t nf) {
     WorkLayout w;
     w.rec = 0;
     w.scal = up(n_total * 48);
-    w.blk_max = w.scal + up(n_curves * 32);
+    w.parts = w.scal + up(n_curves * 32);
+    w.blk_max = w.parts + up(4 * kPrepParts * 8);
     w.blk_arg = w.blk_max + up(n_curves * tiles_max * 8);
     w.total = w.blk_arg + up(n_curves * tiles_max * 8);
     return w;
@@ -474,7 +554,18 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     p.delta = delta;
     p.rec = reinterpret_cast<double *>(base + w.rec);
     p.scal = reinterpret_cast<double *>(base + w.scal);
-    hipLaunchKernelGGL(gls_prep_kernel, dim3((unsigned)n_curves), dim3(kPrepBlock), 0, st, p);
+    if (n_curves == 1 && mode != MODE_RAW && n_total >= 16384) {
+        WidePrepArgs wp;
+        wp.p = p;
+        wp.nparts = (int)((n_total + 4 * kBlock - 1) / (4 * kBlock));
+        wp.nparts = wp.nparts > kPrepParts ? kPrepParts : wp.nparts;
+        wp.part = reinterpret_cast<double *>(base + w.parts);
+        hipLaunchKernelGGL(gls_prep_wide_a, dim3(wp.nparts), dim3(kBlock), 0, st, wp);
+        hipLaunchKernelGGL(gls_prep_wide_b, dim3(wp.nparts), dim3(kBlock), 0, st, wp);
+        hipLaunchKernelGGL(gls_prep_wide_c, dim3(1), dim3(kBlock), 0, st, wp);
+    } else {
+        hipLaunchKernelGGL(gls_prep_kernel, dim3((unsigned)n_curves), dim3(kPrepBlock), 0, st, p);
+    }
     PDC_HIP(hipGetLastError());
 
     int K, S;
