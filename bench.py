@@ -8,7 +8,9 @@ frequencies per GPU (BASELINE.json configs[1]); prints ONE JSON line on rank 0.
 A step = one pass of the hot path over resident inputs: ``pdc_gls_scan_dev`` (weights prologue +
 direct-sum scan + fused epilogue) writing power[nf] in HBM; with N > 1 ranks each rank scans its
 own contiguous slab of an N-times longer grid (weak scaling, samples replicated) and the slabs are
-all-gathered with RCCL so every rank ends the step holding the whole power array.
+all-gathered with RCCL so every rank ends the step holding the whole power array; the gather of
+step i runs on RCCL's stream while the compute stream already scans step i+1 (double-buffered
+outputs, everything drained before the clock stops).
 
 The product path is the C ABI (libperiodicity_hip.so) — torch is used only under torchrun, for
 rendezvous, the barrier and the RCCL all-gather.  ``oracle/`` is touched only by the
@@ -134,12 +136,17 @@ def main():
     if dist_mode:
         tt = torch.from_numpy(np.stack([t, y, dy])).cuda()
         d_t, d_y, d_dy = (tt[i].data_ptr() for i in range(3))
-        power = torch.empty(nf_total, dtype=torch.float64, device="cuda")
+        # two generations of the output buffers: the all-gather of step i (RCCL's own stream) overlaps
+        # the scan of step i+1 (compute stream); a buffer is reused only after its gather was waited on
+        powers = [torch.empty(nf_total, dtype=torch.float64, device="cuda") for _ in range(2)]
+        power = powers[0]
         work_bytes = lib.pdc_gls_work_bytes(n, 1, slab)
         work = torch.empty(work_bytes, dtype=torch.uint8, device="cuda")
         d_work = work.data_ptr()
-        slab_out = torch.empty(slab, dtype=torch.float64, device="cuda")
-        d_power_slab = slab_out.data_ptr()
+        slabs = [torch.empty(slab, dtype=torch.float64, device="cuda") for _ in range(2)]
+        d_power_slab = slabs[0].data_ptr()
+        pending = [None, None]
+        counter = [0]
         stream = torch.cuda.current_stream().cuda_stream
     else:
         bufs = [_cabi.DeviceBuffer.from_array(a, dev) for a in (t, y, dy)]
@@ -158,15 +165,28 @@ def main():
         return e.value
 
     def step(ev=None):
+        out_ptr = d_power_slab
+        if dist_mode:
+            g = counter[0] % 2
+            if pending[g] is not None:      # stream-level wait: buffers of generation g are free again
+                pending[g].wait()
+            out_ptr = slabs[g].data_ptr()
         if ev:
             _cabi.check(lib.pdc_event_record(dev, ev[0], stream))
         _cabi.check(lib.pdc_gls_scan_dev(dev, stream, d_t, d_y, d_dy, None, n, 1, 0, f0, delta,
-                                         j_begin, slab, 1, 0, d_power_slab, None, None, d_work,
+                                         j_begin, slab, 1, 0, out_ptr, None, None, d_work,
                                          work_bytes))
         if ev:
             _cabi.check(lib.pdc_event_record(dev, ev[1], stream))
-        if dist_mode and world >= 1:
-            dist.all_gather_into_tensor(power, slab_out)
+        if dist_mode:
+            pending[g] = dist.all_gather_into_tensor(powers[g], slabs[g], async_op=True)
+            counter[0] += 1
+
+    def drain():
+        if dist_mode:
+            for h in pending:
+                if h is not None:
+                    h.wait()
 
     def sync():
         if dist_mode:
@@ -180,12 +200,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     events = [(new_event(), new_event()) for _ in range(args.steps)]
     barrier()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(events[i])
+    drain()
     sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -203,7 +225,7 @@ def main():
 
     if rank == 0:
         if dist_mode:
-            got = power.cpu().numpy()
+            got = powers[(counter[0] - 1) % 2].cpu().numpy()
         else:
             got = power_buf.to_array(np.float64, nf_total)
         pairs_per_step = float(n) * float(nf_total)
