@@ -296,3 +296,32 @@ def test_full_size_c2_properties():
     part = _cabi.gls_scan(t, y, dy, f0, delta, 4096, j_begin=500_000)
     # (a short slab picks a different tile shape, so agreement is to rounding, not bitwise)
     np.testing.assert_allclose(part, power[500_000:504_096], rtol=1e-8, atol=1e-15)
+
+
+def test_full_size_c3_batch_peaks_only():
+    """BASELINE configs[2]: 4096 curves x 2k samples on a shared 5e4 grid (4.1e11 pairs), reduced on
+    the device to (amax, argmax, highest peak); spot-checked against single-curve calls."""
+    B, n, nf = 4096, 2000, 50_000
+    rng = np.random.default_rng(20241011)
+    t = np.sort(rng.uniform(0, float(n), (B, n)), axis=1)
+    dy = rng.uniform(0.05, 0.2, (B, n))
+    per = 5.0 + 0.01 * np.arange(B)[:, None]
+    y = 1.0 + 0.5 * np.sin(2 * np.pi * t / per) + dy * rng.standard_normal((B, n))
+    offsets = np.arange(B + 1, dtype=np.int64) * n
+    df = 1.0 / n / 5
+    freq = np.arange(0.5 * df, 0.5 * df + (nf - 1.5) * df + df, df)
+    assert freq.size == nf
+    f0, delta, _ = _cabi.grid_params(freq)
+    _, amax, argmax = _cabi.gls_scan_batch(t.ravel(), y.ravel(), dy.ravel(), offsets, f0, delta, nf,
+                                           want_power=False, want_peaks=True)
+    idx, val = _cabi.gls_batch_highest_peak(t.ravel(), y.ravel(), dy.ravel(), offsets, f0, delta, nf)
+    assert np.all(argmax >= 0) and np.all(np.isfinite(amax))
+    found = 1 / freq[argmax]
+    # the injected periods are recovered to the grid resolution dP = P^2 df
+    assert np.mean(np.abs(found - per[:, 0]) < 1.5 * per[:, 0] ** 2 * df) > 0.99
+    assert np.array_equal(idx, argmax) or np.mean(idx == argmax) > 0.999
+    for b in rng.integers(0, B, 5):
+        single = _cabi.gls_scan(t[b], y[b], dy[b], f0, delta, nf)
+        # (a lone curve picks another tile shape than the 4096-curve batch: equal to rounding)
+        assert argmax[b] == np.argmax(single) and abs(amax[b] / single.max() - 1) < 1e-12
+        assert abs(val[b] / single[idx[b]] - 1) < 1e-12
