@@ -198,3 +198,21 @@ def test_class_level_calls_random():
         f_ref, ell_ref = so.stringlength(t, y, dphi=dphi, n_periods=nper)
         assert np.array_equal(sl.frequency, f_ref)
         np.testing.assert_allclose(sl.values, ell_ref, rtol=1e-9)
+
+
+def test_scans_are_bitwise_reproducible_run_to_run():
+    """No result depends on timing: reductions use fixed orders, LDS atomics only touch private
+    counters or feed a total order.  (The FFT path's grid is filled with global fp64 atomics, so it
+    is reproducible only to rounding and is not part of this check.)"""
+    rng = np.random.default_rng(17)
+    t, y, dy = random_curve(rng, 5000)
+    t = np.sort(rng.uniform(0, 5000.0, 5000))
+    m = so.stringlength_scale(y)
+    periods = np.linspace(0.8, 90.0, 700)
+    f0, delta, nf = 0.0004, 0.00013, 20000
+    ref = (_cabi.gls_scan(t, y, dy, f0, delta, nf), _cabi.pdm_scan(t, y, periods, 5, 2, np.var(y, ddof=1)),
+           _cabi.stringlength_scan(t, m, periods))
+    for _ in range(4):
+        assert np.array_equal(_cabi.gls_scan(t, y, dy, f0, delta, nf), ref[0])
+        assert np.array_equal(_cabi.pdm_scan(t, y, periods, 5, 2, np.var(y, ddof=1)), ref[1])
+        assert np.array_equal(_cabi.stringlength_scan(t, m, periods), ref[2])
