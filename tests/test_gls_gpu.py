@@ -325,3 +325,27 @@ def test_full_size_c3_batch_peaks_only():
         # (a lone curve picks another tile shape than the 4096-curve batch: equal to rounding)
         assert argmax[b] == np.argmax(single) and abs(amax[b] / single.max() - 1) < 1e-12
         assert abs(val[b] / single[idx[b]] - 1) < 1e-12
+
+
+def test_full_size_c4_on_one_gpu_both_paths():
+    """BASELINE configs[3] (N=1e6 x nf=1e7 = 1e13 pairs) on ONE GPU: the grid in 8 slabs exactly as
+    the 8-GPU run shards it, cross-checked against the FFT path (which reproduces the reference's own
+    algorithm) and, on a few bins, against the long-double oracle."""
+    n, nf, world = 1_000_000, 10_000_000, 8
+    t, y, dy = synth(n, 20241013)
+    df = 1.0 / (t[-1] - t[0]) / 5
+    fmin = 0.5 * df
+    f0, delta = fmin, df
+    slab = nf // world
+    power = np.concatenate([_cabi.gls_scan(t, y, dy, f0, delta, slab, j_begin=r * slab)
+                            for r in range(world)])
+    assert power.shape == (nf,) and np.all(np.isfinite(power))
+    fft = _cabi.gls_scan_fft(t, y, dy, fmin, df, nf)
+    peak = int(np.argmax(power))
+    assert peak == int(np.argmax(fft))                                   # tier R at the largest config
+    assert abs(1 / (f0 + peak * delta) - 37.3) < 0.01
+    assert np.median(np.abs(fft - power)) < 1e-6 and np.max(np.abs(fft - power)) < 1e-3
+    rng = np.random.default_rng(5)
+    pick = np.unique(np.concatenate([rng.integers(0, nf, 6), [peak]]))
+    exact = co.gls_power_exact(t, y, dy, f0 + delta * pick)
+    assert np.max(np.abs(power[pick] - exact) / np.abs(exact)) <= RTOL
