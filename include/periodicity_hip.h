@@ -126,6 +126,13 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
                          int fit_mean, int psd, double *d_power, void *work, int64_t work_bytes);
 int pdc_trig_sums_fft(const double *t, const double *h, int64_t n, double df, int64_t nf,
                       double fmin, double *S_out, double *C_out, int device);
+/* Batch of curves through the FFT path in one set of launches (layout and outputs as
+ * pdc_gls_scan_batch): with shared_t != 0 this is GLS.bootstrap (spectral.py:140-152) evaluated by
+ * the reference's own algorithm; the batch is processed in chunks sized to ~8 GiB of grids. */
+int pdc_gls_scan_fft_batch(const double *t, const double *y, const double *dy,
+                           const int64_t *offsets, int64_t n_curves, int shared_t,
+                           double fmin, double df, int64_t nf, int fit_mean, int psd,
+                           double *power_out, double *amax_out, int64_t *argmax_out, int device);
 
 /* ---- peak picking on the device --------------------------------------------------
  * Highest local maximum of each of n_curves spectra of nf bins, as

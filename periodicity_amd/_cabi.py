@@ -52,6 +52,7 @@ PROTOTYPES = {
     "pdc_gls_scan_fft": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _I, _I, _VP, _I]),
     "pdc_gls_scan_fft_dev": (_I, [_I, _VP, _VP, _VP, _VP, _L, _D, _D, _L, _I, _I, _VP, _VP, _L]),
     "pdc_trig_sums_fft": (_I, [_VP, _VP, _L, _D, _L, _D, _VP, _VP, _I]),
+    "pdc_gls_scan_fft_batch": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _I, _I, _VP, _VP, _VP, _I]),
     "pdc_highest_peak": (_I, [_VP, _L, _L, _VP, _VP, _I]),
     "pdc_highest_peak_dev": (_I, [_I, _VP, _VP, _L, _L, _VP, _VP]),
     "pdc_gls_batch_highest_peak": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _I, _I, _VP, _VP, _I]),
@@ -201,6 +202,27 @@ def gls_scan_fft(t, y, dy, fmin, df, nf, fit_mean=True, psd=False, device=None):
     check(lib().pdc_gls_scan_fft(_ptr(t), _ptr(y), _ptr(dy), t.size, float(fmin), float(df), nf,
                                  int(bool(fit_mean)), int(bool(psd)), _ptr(out), dev))
     return out
+
+
+def gls_scan_fft_batch(t, y, dy, offsets, fmin, df, nf, fit_mean=True, psd=False, shared_t=False,
+                       want_power=True, want_peaks=False, device=None):
+    """Batch of curves through the FFT path (Tier F); same layout/outputs as ``gls_scan_batch``."""
+    t, y = _f64(t, "t"), _f64(y, "y")
+    dy = None if dy is None else _f64(dy, "dy")
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    nb = offsets.size - 1
+    if nb < 1 or offsets[-1] != y.size or (dy is not None and dy.size != y.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    if (shared_t and t.size != offsets[1]) or (not shared_t and t.size != y.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    power = np.empty((nb, nf), dtype=np.float64) if want_power else None
+    amax = np.empty(nb, dtype=np.float64) if want_peaks else None
+    argmax = np.empty(nb, dtype=np.int64) if want_peaks else None
+    dev = default_device() if device is None else device
+    check(lib().pdc_gls_scan_fft_batch(_ptr(t), _ptr(y), _ptr(dy), _ptr(offsets), nb, int(shared_t),
+                                       float(fmin), float(df), nf, int(bool(fit_mean)),
+                                       int(bool(psd)), _ptr(power), _ptr(amax), _ptr(argmax), dev))
+    return power, amax, argmax
 
 
 def trig_sums_fft(t, h, df, nf, fmin, device=None):

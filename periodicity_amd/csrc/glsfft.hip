@@ -91,6 +91,8 @@ __global__ __launch_bounds__(kBlock) void fft_pass_kernel(const cplx *__restrict
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t T = N / R;
     if (j >= T) return;
+    in += (int64_t)blockIdx.y * N;   // batch of independent transforms, one per blockIdx.y
+    out += (int64_t)blockIdx.y * N;
     const int64_t k = j & (Ns - 1);
     cplx v[R];
 #pragma unroll
@@ -312,6 +314,181 @@ __global__ __launch_bounds__(kBlock) void glsfft_epilogue_kernel(FftEpiArgs a) {
     a.power[j] = p;
 }
 
+
+// ---- batched form: B light curves on one grid (bootstrap replicates share t) -----------------------
+struct FftBatchArgs {
+    const double *t, *y, *dy;
+    const int64_t *offsets;  // [B + 1]
+    int shared_t, fit_mean, psd, ngrid;
+    int64_t nfft, nf;
+    double df, fmin;
+    double *w, *wy;   // [n_total]
+    double *scal;     // [B][4] = {YY, Werr, tmin, -}
+    cplx *grids;      // [B][ngrid][nfft]
+    const cplx *result;  // where the transforms ended up (grids or scratch), same layout
+    double *power;    // [B][nf]
+};
+
+__global__ __launch_bounds__(1024) void glsfft_prep_batch_kernel(FftBatchArgs a) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    const int64_t off = a.offsets[blockIdx.x], n = a.offsets[blockIdx.x + 1] - off;
+    const double *t = a.shared_t ? a.t : a.t + off;
+    const double *y = a.y + off;
+    const double *dy = a.dy ? a.dy + off : nullptr;
+    double acc = 0.0, tmin = __builtin_inf();
+    for (int64_t i = tid; i < n; i += 1024) {
+        const double e = dy ? dy[i] : 1.0;
+        acc += 1.0 / (e * e);
+        tmin = t[i] < tmin ? t[i] : tmin;
+    }
+    const double W = block_sum<1024>(acc, red);
+    for (int o = 32; o > 0; o >>= 1) {
+        const double u = __shfl_down(tmin, o, 64);
+        tmin = u < tmin ? u : tmin;
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = tmin;
+    __syncthreads();
+    tmin = red[0];
+    for (int w = 1; w < 16; ++w) tmin = red[w] < tmin ? red[w] : tmin;
+    double ybar = 0.0;
+    if (a.fit_mean) {
+        acc = 0.0;
+        for (int64_t i = tid; i < n; i += 1024) {
+            const double e = dy ? dy[i] : 1.0;
+            acc += (1.0 / (e * e)) / W * y[i];
+        }
+        ybar = block_sum<1024>(acc, red);
+    }
+    double yy = 0.0;
+    for (int64_t i = tid; i < n; i += 1024) {
+        const double e = dy ? dy[i] : 1.0;
+        const double w = (1.0 / (e * e)) / W;
+        const double yc = y[i] - ybar;
+        a.w[off + i] = w;
+        a.wy[off + i] = w * yc;
+        yy += w * yc * yc;
+    }
+    yy = block_sum<1024>(yy, red);
+    if (tid == 0) {
+        double *s = a.scal + (int64_t)blockIdx.x * 4;
+        s[0] = yy;
+        s[1] = W;
+        s[2] = tmin;
+    }
+}
+
+__device__ __forceinline__ void spread_one(double *grid, int64_t nfft, double dt, double h, double df,
+                                           double fmin) {
+    const double ang = (6.283185307179586 * fmin) * dt;
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    const double hre = h * cs, him = h * sn;
+    const double nfftd = (double)nfft;
+    double tn = fmod((dt * nfftd) * df, nfftd);
+    if (tn != 0.0 && tn < 0.0) tn += nfftd;
+    if (tn - __builtin_floor(tn) == 0.0) {
+        grid_add(grid, (int64_t)tn, hre, him);
+        return;
+    }
+    int64_t ilo = (int64_t)(tn - 2.0);
+    ilo = ilo < 0 ? 0 : (ilo > nfft - 4 ? nfft - 4 : ilo);
+    const double x = tn - (double)ilo;
+    const double prod = ((x * (x - 1.0)) * (x - 2.0)) * (x - 3.0);
+    const double nre = hre * prod, nim = him * prod;
+    const double den[4] = {6.0, -2.0, 2.0, -6.0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t ind = ilo + (3 - j);
+        const double d = den[j] * (tn - (double)ind);
+        grid_add(grid, ind, nre / d, nim / d);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void glsfft_spread_batch_kernel(FftBatchArgs a) {
+    const int64_t b = blockIdx.y;
+    const int64_t off = a.offsets[b], n = a.offsets[b + 1] - off;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double *t = a.shared_t ? a.t : a.t + off;
+    const double dt = t[i] - a.scal[b * 4 + 2];
+    double *g0 = reinterpret_cast<double *>(a.grids + (b * a.ngrid) * a.nfft);
+    spread_one(g0, a.nfft, dt, a.wy[off + i], a.df, a.fmin);
+    spread_one(g0 + 2 * a.nfft, a.nfft, dt, a.w[off + i], 2.0 * a.df, 2.0 * a.fmin);
+    if (a.fit_mean) spread_one(g0 + 4 * a.nfft, a.nfft, dt, a.w[off + i], a.df, a.fmin);
+}
+
+__global__ __launch_bounds__(kBlock) void glsfft_epilogue_batch_kernel(FftBatchArgs a) {
+    const int64_t b = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= a.nf) return;
+    const double nfftd = (double)a.nfft, scale = 1.0 / nfftd;
+    const double *sc = a.scal + b * 4;
+    const double tmin = sc[2];
+    const cplx *g = a.result + (b * a.ngrid) * a.nfft;
+    const double f = a.fmin + a.df * (double)j;
+    double Sh, Ch, S2, C2, S = 0.0, C = 0.0;
+    cplx z = g[j];
+    z.re *= scale;
+    z.im *= scale;
+    finish_sum(z, tmin, f, nfftd, Sh, Ch);
+    z = g[a.nfft + j];
+    z.re *= scale;
+    z.im *= scale;
+    finish_sum(z, tmin, 2.0 * a.fmin + (2.0 * a.df) * (double)j, nfftd, S2, C2);
+    double p;
+    if (a.fit_mean) {
+        z = g[2 * a.nfft + j];
+        z.re *= scale;
+        z.im *= scale;
+        finish_sum(z, tmin, f, nfftd, S, C);
+        p = gls_power_from_sums<true>(Sh, Ch, S, C, S2, C2, sc[0], sc[1], a.psd);
+    } else {
+        p = gls_power_from_sums<false>(Sh, Ch, S, C, S2, C2, sc[0], sc[1], a.psd);
+    }
+    a.power[b * a.nf + j] = p;
+}
+
+// NaN-aware maximum and its first index per row (Signal.amax / argmax, core.py:202-215)
+__global__ __launch_bounds__(kBlock) void row_nanmax_kernel(const double *power, int64_t nf,
+                                                            double *amax, int64_t *argmax) {
+    __shared__ double rv[kBlock / 64];
+    __shared__ long long ri[kBlock / 64];
+    const double *x = power + (int64_t)blockIdx.x * nf;
+    double best = 0.0;
+    long long bi = -1;
+    for (int64_t i = threadIdx.x; i < nf; i += kBlock) {
+        const double v = x[i];
+        if (v == v && (bi < 0 || v > best)) {
+            best = v;
+            bi = i;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_down(best, o, 64);
+        const long long oi = __shfl_down(bi, o, 64);
+        if (oi >= 0 && (bi < 0 || ov > best || (ov == best && oi < bi))) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        rv[threadIdx.x >> 6] = best;
+        ri[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w)
+            if (ri[w] >= 0 && (bi < 0 || rv[w] > best || (rv[w] == best && ri[w] < bi))) {
+                best = rv[w];
+                bi = ri[w];
+            }
+        if (amax) amax[blockIdx.x] = bi >= 0 ? best : __builtin_nan("");
+        if (argmax) argmax[blockIdx.x] = bi;
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------
 int64_t fft_length(int64_t nf) {
     // 1 << int(nf * 5 - 1).bit_length()                                         (spectral.py:18)
@@ -324,15 +501,15 @@ int64_t fft_length(int64_t nf) {
 }
 
 template <int R>
-void launch_pass(hipStream_t st, const cplx *in, cplx *out, int64_t N, int64_t Ns) {
+void launch_pass(hipStream_t st, const cplx *in, cplx *out, int64_t N, int64_t Ns, int batch) {
     const int64_t T = N / R;
-    hipLaunchKernelGGL(fft_pass_kernel<R>, dim3((unsigned)((T + kBlock - 1) / kBlock)), dim3(kBlock),
-                       0, st, in, out, N, Ns);
+    hipLaunchKernelGGL(fft_pass_kernel<R>, dim3((unsigned)((T + kBlock - 1) / kBlock), (unsigned)batch),
+                       dim3(kBlock), 0, st, in, out, N, Ns);
 }
 
-// Unnormalised inverse FFT of `a` (N = 2^bits points) using `b` as the other half of the ping-pong;
-// returns the buffer that holds the result.
-cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N) {
+// Unnormalised inverse FFT of `batch` contiguous arrays of N = 2^bits points in `a`, using `b` (same
+// size) as the other half of the ping-pong; returns the buffer that holds the results.
+cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1) {
     int bits = 0;
     while (((int64_t)1 << bits) < N) ++bits;
     int64_t Ns = 1;
@@ -341,10 +518,10 @@ cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N) {
         int r = bits >= 4 ? 4 : bits;
         if (bits == 5) r = 3;  // 5 = 3 + 2 rather than 4 + 1
         switch (r) {
-            case 4: launch_pass<16>(st, src, dst, N, Ns); break;
-            case 3: launch_pass<8>(st, src, dst, N, Ns); break;
-            case 2: launch_pass<4>(st, src, dst, N, Ns); break;
-            default: launch_pass<2>(st, src, dst, N, Ns); break;
+            case 4: launch_pass<16>(st, src, dst, N, Ns, batch); break;
+            case 3: launch_pass<8>(st, src, dst, N, Ns, batch); break;
+            case 2: launch_pass<4>(st, src, dst, N, Ns, batch); break;
+            default: launch_pass<2>(st, src, dst, N, Ns, batch); break;
         }
         Ns <<= r;
         bits -= r;
@@ -480,6 +657,112 @@ int pdc_gls_scan_fft(const double *t, const double *y, const double *dy, int64_t
     PDC_TRY(pdc_gls_scan_fft_dev(device, st, (double *)d_t, (double *)d_y, (double *)d_dy, n, fmin, df,
                                  nf, fit_mean, psd, (double *)d_pow, d_work, wb));
     PDC_HIP(hipMemcpyAsync(power_out, d_pow, nf * 8, hipMemcpyDeviceToHost, st));
+    PDC_HIP(hipStreamSynchronize(st));
+    return PDC_OK;
+}
+
+
+int pdc_gls_scan_fft_batch(const double *t, const double *y, const double *dy, const int64_t *offsets,
+                           int64_t n_curves, int shared_t, double fmin, double df, int64_t nf,
+                           int fit_mean, int psd, double *power_out, double *amax_out,
+                           int64_t *argmax_out, int device) {
+    PDC_REQUIRE(t && y && offsets, "gls_fft_batch: t, y and offsets must not be NULL");
+    PDC_REQUIRE(n_curves >= 1 && nf >= 0, "gls_fft_batch: bad size");
+    PDC_REQUIRE(power_out || amax_out || argmax_out, "gls_fft_batch: no output requested");
+    PDC_REQUIRE(offsets[0] == 0, "gls_fft_batch: offsets[0] must be 0");
+    int64_t n_max = 0;
+    for (int64_t b = 0; b < n_curves; ++b) {
+        const int64_t nb = offsets[b + 1] - offsets[b];
+        PDC_REQUIRE(nb >= 0, "gls_fft_batch: offsets must be non-decreasing");
+        PDC_REQUIRE(!shared_t || nb == offsets[1] - offsets[0],
+                    "gls_fft_batch: with a shared time axis every curve must have the same length");
+        n_max = nb > n_max ? nb : n_max;
+    }
+    if (nf == 0) return PDC_OK;
+    PDC_TRY(use_device(device));
+    DeviceLock lock(device);
+    const int64_t n_total = offsets[n_curves];
+    const int64_t n_t = shared_t ? offsets[1] : n_total;
+    const int64_t nfft = fft_length(nf);
+    const int ngrid = fit_mean ? 3 : 2;
+    // curves per pass: grids + ping-pong scratch + power within ~8 GiB, and gridDim.y <= 65535
+    const int64_t per_curve = 2 * ngrid * nfft * 16 + nf * 8;
+    int64_t chunk = ((int64_t)8 << 30) / per_curve;
+    chunk = chunk < 1 ? 1 : chunk;
+    chunk = chunk > n_curves ? n_curves : chunk;
+    chunk = chunk > 65535 / ngrid ? 65535 / ngrid : chunk;
+    auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+    const int64_t o_w = 0, o_wy = up(n_total * 8), o_scal = o_wy + up(n_total * 8);
+    const int64_t o_grid = o_scal + up(n_curves * 32);
+    const int64_t o_scratch = o_grid + up(chunk * ngrid * nfft * 16);
+    const int64_t o_pow = o_scratch + up(chunk * ngrid * nfft * 16);
+    const int64_t wb = o_pow + up(chunk * nf * 8);
+    void *d_t, *d_y, *d_dy = nullptr, *d_off, *d_amax = nullptr, *d_arg = nullptr, *d_work;
+    PDC_TRY(cached(device, SLOT_IN0, n_t * 8, &d_t));
+    PDC_TRY(cached(device, SLOT_IN1, n_total * 8, &d_y));
+    if (dy) PDC_TRY(cached(device, SLOT_IN2, n_total * 8, &d_dy));
+    PDC_TRY(cached(device, SLOT_IN3, (n_curves + 1) * 8, &d_off));
+    if (amax_out) PDC_TRY(cached(device, SLOT_OUT1, n_curves * 8, &d_amax));
+    if (argmax_out) PDC_TRY(cached(device, SLOT_OUT2, n_curves * 8, &d_arg));
+    PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
+    hipStream_t st = nullptr;
+    PDC_HIP(hipMemcpyAsync(d_t, t, n_t * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemcpyAsync(d_y, y, n_total * 8, hipMemcpyHostToDevice, st));
+    if (dy) PDC_HIP(hipMemcpyAsync(d_dy, dy, n_total * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemcpyAsync(d_off, offsets, (n_curves + 1) * 8, hipMemcpyHostToDevice, st));
+    char *base = static_cast<char *>(d_work);
+    FftBatchArgs a;
+    a.t = (double *)d_t;
+    a.y = (double *)d_y;
+    a.dy = (double *)d_dy;
+    a.offsets = (int64_t *)d_off;
+    a.shared_t = shared_t;
+    a.fit_mean = fit_mean;
+    a.psd = psd;
+    a.ngrid = ngrid;
+    a.nfft = nfft;
+    a.nf = nf;
+    a.df = df;
+    a.fmin = fmin;
+    a.w = reinterpret_cast<double *>(base + o_w);
+    a.wy = reinterpret_cast<double *>(base + o_wy);
+    a.scal = reinterpret_cast<double *>(base + o_scal);
+    a.grids = reinterpret_cast<cplx *>(base + o_grid);
+    a.result = nullptr;
+    a.power = reinterpret_cast<double *>(base + o_pow);
+    cplx *scratch = reinterpret_cast<cplx *>(base + o_scratch);
+    hipLaunchKernelGGL(glsfft_prep_batch_kernel, dim3((unsigned)n_curves), dim3(1024), 0, st, a);
+    PDC_HIP(hipGetLastError());
+    const double *scal_all = a.scal;
+    for (int64_t c0 = 0; c0 < n_curves; c0 += chunk) {
+        const int64_t bc = n_curves - c0 < chunk ? n_curves - c0 : chunk;
+        FftBatchArgs c = a;
+        c.offsets = a.offsets + c0;
+        c.scal = const_cast<double *>(scal_all) + c0 * 4;
+        PDC_HIP(hipMemsetAsync(c.grids, 0, (size_t)(bc * ngrid * nfft * 16), st));
+        if (n_max > 0) {
+            hipLaunchKernelGGL(glsfft_spread_batch_kernel,
+                               dim3((unsigned)((n_max + kBlock - 1) / kBlock), (unsigned)bc), dim3(kBlock),
+                               0, st, c);
+            PDC_HIP(hipGetLastError());
+        }
+        c.result = inverse_fft(st, c.grids, scratch, nfft, (int)(bc * ngrid));
+        PDC_HIP(hipGetLastError());
+        hipLaunchKernelGGL(glsfft_epilogue_batch_kernel,
+                           dim3((unsigned)((nf + kBlock - 1) / kBlock), (unsigned)bc), dim3(kBlock), 0, st, c);
+        PDC_HIP(hipGetLastError());
+        if (amax_out || argmax_out) {
+            hipLaunchKernelGGL(row_nanmax_kernel, dim3((unsigned)bc), dim3(kBlock), 0, st, c.power, nf,
+                               d_amax ? (double *)d_amax + c0 : nullptr,
+                               d_arg ? (int64_t *)d_arg + c0 : nullptr);
+            PDC_HIP(hipGetLastError());
+        }
+        if (power_out)
+            PDC_HIP(hipMemcpyAsync(power_out + c0 * nf, c.power, (size_t)(bc * nf * 8),
+                                   hipMemcpyDeviceToHost, st));
+    }
+    if (amax_out) PDC_HIP(hipMemcpyAsync(amax_out, d_amax, n_curves * 8, hipMemcpyDeviceToHost, st));
+    if (argmax_out) PDC_HIP(hipMemcpyAsync(argmax_out, d_arg, n_curves * 8, hipMemcpyDeviceToHost, st));
     PDC_HIP(hipStreamSynchronize(st));
     return PDC_OK;
 }

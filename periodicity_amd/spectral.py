@@ -133,12 +133,12 @@ class GLS(object):
         offsets = np.arange(n_bootstraps + 1, dtype=np.int64) * ndata
         bs_replicates = np.empty(n_bootstraps)
         if n_bootstraps and self.method == "fft":
-            # replicate-by-replicate through the reference's own algorithm, like upstream's loop
+            # all replicates through the reference's own algorithm in one batched set of launches
             df, fmin, _ = self._grid_scalars(self.signal)
-            for i in range(n_bootstraps):
-                power = _cabi.gls_scan_fft(t, values[picks[i]], err[picks[i]], fmin, df, nf, True,
-                                           self.psd, device=self.device)
-                bs_replicates[i] = np.nanmax(power)
+            _, amax, _ = _cabi.gls_scan_fft_batch(
+                t, values[picks].ravel(), err[picks].ravel(), offsets, fmin, df, nf, True, self.psd,
+                shared_t=True, want_power=False, want_peaks=True, device=self.device)
+            bs_replicates[:] = amax
         elif n_bootstraps:
             _, amax, _ = _cabi.gls_scan_batch(
                 t, values[picks].ravel(), err[picks].ravel(), offsets, f0, delta, nf, True,

@@ -142,3 +142,37 @@ def test_full_size_c2_matches_cpu_reference_path():
     assert int(np.argmax(got)) == int(np.argmax(want))
     direct = _cabi.gls_scan(t, y, dy, fmin, df, nf)
     assert int(np.argmax(direct)) == int(np.argmax(got))      # tier R, the other way round
+
+
+def test_batched_fft_path_equals_single_calls():
+    rng = np.random.default_rng(12)
+    lens = [50, 300, 301, 1000, 7]
+    curves = [synth(n, 200 + i) for i, n in enumerate(lens)]
+    offsets = np.concatenate([[0], np.cumsum(lens)])
+    t, y, dy = (np.concatenate([c[i] for c in curves]) for i in range(3))
+    nf, df, fmin = 3000, 0.00021, 0.0004
+    for fit_mean in (True, False):
+        power, amax, argmax = _cabi.gls_scan_fft_batch(t, y, dy, offsets, fmin, df, nf, fit_mean,
+                                                       want_peaks=True)
+        for b, (tb, yb, dyb) in enumerate(curves):
+            single = _cabi.gls_scan_fft(tb, yb, dyb, fmin, df, nf, fit_mean)
+            assert_tier_f(power[b], single, rtol=1e-9, afloor=1e-12)   # (global atomics: rounding only)
+            assert argmax[b] == np.nanargmax(power[b]) and amax[b] == np.nanmax(power[b])
+    # shared time axis (bootstrap shape), equal weights
+    tt, yy, _ = curves[3]
+    picks = rng.integers(0, 1000, (9, 1000))
+    offs = np.arange(10) * 1000
+    power, _, _ = _cabi.gls_scan_fft_batch(tt, yy[picks].ravel(), None, offs, fmin, df, nf, shared_t=True)
+    for b in range(9):
+        assert_tier_f(power[b], _cabi.gls_scan_fft(tt, yy[picks[b]], None, fmin, df, nf), 1e-9, 1e-12)
+
+
+def test_bootstrap_1000_replicates_through_both_paths_agree_on_the_false_alarm_level():
+    t, y, dy = synth(400, 31)
+    fft, direct = GLS(method="fft"), GLS()
+    fft(TSeries(t, y), err=dy)
+    direct(TSeries(t, y), err=dy)
+    r_fft = fft.bootstrap(300, random_seed=7)
+    r_dir = direct.bootstrap(300, random_seed=7)
+    assert np.max(np.abs(r_fft - r_dir)) < 5e-3          # same draws, approximation error only
+    assert abs(fft.fal(0.05) - direct.fal(0.05)) < 5e-3

@@ -27,3 +27,14 @@ s5 = TSeries(t5, y5)
 r["C5 PDM class call ms"] = best(lambda: PDM(p_min=1.0, p_max=100.0, n_periods=100_000)(s5), 3) * 1e3
 r["C5 StringLength class call ms"] = best(lambda: StringLength(n_periods=100_000)(s5), 3) * 1e3
 print(json.dumps({k: round(v, 2) for k, v in r.items()}))
+
+# bootstrap false-alarm levels: 1000 replicates of a 2000-sample curve on its default grid
+tb, yb, dyb = bench.synth_curve(2000, k=6, period=11.0)
+sb = TSeries(tb, yb)
+rb = {}
+for method in ("direct", "fft"):
+    g = GLS(method=method)
+    g(sb, err=dyb)
+    rb[f"bootstrap(1000) N=2000 nf={g.frequency.size} method={method} ms"] = round(
+        best(lambda: g.bootstrap(1000, random_seed=1), 2) * 1e3, 1)
+print(json.dumps(rb))
