@@ -19,6 +19,8 @@
 #include "pdc_internal.h"
 #include "gls_epilogue.h"
 
+#include <cstdlib>
+
 using namespace pdc;
 
 namespace {
@@ -108,6 +110,82 @@ __global__ __launch_bounds__(kBlock) void fft_pass_kernel(const cplx *__restrict
     const int64_t j0 = (j - k) * R + k;
 #pragma unroll
     for (int r = 0; r < R; ++r) out[j0 + r * Ns] = v[r];
+}
+
+
+// One Stockham pass of radix R = 16 x RB (RB = 16, 8, 4, 2) through LDS: one HBM trip does a radix-16
+// stage and a radix-RB stage.  A workgroup of 256 threads owns JT = 256/RB consecutive butterflies j
+// (each an R-point DFT over the inputs in[j + r*T], r = r1 + RB*r2, r1 < RB, r2 < 16):
+//   stage A  thread (jj, r1): outer twiddles, 16-point DFT over r2, inner twiddle W_R^(r1*s2) -> LDS
+//   stage B  (jj, s2) pairs, 16/RB per thread: RB-point DFT over r1 -> Y[s2 + 16 s1]
+//            -> out[(j-k)*R + k + s*Ns]
+// Global accesses are runs of >= 16 consecutive complex numbers (256 B).  Requires N >= 4096.
+template <int RB>
+__global__ __launch_bounds__(256) void fft_pass_lds_kernel(const cplx *__restrict__ in,
+                                                            cplx *__restrict__ out, int64_t N,
+                                                            int64_t Ns) {
+    constexpr int R = 16 * RB;
+    constexpr int JT = 256 / RB;          // butterflies per workgroup
+    constexpr int ROW = R + 16;           // padded LDS row per butterfly
+    __shared__ cplx tile[JT * ROW];       // [jj][r1][s2]
+    __shared__ cplx wR[R];
+    const int tid = threadIdx.x;
+    in += (int64_t)blockIdx.y * N;
+    out += (int64_t)blockIdx.y * N;
+    if (tid < R) {
+        double s, c;
+        sincos_cycles((double)tid * (1.0 / (double)R), s, c);
+        wR[tid] = cplx{c, s};
+    }
+    const int64_t T = N / R;
+    const int64_t j_base = (int64_t)blockIdx.x * JT;
+    // ---- stage A -------------------------------------------------------------------------------
+    {
+        const int jj = tid % JT, r1 = tid / JT;
+        const int64_t j = j_base + jj;
+        const int64_t k = j & (Ns - 1);
+        cplx v[16];
+#pragma unroll
+        for (int r2 = 0; r2 < 16; ++r2) v[r2] = in[j + (int64_t)(r1 + RB * r2) * T];
+        if (Ns > 1) {
+            // outer twiddle e^{2 pi i r k / (R Ns)}, r = r1 + RB r2: tw(r1) * tw(RB)^r2
+            const double inv = 1.0 / (double)(Ns * R);
+            double s, c;
+            sincos_cycles((double)((int64_t)r1 * k) * inv, s, c);
+            cplx tw = cplx{c, s};
+            sincos_cycles((double)((int64_t)RB * k) * inv, s, c);
+            const cplx step = cplx{c, s};
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) {
+                v[r2] = cmul(v[r2], tw);
+                tw = cmul(tw, step);
+            }
+        }
+        Dft<16>::run(v);
+        __syncthreads();  // wR ready
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2)
+            tile[jj * ROW + r1 * 16 + s2] = cmul(v[s2], wR[(r1 * s2) % R]);
+    }
+    __syncthreads();
+    // ---- stage B -------------------------------------------------------------------------------
+#pragma unroll
+    for (int it = 0; it < 16 / RB; ++it) {
+        const int pair = tid + it * 256;  // (jj, s2) pairs, JT * 16 of them
+        // lanes run over jj when consecutive j write consecutive addresses (Ns >= 16), over s2 when
+        // the R outputs of one j are contiguous (first pass, Ns == 1)
+        const int jj = Ns > 1 ? pair % JT : pair / 16;
+        const int s2 = Ns > 1 ? pair / JT : pair % 16;
+        const int64_t j = j_base + jj;
+        const int64_t k = j & (Ns - 1);
+        cplx v[RB];
+#pragma unroll
+        for (int r1 = 0; r1 < RB; ++r1) v[r1] = tile[jj * ROW + r1 * 16 + s2];
+        Dft<RB>::run(v);
+        const int64_t j0 = (j - k) * R + k;
+#pragma unroll
+        for (int s1 = 0; s1 < RB; ++s1) out[j0 + (int64_t)(s2 + 16 * s1) * Ns] = v[s1];
+    }
 }
 
 // ---- prologue: spectral.py:99-108, 120 -- two grid-wide kernels, deterministic partials ------------
@@ -240,6 +318,51 @@ __global__ __launch_bounds__(kBlock) void glsfft_spread_kernel(SpreadArgs a) {
         const double d = den[j] * (tn - (double)ind);
         grid_add(a.grid, ind, nre / d, nim / d);
     }
+}
+
+__device__ __forceinline__ void spread_one(double *grid, int64_t nfft, double dt, double h, double df,
+                                           double fmin) {
+    const double ang = (6.283185307179586 * fmin) * dt;
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    const double hre = h * cs, him = h * sn;
+    const double nfftd = (double)nfft;
+    double tn = fmod((dt * nfftd) * df, nfftd);
+    if (tn != 0.0 && tn < 0.0) tn += nfftd;
+    if (tn - __builtin_floor(tn) == 0.0) {
+        grid_add(grid, (int64_t)tn, hre, him);
+        return;
+    }
+    int64_t ilo = (int64_t)(tn - 2.0);
+    ilo = ilo < 0 ? 0 : (ilo > nfft - 4 ? nfft - 4 : ilo);
+    const double x = tn - (double)ilo;
+    const double prod = ((x * (x - 1.0)) * (x - 2.0)) * (x - 3.0);
+    const double nre = hre * prod, nim = him * prod;
+    const double den[4] = {6.0, -2.0, 2.0, -6.0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t ind = ilo + (3 - j);
+        const double d = den[j] * (tn - (double)ind);
+        grid_add(grid, ind, nre / d, nim / d);
+    }
+}
+
+// All three (or two) grids of one curve in a single launch: (w*y @ df), (w @ 2 df), (w @ df).
+struct Spread3Args {
+    const double *t, *wy, *w, *scal;
+    int64_t n, nfft;
+    double df, fmin;
+    double *grids;  // [ngrid][nfft] complex, zeroed
+    int fit_mean;
+};
+
+__global__ __launch_bounds__(kBlock) void glsfft_spread3_kernel(Spread3Args a) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const double dt = a.t[i] - a.scal[2];
+    spread_one(a.grids, a.nfft, dt, a.wy[i], a.df, a.fmin);
+    spread_one(a.grids + 2 * a.nfft, a.nfft, dt, a.w[i], 2.0 * a.df, 2.0 * a.fmin);   // (:110)
+    if (a.fit_mean) spread_one(a.grids + 4 * a.nfft, a.nfft, dt, a.w[i], a.df, a.fmin);
 }
 
 // ---- epilogue: spectral.py:34-39 then :113-132 ----------------------------------------------------------
@@ -379,33 +502,6 @@ __global__ __launch_bounds__(1024) void glsfft_prep_batch_kernel(FftBatchArgs a)
     }
 }
 
-__device__ __forceinline__ void spread_one(double *grid, int64_t nfft, double dt, double h, double df,
-                                           double fmin) {
-    const double ang = (6.283185307179586 * fmin) * dt;
-    double sn, cs;
-    sincos(ang, &sn, &cs);
-    const double hre = h * cs, him = h * sn;
-    const double nfftd = (double)nfft;
-    double tn = fmod((dt * nfftd) * df, nfftd);
-    if (tn != 0.0 && tn < 0.0) tn += nfftd;
-    if (tn - __builtin_floor(tn) == 0.0) {
-        grid_add(grid, (int64_t)tn, hre, him);
-        return;
-    }
-    int64_t ilo = (int64_t)(tn - 2.0);
-    ilo = ilo < 0 ? 0 : (ilo > nfft - 4 ? nfft - 4 : ilo);
-    const double x = tn - (double)ilo;
-    const double prod = ((x * (x - 1.0)) * (x - 2.0)) * (x - 3.0);
-    const double nre = hre * prod, nim = him * prod;
-    const double den[4] = {6.0, -2.0, 2.0, -6.0};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t ind = ilo + (3 - j);
-        const double d = den[j] * (tn - (double)ind);
-        grid_add(grid, ind, nre / d, nim / d);
-    }
-}
-
 __global__ __launch_bounds__(kBlock) void glsfft_spread_batch_kernel(FftBatchArgs a) {
     const int64_t b = blockIdx.y;
     const int64_t off = a.offsets[b], n = a.offsets[b + 1] - off;
@@ -514,9 +610,32 @@ cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1) {
     while (((int64_t)1 << bits) < N) ++bits;
     int64_t Ns = 1;
     cplx *src = a, *dst = b;
+    static const bool no_lds = [] { const char *e = getenv("PDC_FFT_NO256"); return e && e[0] == '1'; }();
     while (bits > 0) {
         int r = bits >= 4 ? 4 : bits;
         if (bits == 5) r = 3;  // 5 = 3 + 2 rather than 4 + 1
+        // LDS-blocked passes (radix 16 x RB in one trip through HBM): 8 bits at a time, then the
+        // remainder in one more LDS pass if it is 5..7 bits, else in a plain radix-2/4/8/16 pass
+        int lds_bits = 0;
+        if (!no_lds && bits >= 5 && N >= 4096)  // a workgroup covers R * JT = 4096 points
+            lds_bits = bits >= 8 ? 8 : bits;
+        if (lds_bits) {
+            const int64_t R = (int64_t)1 << lds_bits;
+            const int jt = 256 / (int)(R / 16);
+            const dim3 grid((unsigned)((N / R) / jt), (unsigned)batch);
+            switch (lds_bits) {
+                case 8: hipLaunchKernelGGL(fft_pass_lds_kernel<16>, grid, dim3(256), 0, st, src, dst, N, Ns); break;
+                case 7: hipLaunchKernelGGL(fft_pass_lds_kernel<8>, grid, dim3(256), 0, st, src, dst, N, Ns); break;
+                case 6: hipLaunchKernelGGL(fft_pass_lds_kernel<4>, grid, dim3(256), 0, st, src, dst, N, Ns); break;
+                default: hipLaunchKernelGGL(fft_pass_lds_kernel<2>, grid, dim3(256), 0, st, src, dst, N, Ns); break;
+            }
+            Ns <<= lds_bits;
+            bits -= lds_bits;
+            cplx *tmp = src;
+            src = dst;
+            dst = tmp;
+            continue;
+        }
         switch (r) {
             case 4: launch_pass<16>(st, src, dst, N, Ns, batch); break;
             case 3: launch_pass<8>(st, src, dst, N, Ns, batch); break;
@@ -543,12 +662,10 @@ FftLayout fft_layout(int64_t n, int64_t nfft) {
     L.w = up(n * 8);
     L.scal = L.w + up(n * 8);
     int64_t off = L.scal + up((4 * kMaxPart + 8) * 8);  // scal[8] | part[3][kMaxPart] | ypart[kMaxPart]
-    for (int g = 0; g < 3; ++g) {
-        L.grid[g] = off;
-        off += up(nfft * 16);
-    }
+    for (int g = 0; g < 3; ++g) L.grid[g] = off + g * nfft * 16;  // contiguous: batched FFT stride = nfft
+    off += up(3 * nfft * 16);
     L.scratch = off;
-    L.total = off + up(nfft * 16);
+    L.total = off + up(3 * nfft * 16);  // ping-pong partner of all three grids
     return L;
 }
 
@@ -588,32 +705,41 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
     PDC_HIP(hipGetLastError());
 
     const int ngrid = fit_mean ? 3 : 2;
-    cplx *result[3] = {nullptr, nullptr, nullptr};
-    for (int g = 0; g < ngrid; ++g) {
-        PDC_HIP(hipMemsetAsync(grid[g], 0, (size_t)nfft * 16, st));
-        SpreadArgs s;
-        s.t = d_t;
-        s.h = g == 0 ? wy : w;
-        s.scal = scal;
-        s.tmin_value = 0.0;
-        s.n = n;
-        s.nfft = nfft;
-        s.df = g == 1 ? 2.0 * df : df;      // _trig_sum(t, w, 2 * df, nf, 2 * fmin)   (:110)
-        s.fmin = g == 1 ? 2.0 * fmin : fmin;
-        s.grid = reinterpret_cast<double *>(grid[g]);
+    // One grid's ping-pong (32 B per point) may fit in the 256 MiB Infinity Cache while all of them do
+    // not: then zero, fill and transform the grids one after the other so that each stays cache-warm
+    // (measured at nfft = 2^23: 0.66 vs 0.69 ms); otherwise one memset, one fused spread launch and
+    // batched FFT passes (gridDim.y = ngrid; 6.4 vs 6.7 ms at nfft = 2^26).
+    const int64_t mall = (int64_t)256 << 20;
+    const cplx *result[3] = {nullptr, nullptr, nullptr};
+    if (nfft * 32 <= mall && (int64_t)ngrid * nfft * 32 > mall) {
+        for (int g = 0; g < ngrid; ++g) {
+            PDC_HIP(hipMemsetAsync(grid[g], 0, (size_t)nfft * 16, st));
+            SpreadArgs sp;
+            sp.t = d_t;
+            sp.h = g == 0 ? wy : w;
+            sp.scal = scal;
+            sp.tmin_value = 0.0;
+            sp.n = n;
+            sp.nfft = nfft;
+            sp.df = g == 1 ? 2.0 * df : df;      // _trig_sum(t, w, 2 * df, nf, 2 * fmin)   (:110)
+            sp.fmin = g == 1 ? 2.0 * fmin : fmin;
+            sp.grid = reinterpret_cast<double *>(grid[g]);
+            if (n > 0)
+                hipLaunchKernelGGL(glsfft_spread_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
+                                   dim3(kBlock), 0, st, sp);
+            result[g] = inverse_fft(st, grid[g], scratch + g * nfft, nfft);
+        }
+    } else {
+        PDC_HIP(hipMemsetAsync(grid[0], 0, (size_t)ngrid * nfft * 16, st));
         if (n > 0) {
-            hipLaunchKernelGGL(glsfft_spread_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
-                               dim3(kBlock), 0, st, s);
-            PDC_HIP(hipGetLastError());
+            Spread3Args s3{d_t, wy, w, scal, n, nfft, df, fmin, reinterpret_cast<double *>(grid[0]), fit_mean};
+            hipLaunchKernelGGL(glsfft_spread3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
+                               dim3(kBlock), 0, st, s3);
         }
-        result[g] = inverse_fft(st, grid[g], scratch, nfft);
-        PDC_HIP(hipGetLastError());
-        if (result[g] == scratch) {
-            // keep the result in this grid's own buffer so the scratch is free for the next one
-            PDC_HIP(hipMemcpyAsync(grid[g], scratch, (size_t)nf * 16, hipMemcpyDeviceToDevice, st));
-            result[g] = grid[g];
-        }
+        const cplx *res = inverse_fft(st, grid[0], scratch, nfft, ngrid);
+        for (int g = 0; g < ngrid; ++g) result[g] = res + g * nfft;
     }
+    PDC_HIP(hipGetLastError());
     FftEpiArgs e;
     e.gh = result[0];
     e.g2 = result[1];
