@@ -89,7 +89,7 @@ struct Dft<1> {
 template <int R>
 __global__ __launch_bounds__(kBlock) void fft_pass_kernel(const cplx *__restrict__ in,
                                                           cplx *__restrict__ out, int64_t N,
-                                                          int64_t Ns) {
+                                                          int64_t Ns, int64_t keep) {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t T = N / R;
     if (j >= T) return;
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(kBlock) void fft_pass_kernel(const cplx *__restrict
     Dft<R>::run(v);
     const int64_t j0 = (j - k) * R + k;
 #pragma unroll
-    for (int r = 0; r < R; ++r) out[j0 + r * Ns] = v[r];
+    for (int r = 0; r < R; ++r)
+        if (j0 + r * Ns < keep) out[j0 + r * Ns] = v[r];  // last pass: only the first `keep` outputs
 }
 
 
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void fft_pass_kernel(const cplx *__restrict
 template <int RB>
 __global__ __launch_bounds__(256) void fft_pass_lds_kernel(const cplx *__restrict__ in,
                                                             cplx *__restrict__ out, int64_t N,
-                                                            int64_t Ns) {
+                                                            int64_t Ns, int64_t keep) {
     constexpr int R = 16 * RB;
     constexpr int JT = 256 / RB;          // butterflies per workgroup
     constexpr int ROW = R + 16;           // padded LDS row per butterfly
@@ -184,7 +185,10 @@ __global__ __launch_bounds__(256) void fft_pass_lds_kernel(const cplx *__restric
         Dft<RB>::run(v);
         const int64_t j0 = (j - k) * R + k;
 #pragma unroll
-        for (int s1 = 0; s1 < RB; ++s1) out[j0 + (int64_t)(s2 + 16 * s1) * Ns] = v[s1];
+        for (int s1 = 0; s1 < RB; ++s1) {
+            const int64_t o = j0 + (int64_t)(s2 + 16 * s1) * Ns;
+            if (o < keep) out[o] = v[s1];  // last pass: only the first `keep` outputs are ever read
+        }
     }
 }
 
@@ -597,15 +601,18 @@ int64_t fft_length(int64_t nf) {
 }
 
 template <int R>
-void launch_pass(hipStream_t st, const cplx *in, cplx *out, int64_t N, int64_t Ns, int batch) {
+void launch_pass(hipStream_t st, const cplx *in, cplx *out, int64_t N, int64_t Ns, int batch,
+                 int64_t keep) {
     const int64_t T = N / R;
     hipLaunchKernelGGL(fft_pass_kernel<R>, dim3((unsigned)((T + kBlock - 1) / kBlock), (unsigned)batch),
-                       dim3(kBlock), 0, st, in, out, N, Ns);
+                       dim3(kBlock), 0, st, in, out, N, Ns, keep);
 }
 
 // Unnormalised inverse FFT of `batch` contiguous arrays of N = 2^bits points in `a`, using `b` (same
-// size) as the other half of the ping-pong; returns the buffer that holds the results.
-cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1) {
+// size) as the other half of the ping-pong; returns the buffer that holds the results.  Only the first
+// `keep_out` outputs of every transform are needed by the caller (spectral.py:34 keeps [:nf]): the
+// final pass skips the stores beyond them.
+cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1, int64_t keep_out = -1) {
     int bits = 0;
     while (((int64_t)1 << bits) < N) ++bits;
     int64_t Ns = 1;
@@ -620,14 +627,15 @@ cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1) {
         if (!no_lds && bits >= 5 && N >= 4096)  // a workgroup covers R * JT = 4096 points
             lds_bits = bits >= 8 ? 8 : bits;
         if (lds_bits) {
+            const int64_t keep = (bits == lds_bits && keep_out >= 0) ? keep_out : N;  // final pass only
             const int64_t R = (int64_t)1 << lds_bits;
             const int jt = 256 / (int)(R / 16);
             const dim3 grid((unsigned)((N / R) / jt), (unsigned)batch);
             switch (lds_bits) {
-                case 8: hipLaunchKernelGGL(fft_pass_lds_kernel<16>, grid, dim3(256), 0, st, src, dst, N, Ns); break;
-                case 7: hipLaunchKernelGGL(fft_pass_lds_kernel<8>, grid, dim3(256), 0, st, src, dst, N, Ns); break;
-                case 6: hipLaunchKernelGGL(fft_pass_lds_kernel<4>, grid, dim3(256), 0, st, src, dst, N, Ns); break;
-                default: hipLaunchKernelGGL(fft_pass_lds_kernel<2>, grid, dim3(256), 0, st, src, dst, N, Ns); break;
+                case 8: hipLaunchKernelGGL(fft_pass_lds_kernel<16>, grid, dim3(256), 0, st, src, dst, N, Ns, keep); break;
+                case 7: hipLaunchKernelGGL(fft_pass_lds_kernel<8>, grid, dim3(256), 0, st, src, dst, N, Ns, keep); break;
+                case 6: hipLaunchKernelGGL(fft_pass_lds_kernel<4>, grid, dim3(256), 0, st, src, dst, N, Ns, keep); break;
+                default: hipLaunchKernelGGL(fft_pass_lds_kernel<2>, grid, dim3(256), 0, st, src, dst, N, Ns, keep); break;
             }
             Ns <<= lds_bits;
             bits -= lds_bits;
@@ -636,11 +644,12 @@ cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1) {
             dst = tmp;
             continue;
         }
+        const int64_t keep = (bits == r && keep_out >= 0) ? keep_out : N;  // final pass only
         switch (r) {
-            case 4: launch_pass<16>(st, src, dst, N, Ns, batch); break;
-            case 3: launch_pass<8>(st, src, dst, N, Ns, batch); break;
-            case 2: launch_pass<4>(st, src, dst, N, Ns, batch); break;
-            default: launch_pass<2>(st, src, dst, N, Ns, batch); break;
+            case 4: launch_pass<16>(st, src, dst, N, Ns, batch, keep); break;
+            case 3: launch_pass<8>(st, src, dst, N, Ns, batch, keep); break;
+            case 2: launch_pass<4>(st, src, dst, N, Ns, batch, keep); break;
+            default: launch_pass<2>(st, src, dst, N, Ns, batch, keep); break;
         }
         Ns <<= r;
         bits -= r;
@@ -727,7 +736,7 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
             if (n > 0)
                 hipLaunchKernelGGL(glsfft_spread_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
                                    dim3(kBlock), 0, st, sp);
-            result[g] = inverse_fft(st, grid[g], scratch + g * nfft, nfft);
+            result[g] = inverse_fft(st, grid[g], scratch + g * nfft, nfft, 1, nf);
         }
     } else {
         PDC_HIP(hipMemsetAsync(grid[0], 0, (size_t)ngrid * nfft * 16, st));
@@ -736,7 +745,7 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
             hipLaunchKernelGGL(glsfft_spread3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
                                dim3(kBlock), 0, st, s3);
         }
-        const cplx *res = inverse_fft(st, grid[0], scratch, nfft, ngrid);
+        const cplx *res = inverse_fft(st, grid[0], scratch, nfft, ngrid, nf);
         for (int g = 0; g < ngrid; ++g) result[g] = res + g * nfft;
     }
     PDC_HIP(hipGetLastError());
@@ -872,7 +881,7 @@ int pdc_gls_scan_fft_batch(const double *t, const double *y, const double *dy, c
                                0, st, c);
             PDC_HIP(hipGetLastError());
         }
-        c.result = inverse_fft(st, c.grids, scratch, nfft, (int)(bc * ngrid));
+        c.result = inverse_fft(st, c.grids, scratch, nfft, (int)(bc * ngrid), nf);
         PDC_HIP(hipGetLastError());
         hipLaunchKernelGGL(glsfft_epilogue_batch_kernel,
                            dim3((unsigned)((nf + kBlock - 1) / kBlock), (unsigned)bc), dim3(kBlock), 0, st, c);
@@ -918,7 +927,7 @@ int pdc_trig_sums_fft(const double *t, const double *h, int64_t n, double df, in
     hipLaunchKernelGGL(glsfft_spread_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock),
                        0, st, s);
     PDC_HIP(hipGetLastError());
-    cplx *res = inverse_fft(st, grid, scratch, nfft);
+    cplx *res = inverse_fft(st, grid, scratch, nfft, 1, nf);
     PDC_HIP(hipGetLastError());
     FftEpiArgs e{};
     e.gh = res;
