@@ -46,6 +46,7 @@ constexpr int kWin = 192;        // sorted positions per range window
 constexpr int kRCap = 256;       // samples a wave sorts by itself (4 per lane)
 constexpr int kRPer = kRCap / 64;
 constexpr int kWFine = 256;      // fine buckets per wave range
+constexpr int kCPL = kWFine / 64; // fine counters per lane (multiple of 4)
 constexpr int kWInsertMax = 16;  // fullest fine bucket the insertion-sort finish accepts
 constexpr int kDCap = 2048;      // workgroup-level (deferred) LDS sort capacity
 constexpr int kMaxRanges = 1024; // ranges per slice
@@ -360,7 +361,9 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                 const double fscale = (double)kBuckets * (double)g;
                 const int foff = lo_b * g;
                 const int flast = nbk <= kWFine ? nbk * g - 1 : (nbk >> shift);
-                reinterpret_cast<uint4 *>(fine_w)[lane] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int q = 0; q < kCPL / 4; ++q)
+                    reinterpret_cast<uint4 *>(fine_w)[lane * (kCPL / 4) + q] = make_uint4(0u, 0u, 0u, 0u);
                 if (lane < 4) fine_w[kWFine + lane] = 0u;
                 wave_sync();
                 unsigned long long ek[kRPer];
@@ -385,24 +388,44 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                     }
                 }
                 wave_sync();
-                // wave-level exclusive scan of the 256 counters (4 per lane) + fullest bucket
-                const uint4 c = reinterpret_cast<uint4 *>(fine_w)[lane];
-                const unsigned mx = max(max(c.x, c.y), max(c.z, c.w));
+                // wave-level exclusive scan of the kWFine counters (kCPL per lane) + fullest bucket
+                unsigned c[kCPL];
+#pragma unroll
+                for (int q = 0; q < kCPL / 4; ++q) {
+                    const uint4 v = reinterpret_cast<uint4 *>(fine_w)[lane * (kCPL / 4) + q];
+                    c[4 * q] = v.x;
+                    c[4 * q + 1] = v.y;
+                    c[4 * q + 2] = v.z;
+                    c[4 * q + 3] = v.w;
+                }
+                unsigned mx = 0, sum4 = 0;
+#pragma unroll
+                for (int q = 0; q < kCPL; ++q) {
+                    mx = c[q] > mx ? c[q] : mx;
+                    sum4 += c[q];
+                }
                 if (__any(mx > (unsigned)kWInsertMax)) {
                     if (lane == 0) atomicOr(&defer[r >> 5], 1u << (r & 31));
                     continue;
                 }
-                const unsigned sum4 = c.x + c.y + c.z + c.w;
                 unsigned incl = sum4;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
                     const unsigned up = __shfl_up(incl, o, 64);
                     if (lane >= o) incl += up;
                 }
-                const unsigned base = incl - sum4;
+                unsigned run = incl - sum4;
                 wave_sync();
-                reinterpret_cast<uint4 *>(fine_w)[lane] =
-                    make_uint4(base, base + c.x, base + c.x + c.y, base + c.x + c.y + c.z);
+#pragma unroll
+                for (int q = 0; q < kCPL; ++q) {
+                    const unsigned t = c[q];
+                    c[q] = run;
+                    run += t;
+                }
+#pragma unroll
+                for (int q = 0; q < kCPL / 4; ++q)
+                    reinterpret_cast<uint4 *>(fine_w)[lane * (kCPL / 4) + q] =
+                        make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
                 if (lane == 63) fine_w[kWFine] = incl;  // == cnt
                 wave_sync();
 #pragma unroll
@@ -415,10 +438,10 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                     }
                 }
                 wave_sync();
-                // finish: each lane orders its 4 fine buckets by (bits, index)
+                // finish: each lane orders its kCPL fine buckets by (bits, index)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int f = lane * 4 + q;
+                for (int q = 0; q < kCPL; ++q) {
+                    const int f = lane * kCPL + q;
                     const int s0 = (int)fine_w[f], s1 = (int)fine_w[f + 1];
                     for (int x = s0 + 1; x < s1; ++x) {
                         const unsigned long long kx = keys_w[x];
