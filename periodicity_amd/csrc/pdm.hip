@@ -25,7 +25,7 @@ using namespace pdc;
 
 namespace {
 
-constexpr int kChunk = 512;
+constexpr int kChunk = 128;
 
 struct PdmArgs {
     const double *t, *x, *periods;
@@ -60,7 +60,9 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     const int m0 = a.nb * a.nc;
     const int nbins = m0 + 1;  // + overflow bin for phi == 1.0
     double2 *stage = reinterpret_cast<double2 *>(lds_raw);                  // [kChunk] (t, x')
-    double *hsum = reinterpret_cast<double *>(stage + kChunk);              // [nbins][BLOCK]
+    // the staging area doubles as the q_over/q_nan exchange ([2][BLOCK] doubles) at the end
+    constexpr int kStage = kChunk > BLOCK ? kChunk : BLOCK;
+    double *hsum = reinterpret_cast<double *>(stage + kStage);              // [nbins][BLOCK]
     unsigned *hcnt = reinterpret_cast<unsigned *>(hsum + (size_t)nbins * BLOCK);  // [nbins][BLOCK]
     double *edge = reinterpret_cast<double *>(hcnt + (size_t)nbins * BLOCK);      // [m0 + 2]
     double *red = edge + m0 + 2;                                                  // [BLOCK/64]
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
 }
 
 size_t lds_bytes(int m0, int block) {
-    return (size_t)kChunk * 16 + (size_t)(m0 + 1) * block * 12 + (size_t)(m0 + 2) * 8 + 64;
+    const size_t stage = (size_t)(kChunk > block ? kChunk : block) * 16;
+    return stage + (size_t)(m0 + 1) * block * 12 + (size_t)(m0 + 2) * 8 + 64;
 }
 
 }  // namespace
