@@ -6,8 +6,9 @@
 //
 // Decomposition
 //   gls_prep_kernel   one workgroup per light curve: weights (spectral.py:99-108), YY (:120) and
-//                     one 48-byte record per sample {t - t0, w*y, w, cos(2 pi delta t'),
-//                     sin(2 pi delta t'), 2 cos(2 pi delta t')}.
+//                     one 48-byte record per sample {t - t0, sqrt(w)*y, sqrt(w), cos(2 pi delta t'),
+//                     sin(2 pi delta t'), 2 cos(2 pi delta t')} ({.., w*y, w, ..} when all weights
+//                     are equal or the caller supplies them).
 //   gls_scan_kernel   each thread owns K consecutive trial frequencies; the workgroup streams the
 //                     curve's records once through LDS (coalesced 16-byte loads, register
 //                     prefetch of the next chunk) and every lane reads each record as an LDS
@@ -111,6 +112,10 @@ __global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
         }
         double sd, cd;
         sincos_cycles(frac_product(a.delta, tp), sd, cd);
+        if (!a.raw && dy) {  // weighted scan: the kernel carries sqrt(w) sin / sqrt(w) cos
+            w = sqrt(w);
+            wy = w * (y[i] - ybar);
+        }
         double2 *r = reinterpret_cast<double2 *>(rec + i * 6);
         r[0] = make_double2(tp, wy);
         r[1] = make_double2(w, cd);
@@ -180,9 +185,10 @@ __global__ __launch_bounds__(kBlock) void gls_prep_wide_b(WidePrepArgs a) {
         wsum += w;
         double sd, cd;
         sincos_cycles(frac_product(a.p.delta, tp), sd, cd);
+        const double rw = a.p.dy ? sqrt(w) : w;  // weighted scan: sqrt(w) and sqrt(w) y
         double2 *r = reinterpret_cast<double2 *>(a.p.rec + i * 6);
-        r[0] = make_double2(tp, wy);
-        r[1] = make_double2(w, cd);
+        r[0] = make_double2(tp, a.p.dy ? rw * yc : wy);
+        r[1] = make_double2(rw, cd);
         r[2] = make_double2(sd, cd + cd);
     }
     yy = block_sum<kBlock>(yy, red);
@@ -292,6 +298,12 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
             // k = 0: one software sincos at this thread's first frequency
             double s, c;
             sincos_cycles_half(frac_product(fb, t), s, c);
+            if (MODE == MODE_FIT_MEAN || MODE == MODE_NO_MEAN) {
+                // carry u = sqrt(w) sin, v = sqrt(w) cos: rotation and recurrence are linear, and
+                // every sum becomes one fma (w = sqrt(w) here, wy = sqrt(w) y)
+                s *= w;
+                c *= w;
+            }
             double sp = 0.0, cp = 0.0;  // previous step of the recurrence
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -306,13 +318,12 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
                     SS[k] = __builtin_fma(s, s, SS[k]);
                     SC[k] = __builtin_fma(s, c, SC[k]);
                 } else if (MODE != MODE_RAW) {
-                    const double ws = w * s;
                     if (MODE == MODE_FIT_MEAN) {
-                        S[k] += ws;
+                        S[k] = __builtin_fma(w, s, S[k]);
                         C[k] = __builtin_fma(w, c, C[k]);
                     }
-                    SS[k] = __builtin_fma(ws, s, SS[k]);
-                    SC[k] = __builtin_fma(ws, c, SC[k]);
+                    SS[k] = __builtin_fma(s, s, SS[k]);
+                    SC[k] = __builtin_fma(s, c, SC[k]);
                 }
                 if (k + 1 < K) {
                     double sn, cn;
