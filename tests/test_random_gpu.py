@@ -10,15 +10,40 @@ from periodicity_amd import _cabi
 pytestmark = pytest.mark.gpu
 
 
-def assert_close_spectrum(got, want, rtol, afloor, singular_ok=0.0):
+def exact_power_and_sensitivity(t, y, err, freq, fit_mean, psd, eps=1e-13, trials=4):
+    """Long-double-sum power through the reference epilogue, and per bin the largest change of that
+    power when each of the six sums moves by ``eps`` (sums are O(1): weights add up to one)."""
+    w, yc, e = so.gls_weights(y, err, fit_mean)
+    f = np.ascontiguousarray(freq, dtype=float)
+    Sh, Ch = co.trig_sums_exact(t, w * yc, f)
+    S2, C2 = co.trig_sums_exact(t, w, 2 * f)
+    S, C = co.trig_sums_exact(t, w, f) if fit_mean else (None, None)
+    YY = np.dot(w, yc ** 2)
+    want = so.gls_epilogue(Sh, Ch, S2, C2, S, C, YY, fit_mean, psd, e)
+    rng = np.random.default_rng(0)
+    wobble = np.zeros_like(want)
+    for _ in range(trials):
+        moved = [None if a is None else a + eps * rng.choice([-1.0, 1.0], a.shape)
+                 for a in (Sh, Ch, S2, C2, S, C)]
+        other = so.gls_epilogue(*moved, YY, fit_mean, psd, e)
+        with np.errstate(invalid="ignore"):
+            wobble = np.fmax(wobble, np.abs(other - want))
+    return want, wobble
+
+
+def assert_close_spectrum(got, want, rtol, afloor, singular_ok=0.0, extra=None):
     """Bins where either side is non-finite are 0/0 singularities of the epilogue (CC or SS -> 0,
     e.g. two samples, or integer times at Nyquist); allow a fraction ``singular_ok`` of them."""
     want = np.asarray(want)
     fin = np.isfinite(want) & np.isfinite(got)
-    assert np.mean(np.isfinite(want) != np.isfinite(got)) <= singular_ok
+    mismatch = np.isfinite(want) != np.isfinite(got)
+    if extra is not None:  # a bin the oracle itself calls singular may come out as anything
+        mismatch &= np.isfinite(want) & np.isfinite(extra)
+    assert np.mean(mismatch) <= singular_ok
     if fin.any():
         scale = np.max(np.abs(want[fin]))
-        assert np.all(np.abs(got[fin] - want[fin]) <= rtol * np.abs(want[fin]) + afloor * scale)
+        slack = 0.0 if extra is None else np.nan_to_num(extra[fin], nan=np.inf)
+        assert np.all(np.abs(got[fin] - want[fin]) <= rtol * np.abs(want[fin]) + afloor * scale + slack)
 
 
 def random_curve(rng, n):
@@ -36,8 +61,8 @@ def random_curve(rng, n):
     return t, y, dy
 
 
-def test_gls_direct_random_cases():
-    rng = np.random.default_rng(2024)
+def test_gls_direct_random_cases(seed=2024):
+    rng = np.random.default_rng(seed)
     for case in range(60):
         n = int(rng.choice([3, 5, 17, 64, 255, 256, 257, 300, 513, 777]))
         t, y, dy = random_curve(rng, n)
@@ -48,14 +73,15 @@ def test_gls_direct_random_cases():
         fit_mean, psd = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         err = dy if rng.integers(0, 3) else None
         got = _cabi.gls_scan(t, y, err, f0, delta, nf, fit_mean, psd)
-        want = co.gls_power_exact(t, y, err, freq, fit_mean, psd)
-        # tiny-N spectra have genuinely singular bins (CC or SS -> 0): compare where the oracle's own
-        # conditioning allows, i.e. relative to the spectrum scale
-        assert_close_spectrum(got, want, 1e-6, 1e-9), case
+        want, wobble = exact_power_and_sensitivity(t, y, err, freq, fit_mean, psd)
+        # tiny-N / evenly sampled spectra have genuinely (near-)singular bins (CC or SS -> 0), where
+        # the epilogue amplifies rounding in the sums by 1/CC: the gate is 1e-6 relative plus what
+        # the oracle's own epilogue does with sums moved by 1e-13 (about 100 fp64 roundings)
+        assert_close_spectrum(got, want, 1e-6, 1e-9, extra=wobble), case
 
 
-def test_gls_batch_random_ragged():
-    rng = np.random.default_rng(7)
+def test_gls_batch_random_ragged(seed=7):
+    rng = np.random.default_rng(seed)
     for case in range(8):
         lens = rng.integers(1, 700, size=int(rng.integers(2, 12)))
         curves = [random_curve(rng, int(n)) for n in lens]
@@ -71,8 +97,8 @@ def test_gls_batch_random_ragged():
                 assert argmax[b] == np.nanargmax(single)
 
 
-def test_gls_fft_random_cases():
-    rng = np.random.default_rng(99)
+def test_gls_fft_random_cases(seed=99):
+    rng = np.random.default_rng(seed)
     for case in range(40):
         n = int(rng.choice([9, 30, 100, 333, 1000]))   # (2-3 samples: every bin is a 0/0 singularity)
         t, y, dy = random_curve(rng, n)
@@ -97,8 +123,8 @@ def test_gls_fft_random_cases():
         assert_close_spectrum(got, want, 1e-7, 1e-9, singular_ok=0.02), case
 
 
-def test_pdm_random_cases():
-    rng = np.random.default_rng(11)
+def test_pdm_random_cases(seed=11):
+    rng = np.random.default_rng(seed)
     for case in range(60):
         n = int(rng.choice([2, 3, 10, 100, 511, 512, 513, 1500]))
         t, y, _ = random_curve(rng, n)
@@ -115,8 +141,8 @@ def test_pdm_random_cases():
         np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=str(case))
 
 
-def test_stringlength_random_cases():
-    rng = np.random.default_rng(13)
+def test_stringlength_random_cases(seed=13):
+    rng = np.random.default_rng(seed)
     for case in range(50):
         n = int(rng.choice([1, 2, 3, 63, 64, 65, 191, 193, 1000, 4097, 6000]))
         t, y, _ = random_curve(rng, n)
