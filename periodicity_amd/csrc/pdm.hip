@@ -91,7 +91,7 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     const double q_total = block_reduce<BLOCK>(acc, red, false);
 
     constexpr int PERIODS = BLOCK / SPLIT;       // trial periods per workgroup
-    const int wave = tid >> 6, part = wave % SPLIT;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), part = wave % SPLIT;  // scalar
     const int slot = (wave / SPLIT) * 64 + (tid & 63);  // period slot inside the workgroup
     const int64_t pidx = (int64_t)blockIdx.x * PERIODS + slot;
     const double period = pidx < a.n_periods ? a.periods[pidx] : 1.0;
@@ -114,50 +114,56 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         __syncthreads();
         const int cnt = (int)((a.n - base) < kChunk ? (a.n - base) : kChunk);
         const int i_end = cnt < (part + 1) * (kChunk / SPLIT) ? cnt : (part + 1) * (kChunk / SPLIT);
-        // two samples per trip: two independent read -> bin -> atomic chains in flight per wave
-        auto bin_of = [&](const double2 tx, int &k) -> bool {
-            const double q = tx.x * rp;
-            const double fr = q - __builtin_floor(q);
-            const double u = fr * dm0;
+        // two samples per trip: two independent read -> bin -> atomic chains in flight per wave.
+        // Fast path: 7 VALU ops (v_fract_f64 twice); the histogram update is unconditional.
+        auto fast_bin = [&](const double t, int &k) -> bool {
+            const double u = __builtin_amdgcn_fract(t * rp) * dm0;
             k = (int)u;
-            const double g = u - (double)k;
-            if (__builtin_fabs(g - 0.5) < thr) return true;
-            // exact path: numpy's float remainder of the IEEE quotient, explicit edges
+            return __builtin_fabs(__builtin_amdgcn_fract(u) - 0.5) < thr;
+        };
+        // exact path: numpy's float remainder of the IEEE quotient, explicit edges; a NaN phase
+        // belongs to no bin (adds zero to bin 0)
+        auto exact_bin = [&](const double2 tx, int &k, double &val, unsigned &inc) {
             const double qe = tx.x / period;
             const double phi = qe - __builtin_floor(qe);  // == fmod-based Python % for divisor 1
-            if (phi != phi) {                             // NaN phase belongs to no bin
+            if (phi != phi) {
                 q_nan += tx.y * tx.y;
-                return false;
+                k = 0;
+                val = 0.0;
+                inc = 0u;
+                return;
             }
             k = (int)(phi * dm0);
             k = k < 0 ? 0 : (k > m0 ? m0 : k);
             while (k > 0 && phi < edge[k]) --k;
             while (k < m0 && phi >= edge[k + 1]) ++k;
             if (k == m0) q_over += tx.y * tx.y;
-            return true;
+        };
+        auto add = [&](const int k, const double val, const unsigned inc) {
+            atomicAdd(&hsum[k * BLOCK + tid], val);
+            atomicAdd(&hcnt[k * BLOCK + tid], inc);
+        };
+        auto update = [&](const double2 tx) {
+            int k;
+            double val = tx.y;
+            unsigned inc = 1u;
+            if (!fast_bin(tx.x, k)) exact_bin(tx, k, val, inc);
+            add(k, val, inc);
         };
         int i = part * (kChunk / SPLIT);
         for (; i + 1 < i_end; i += 2) {
+            // both fast bins first: two independent dependency chains back to back
             const double2 ta = stage[i], tb = stage[i + 1];
             int ka, kb;
-            const bool oa = bin_of(ta, ka), ob = bin_of(tb, kb);
-            if (oa) {
-                atomicAdd(&hsum[ka * BLOCK + tid], ta.y);
-                atomicAdd(&hcnt[ka * BLOCK + tid], 1u);
-            }
-            if (ob) {
-                atomicAdd(&hsum[kb * BLOCK + tid], tb.y);
-                atomicAdd(&hcnt[kb * BLOCK + tid], 1u);
-            }
+            double va = ta.y, vb = tb.y;
+            unsigned ia = 1u, ib = 1u;
+            const bool fa = fast_bin(ta.x, ka), fb = fast_bin(tb.x, kb);
+            if (!fa) exact_bin(ta, ka, va, ia);
+            add(ka, va, ia);
+            if (!fb) exact_bin(tb, kb, vb, ib);
+            add(kb, vb, ib);
         }
-        if (i < i_end) {
-            const double2 ta = stage[i];
-            int ka;
-            if (bin_of(ta, ka)) {
-                atomicAdd(&hsum[ka * BLOCK + tid], ta.y);
-                atomicAdd(&hcnt[ka * BLOCK + tid], 1u);
-            }
-        }
+        for (; i < i_end; ++i) update(stage[i]);
     }
 
     if (SPLIT > 1) {
