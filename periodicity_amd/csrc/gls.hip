@@ -64,6 +64,10 @@ struct PrepArgs {
     int shared_t, fit_mean, raw;
     double delta;
     double *rec, *scal;
+    // shared-time-axis batches (gls_shared_kernel): weights transposed to [sample][curve]
+    double *rw = nullptr;   // {w (y - ybar), w} pairs, or w (y - ybar) alone when all weights are equal
+    double *tp = nullptr;   // [n] t - t0
+    int64_t bpad = 0;
 };
 
 // ---- prologue: spectral.py:99-108, 120 ------------------------------------------------------------
@@ -96,6 +100,20 @@ __global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
         }
     }
     double yy = 0.0, wsum = 0.0;
+    if (a.rw) {
+        // shared time axis: no per-curve records, only this curve's column of the weight table
+        for (int64_t i = tid; i < n; i += kPrepBlock) {
+            const double e = dy ? dy[i] : 1.0;
+            const double w = (1.0 / (e * e)) / W;
+            const double yc = y[i] - ybar;
+            const double wy = w * yc;
+            yy += wy * yc;
+            wsum += w;
+            if (dy) reinterpret_cast<double2 *>(a.rw)[i * a.bpad + blockIdx.x] = make_double2(wy, w);
+            else a.rw[i * a.bpad + blockIdx.x] = wy;
+            if (blockIdx.x == 0) a.tp[i] = t[i] - t0;
+        }
+    } else
     for (int64_t i = tid; i < n; i += kPrepBlock) {
         const double tp = t[i] - t0;
         double w, wy;
@@ -443,6 +461,181 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     }
 }
 
+// ---- batches on ONE time axis (GLS.bootstrap's shape, spectral.py:140-152) -----------------------------
+// sin/cos of a (frequency, sample) pair are the same for every curve of the batch, so they are
+// computed once per workgroup and shared: lanes own 64 consecutive frequencies; the workgroup's 16
+// waves first fill an LDS tile {s, c, s^2, s c}[sample][lane] for 32 samples (2 samples per wave,
+// direct sincos, no recurrence), then each wave accumulates ITS group of RT curves against the
+// tile.  A curve's per-sample weights are wave-uniform, so they arrive through the scalar cache
+// (s_load from the [sample][curve] table) and feed v_fma_f64 as SGPR operands: 6 fma per (pair,
+// curve) - 2 when all weights are equal, where the four weight-only sums are shared too - against
+// ~10.5 instructions per pair in gls_scan_kernel.  (v_mfma_f64_16x16x4 would take 64 cycles for the
+// 128 pair-curves it can hold with 6 of 8 outputs useful; the 96 v_fma_f64 it replaces take 48.)
+constexpr int kShBlock = 1024;
+constexpr int kShWaves = kShBlock / 64;
+constexpr int kShChunk = 32;
+constexpr int kShCurvesW = 8;   // curves per wave, individual weights (48 accumulators)
+constexpr int kShCurvesU = 16;  // curves per wave, equal weights (32 + 4 accumulators)
+
+struct SharedArgs {
+    const double *tp;    // [n] t - t0
+    const double *rw;    // [n][bpad] {w (y - ybar), w}, or [n][bpad] w (y - ybar) for equal weights
+    const double *scal;  // [n_curves][4] = {YY, sum w, sum err^-2, t0}
+    int64_t n, n_curves, bpad, tiles, groups;
+    double f0, delta;
+    int64_t j_begin, nf;
+    int psd;
+    double *power;
+    double *blk_max;  // [n_curves][tiles] or nullptr
+    int64_t *blk_arg;
+};
+
+using w8 = double __attribute__((ext_vector_type(8)));
+using cw8 = __attribute__((address_space(4))) w8;
+
+template <bool FIT_MEAN, bool UNI>
+__global__ __launch_bounds__(kShBlock) void gls_shared_kernel(SharedArgs a) {
+    constexpr int RT = UNI ? kShCurvesU : kShCurvesW;
+    constexpr int NW = UNI ? 1 : RT;  // sets of weight-only sums
+    constexpr int MODE = FIT_MEAN ? (UNI ? MODE_FIT_MEAN_U : MODE_FIT_MEAN)
+                                  : (UNI ? MODE_NO_MEAN_U : MODE_NO_MEAN);
+    __shared__ double2 trig_sc[kShChunk + 2][64];  // {sin, cos}; + rows for the read-ahead
+    __shared__ double2 trig_qq[kShChunk + 2][64];  // {sin^2, sin cos}
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // consecutive logical workgroups of one XCD share a curve group: its weight table stays in L2
+    const int64_t G = a.groups * a.tiles;
+    const int64_t per_xcd = (G + 7) / 8;
+    const int64_t L = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (L >= G) return;
+    const int64_t group = L / a.tiles, tile = L - group * a.tiles;
+    const int64_t j = tile * 64 + lane;
+    const double f = __dadd_rn(a.f0, __dmul_rn((double)(a.j_begin + j), a.delta));  // numpy arange
+    const int64_t r0 = (group * kShWaves + wave) * RT;  // first curve of this wave
+
+    double Sh[RT], Ch[RT], S[NW], C[NW], SS[NW], SC[NW];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) Sh[r] = Ch[r] = 0.0;
+#pragma unroll
+    for (int r = 0; r < NW; ++r) S[r] = C[r] = SS[r] = SC[r] = 0.0;
+
+    for (int64_t base = 0; base < a.n; base += kShChunk) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kShChunk / kShWaves; ++q) {
+            const int il = wave * (kShChunk / kShWaves) + q;
+            const int64_t i = base + il;
+            const double t = i < a.n ? a.tp[i] : 0.0;
+            double s, c;
+            sincos_cycles_half(frac_product(f, t), s, c);
+            if (i >= a.n) s = c = 0.0;  // padding rows contribute nothing
+            trig_sc[il][lane] = make_double2(s, c);
+            trig_qq[il][lane] = make_double2(s * s, s * c);
+        }
+        __syncthreads();
+        const int cnt = (int)((a.n - base) < kShChunk ? (a.n - base) : kShChunk);
+        // Software pipeline: scalar loads return out of order, so waiting for one waits for all.
+        // Per sample the wave needs two 64-byte blocks of weights (4 + 4 curves, or 8 + 8 with
+        // equal weights) and one LDS tile row; those of sample il+1 are requested right after the
+        // wait for sample il's and before its fmas.  Two samples per trip so that the two register
+        // sets swap roles without copies; an odd chunk runs one padding sample (zero tile row, zero
+        // weights: the table carries two zeroed rows after the last sample).
+        const cw8 *wrow = reinterpret_cast<const cw8 *>(
+            reinterpret_cast<uintptr_t>(a.rw + ((base * a.bpad + r0) * (UNI ? 1 : 2))));
+        const int64_t wstride = a.bpad * (UNI ? 1 : 2) / 8;  // w8 per sample row
+        auto accumulate = [&](const w8 &b0, const w8 &b1, const double2 sc, const double2 qq) {
+            if (UNI) {
+                if (FIT_MEAN) {
+                    S[0] += sc.x;
+                    C[0] += sc.y;
+                }
+                SS[0] += qq.x;
+                SC[0] += qq.y;
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const double wy = r < 8 ? b0[r & 7] : b1[r & 7];
+                    Sh[r] = __builtin_fma(wy, sc.x, Sh[r]);
+                    Ch[r] = __builtin_fma(wy, sc.y, Ch[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const double wy = r < 4 ? b0[2 * (r & 3)] : b1[2 * (r & 3)];
+                    const double w = r < 4 ? b0[2 * (r & 3) + 1] : b1[2 * (r & 3) + 1];
+                    Sh[r] = __builtin_fma(wy, sc.x, Sh[r]);
+                    Ch[r] = __builtin_fma(wy, sc.y, Ch[r]);
+                    if (FIT_MEAN) {
+                        S[r] = __builtin_fma(w, sc.x, S[r]);
+                        C[r] = __builtin_fma(w, sc.y, C[r]);
+                    }
+                    SS[r] = __builtin_fma(w, qq.x, SS[r]);
+                    SC[r] = __builtin_fma(w, qq.y, SC[r]);
+                }
+            }
+        };
+        w8 a0 = wrow[0], a1 = wrow[1];
+        double2 sca = trig_sc[0][lane], qqa = trig_qq[0][lane];
+        for (int il = 0; il < cnt; il += 2) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): set A has arrived
+            const w8 b0 = wrow[wstride], b1 = wrow[wstride + 1];
+            const double2 scb = trig_sc[il + 1][lane], qqb = trig_qq[il + 1][lane];
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(a0, a1, sca, qqa);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // set B has arrived
+            a0 = wrow[2 * wstride];
+            a1 = wrow[2 * wstride + 1];
+            sca = trig_sc[il + 2][lane];
+            qqa = trig_qq[il + 2][lane];
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(b0, b1, scb, qqb);
+            __builtin_amdgcn_sched_barrier(0);
+            wrow += 2 * wstride;
+        }
+    }
+
+    const bool valid = j < a.nf;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int64_t b = r0 + r;
+        if (b >= a.n_curves) break;  // wave-uniform
+        const double *sc = a.scal + b * 4;
+        const double YY = sc[0], Wsum = sc[1], Werr = sc[2];
+        double s1 = S[UNI ? 0 : r], c1 = C[UNI ? 0 : r], ss = SS[UNI ? 0 : r], sc2 = SC[UNI ? 0 : r];
+        if (UNI) {  // w = (1/1)/W for every sample
+            const double w0 = 1.0 / Werr;
+            s1 *= w0;
+            c1 *= w0;
+            ss *= w0;
+            sc2 *= w0;
+        }
+        const double p = gls_power<MODE>(Sh[r], Ch[r], s1, c1, ss, sc2, YY, Wsum, Werr, a.psd);
+        if (valid && a.power) a.power[b * a.nf + j] = p;
+        if (a.blk_max) {
+            double best = 0.0;
+            long long best_j = -1;
+            if (valid && p == p) {
+                best = p;
+                best_j = j;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = __shfl_down(best, o, 64);
+                const long long oj = __shfl_down(best_j, o, 64);
+                if (oj >= 0 && (best_j < 0 || ov > best || (ov == best && oj < best_j))) {
+                    best = ov;
+                    best_j = oj;
+                }
+            }
+            if (lane == 0) {
+                a.blk_max[b * a.tiles + tile] = best;
+                a.blk_arg[b * a.tiles + tile] = best_j;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void gls_peak_kernel(const double *blk_max, const int64_t *blk_arg,
                                                       int64_t tiles, double *amax, int64_t *argmax) {
     const int64_t curve = blockIdx.x;
@@ -525,7 +718,7 @@ struct WorkLayout {
 
 WorkLayout layout(int64_t n_total, int64_t n_curves, int64_t nf) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
-    const int64_t tiles_max = (nf + 64 * 4 - 1) / (64 * 4);  // smallest tile: K = 4, S = 4
+    const int64_t tiles_max = (nf + 63) / 64;  // smallest tile: gls_shared_kernel, 64 frequencies
     WorkLayout w;
     w.rec = 0;
     w.scal = up(n_total * 48);
@@ -565,6 +758,61 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     p.delta = delta;
     p.rec = reinterpret_cast<double *>(base + w.rec);
     p.scal = reinterpret_cast<double *>(base + w.scal);
+    const bool peaks = d_amax || d_argmax;
+
+    // Batches on one time axis: share the trigonometry between curves (gls_shared_kernel) when
+    // enough curves fill its curve groups and the [sample][curve] table fits the record area.
+    // PDC_GLS_SHARED=0/1 forces the choice (tests).
+    static const int env_shared = [] { const char *e = getenv("PDC_GLS_SHARED"); return e ? atoi(e) : -1; }();
+    if (shared_t && mode != MODE_RAW && n_curves >= 2 && env_shared != 0) {
+        const bool uni = d_dy == nullptr;
+        const int64_t n = n_total / n_curves;
+        const int64_t group = (int64_t)kShWaves * (uni ? kShCurvesU : kShCurvesW);
+        const int64_t bpad = (n_curves + group - 1) / group * group;
+        const int64_t table = (n + 2) * bpad * (uni ? 8 : 16);  // + two rows: the kernel reads ahead
+        if ((n_curves >= 96 || env_shared == 1) && table + n * 8 <= w.scal && n * n_curves == n_total) {
+            p.rw = p.rec;
+            p.tp = reinterpret_cast<double *>(base + table);
+            p.bpad = bpad;
+            PDC_HIP(hipMemsetAsync(base + table / (n + 2) * n, 0, table / (n + 2) * 2, st));
+            hipLaunchKernelGGL(gls_prep_kernel, dim3((unsigned)n_curves), dim3(kPrepBlock), 0, st, p);
+            PDC_HIP(hipGetLastError());
+            SharedArgs sa;
+            sa.tp = p.tp;
+            sa.rw = p.rw;
+            sa.scal = p.scal;
+            sa.n = n;
+            sa.n_curves = n_curves;
+            sa.bpad = bpad;
+            sa.tiles = (nf + 63) / 64;
+            sa.groups = bpad / group;
+            sa.f0 = f0;
+            sa.delta = delta;
+            sa.j_begin = j_begin;
+            sa.nf = nf;
+            sa.psd = psd;
+            sa.power = d_power;
+            sa.blk_max = peaks ? reinterpret_cast<double *>(base + w.blk_max) : nullptr;
+            sa.blk_arg = peaks ? reinterpret_cast<int64_t *>(base + w.blk_arg) : nullptr;
+            const int64_t G = sa.groups * sa.tiles;
+            PDC_REQUIRE(G < (int64_t)1 << 31, "gls: grid too large");
+            const dim3 grid((unsigned)(((G + 7) / 8) * 8));
+            if (mode == MODE_FIT_MEAN) {
+                if (uni) hipLaunchKernelGGL((gls_shared_kernel<true, true>), grid, dim3(kShBlock), 0, st, sa);
+                else hipLaunchKernelGGL((gls_shared_kernel<true, false>), grid, dim3(kShBlock), 0, st, sa);
+            } else {
+                if (uni) hipLaunchKernelGGL((gls_shared_kernel<false, true>), grid, dim3(kShBlock), 0, st, sa);
+                else hipLaunchKernelGGL((gls_shared_kernel<false, false>), grid, dim3(kShBlock), 0, st, sa);
+            }
+            PDC_HIP(hipGetLastError());
+            if (peaks) {
+                hipLaunchKernelGGL(gls_peak_kernel, dim3((unsigned)n_curves), dim3(64), 0, st, sa.blk_max,
+                                   sa.blk_arg, sa.tiles, d_amax, d_argmax);
+                PDC_HIP(hipGetLastError());
+            }
+            return PDC_OK;
+        }
+    }
     if (n_curves == 1 && mode != MODE_RAW && n_total >= 16384) {
         WidePrepArgs wp;
         wp.p = p;
@@ -597,7 +845,6 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     a.power = d_power;
     a.raw_s = d_raw_s;
     a.raw_c = d_raw_c;
-    const bool peaks = d_amax || d_argmax;
     a.blk_max = peaks ? reinterpret_cast<double *>(base + w.blk_max) : nullptr;
     a.blk_arg = peaks ? reinterpret_cast<int64_t *>(base + w.blk_arg) : nullptr;
     const int64_t G = a.n_curves * a.tiles;

@@ -132,16 +132,19 @@ class GLS(object):
             picks[i] = rng.integers(0, ndata, ndata)
         offsets = np.arange(n_bootstraps + 1, dtype=np.int64) * ndata
         bs_replicates = np.empty(n_bootstraps)
+        # err=None upstream means all-ones errors (``spectral.py:99-100``): resampling leaves them
+        # all ones, and the equal-weights kernels share the weight-only sums between replicates
+        resampled_err = None if np.all(err == 1.0) else err[picks].ravel()
         if n_bootstraps and self.method == "fft":
             # all replicates through the reference's own algorithm in one batched set of launches
             df, fmin, _ = self._grid_scalars(self.signal)
             _, amax, _ = _cabi.gls_scan_fft_batch(
-                t, values[picks].ravel(), err[picks].ravel(), offsets, fmin, df, nf, True, self.psd,
+                t, values[picks].ravel(), resampled_err, offsets, fmin, df, nf, True, self.psd,
                 shared_t=True, want_power=False, want_peaks=True, device=self.device)
             bs_replicates[:] = amax
         elif n_bootstraps:
             _, amax, _ = _cabi.gls_scan_batch(
-                t, values[picks].ravel(), err[picks].ravel(), offsets, f0, delta, nf, True,
+                t, values[picks].ravel(), resampled_err, offsets, f0, delta, nf, True,
                 self.psd, shared_t=True, want_power=False, want_peaks=True, device=self.device)
             bs_replicates[:] = amax
         self.bs_replicates = bs_replicates

@@ -182,6 +182,37 @@ def test_shared_time_axis_batch():
         assert np.array_equal(single, power[b])
 
 
+@pytest.mark.parametrize("with_dy,fit_mean,psd", [(True, True, False), (True, False, True),
+                                                  (False, True, False), (False, False, True)])
+def test_shared_time_axis_many_curves_share_the_trigonometry(with_dy, fit_mean, psd):
+    """>= 96 curves on one time axis run through gls_shared_kernel (sin/cos computed once per
+    workgroup, per-curve weights from the scalar cache): rows agree with per-curve calls to
+    rounding and with the long-double sums to Tier E; odd sample counts exercise the padding row."""
+    rng = np.random.default_rng(11)
+    B, n, nf = 131, 257, 700
+    t = np.sort(rng.uniform(0, 40, n))
+    y = np.sin(2 * np.pi * t / 3.3)[None, :] + rng.standard_normal((B, n))
+    dy = rng.uniform(0.1, 0.5, (B, n)) if with_dy else None
+    offsets = np.arange(B + 1) * n
+    f0, delta = 0.01, 0.0021
+    freq = f0 + delta * np.arange(nf)
+    power, amax, argmax = _cabi.gls_scan_batch(t, y.ravel(), None if dy is None else dy.ravel(),
+                                               offsets, f0, delta, nf, fit_mean, psd, shared_t=True,
+                                               want_peaks=True)
+    for b in range(B):
+        single = _cabi.gls_scan(t, y[b], None if dy is None else dy[b], f0, delta, nf, fit_mean, psd)
+        np.testing.assert_allclose(power[b], single, rtol=1e-10, atol=1e-13 * np.max(single))
+        assert argmax[b] == np.nanargmax(power[b]) and amax[b] == np.nanmax(power[b])
+    for b in (0, 77, B - 1):
+        exact = co.gls_power_exact(t, y[b], None if dy is None else dy[b], freq, fit_mean, psd)
+        assert_tier_e(power[b], exact)
+    # peaks-only mode (what GLS.bootstrap asks for) gives the same maxima
+    _, amax2, argmax2 = _cabi.gls_scan_batch(t, y.ravel(), None if dy is None else dy.ravel(), offsets,
+                                             f0, delta, nf, fit_mean, psd, shared_t=True,
+                                             want_power=False, want_peaks=True)
+    assert np.array_equal(amax, amax2) and np.array_equal(argmax, argmax2)
+
+
 def test_slabs_tile_the_grid_bitwise():
     t, y, dy = synth(3000, 21)
     freq = np.arange(0.0001, 0.9, 0.00011)

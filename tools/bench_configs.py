@@ -127,7 +127,7 @@ def main():
                         "work_MiB": round(wb / 2**20, 1)})
             for b in (bt, by, bdy, work, power):
                 b.free()
-    if only & {"c3", "c3peaks", "c3shared"}:
+    if only & {"c3", "c3peaks", "c3shared", "c3sharednoerr"}:
         B, n, nf = 4096, 2000, 50_000
         rng = np.random.default_rng(20241008 + 3)
         ts, ys, dys = [], [], []
@@ -147,6 +147,8 @@ def main():
             out.append(run_gls(tm, "C3 GLS batch 4096 x 2k x 5e4 (power out)", t, y, dy, offsets, B, *gp, args.reps))
         if "c3peaks" in only:
             out.append(run_gls(tm, "C3 GLS batch (amax/argmax only)", t, y, dy, offsets, B, *gp, args.reps, peaks_only=True))
+        if "c3sharednoerr" in only:
+            out.append(run_gls(tm, "C3 GLS batch shared t, err=None (bootstrap of an unweighted fit, peaks only)", ts[0], y, None, offsets, B, *gp, args.reps, shared_t=1, peaks_only=True))
         if "c3shared" in only:
             out.append(run_gls(tm, "C3 GLS batch shared t (bootstrap shape, peaks only)", ts[0], y, dy, offsets, B, *gp, args.reps, shared_t=1, peaks_only=True))
     if only & {"c5pdm", "c5sl"}:
