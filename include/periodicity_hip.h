@@ -162,6 +162,13 @@ int pdc_pdm_scan_dev(int device, void *stream, const double *d_t, const double *
                      const double *d_periods, int64_t n_periods, int nb, int nc, double sigma,
                      double *d_theta);
 
+/* The period grid cut into contiguous slabs over `n_devices` GPUs of this node (one process, one
+ * stream per slab; a device may be listed more than once).  Replaces the multiprocessing.Pool
+ * fan-out of phase.py:182-186; trial periods are independent, so there is no exchange step. */
+int pdc_pdm_scan_multi(const double *t, const double *x, int64_t n,
+                       const double *periods, int64_t n_periods, int nb, int nc, double sigma,
+                       double *theta_out, const int *devices, int n_devices);
+
 /* ---- String Length -----------------------------------------------------------------------------
  * Replaces pool.map(StringLength._stringlength, periods) (phase.py:45-51, 69-70) including the
  * fold ((t - 0)/period) % 1 (core.py:543-544) and the stable sort by phase of the TSeries
@@ -174,6 +181,11 @@ int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods);
 int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
                               int64_t n, const double *d_periods, int64_t n_periods,
                               double *d_ell, void *work, int64_t work_bytes);
+
+/* As pdc_pdm_scan_multi, for phase.py:69-70. */
+int pdc_stringlength_scan_multi(const double *t, const double *m, int64_t n,
+                                const double *periods, int64_t n_periods,
+                                double *ell_out, const int *devices, int n_devices);
 
 #ifdef __cplusplus
 }

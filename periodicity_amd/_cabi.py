@@ -61,6 +61,8 @@ PROTOTYPES = {
     "pdc_stringlength_scan": (_I, [_VP, _VP, _L, _VP, _L, _VP, _I]),
     "pdc_stringlength_work_bytes": (_L, [_L, _L]),
     "pdc_stringlength_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _VP, _VP, _L]),
+    "pdc_pdm_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _I, _I, _D, _VP, _VP, _I]),
+    "pdc_stringlength_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _VP, _VP, _I]),
 }
 
 
@@ -268,22 +270,40 @@ def gls_batch_highest_peak(t, y, dy, offsets, f0, delta, nf, fit_mean=True, psd=
     return idx, val
 
 
-def pdm_scan(t, x, periods, nb, nc, sigma, device=None):
+def pdm_scan(t, x, periods, nb, nc, sigma, device=None, devices=None):
+    """theta at every trial period; ``devices`` (a sequence of GPU ordinals) cuts the period grid
+    into one contiguous slab per entry (``pdc_pdm_scan_multi``)."""
     t, x, periods = _f64(t, "t"), _f64(x, "x"), _f64(periods, "periods")
     if x.size != t.size:
         raise ValueError("Input arrays have incompatible lengths.")
     out = np.empty(periods.size, dtype=np.float64)
+    if devices is not None and len(devices) > 1:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        check(lib().pdc_pdm_scan_multi(_ptr(t), _ptr(x), t.size, _ptr(periods), periods.size, int(nb),
+                                       int(nc), float(sigma), _ptr(out), _ptr(devs), devs.size))
+        return out
+    if devices is not None and device is None:
+        device = devices[0]
     dev = default_device() if device is None else device
     check(lib().pdc_pdm_scan(_ptr(t), _ptr(x), t.size, _ptr(periods), periods.size, int(nb),
                              int(nc), float(sigma), _ptr(out), dev))
     return out
 
 
-def stringlength_scan(t, m, periods, device=None):
+def stringlength_scan(t, m, periods, device=None, devices=None):
+    """String length at every trial period; ``devices`` as in :func:`pdm_scan`
+    (``pdc_stringlength_scan_multi``)."""
     t, m, periods = _f64(t, "t"), _f64(m, "m"), _f64(periods, "periods")
     if m.size != t.size:
         raise ValueError("Input arrays have incompatible lengths.")
     out = np.empty(periods.size, dtype=np.float64)
+    if devices is not None and len(devices) > 1:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        check(lib().pdc_stringlength_scan_multi(_ptr(t), _ptr(m), t.size, _ptr(periods), periods.size,
+                                                _ptr(out), _ptr(devs), devs.size))
+        return out
+    if devices is not None and device is None:
+        device = devices[0]
     dev = default_device() if device is None else device
     check(lib().pdc_stringlength_scan(_ptr(t), _ptr(m), t.size, _ptr(periods), periods.size,
                                       _ptr(out), dev))

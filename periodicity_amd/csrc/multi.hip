@@ -125,3 +125,92 @@ extern "C" int pdc_gls_scan_multi(const double *t, const double *y, const double
     free_all(pd, devices);
     return rc;
 }
+
+// ---- phase scans over several GPUs ------------------------------------------------------------------
+// The trial-period grid is cut into contiguous slabs, one per listed device (a device may be listed
+// more than once: its slabs then run on separate streams); samples are replicated, every slab comes
+// back with its own D2H copy, and there is no exchange step at all.
+namespace {
+
+struct PhaseSlot {
+    void *t = nullptr, *v = nullptr, *periods = nullptr, *out = nullptr, *work = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+void free_slots(std::vector<PhaseSlot> &slots, const int *devices) {
+    for (size_t d = 0; d < slots.size(); ++d) {
+        if (hipSetDevice(devices[d]) != hipSuccess) continue;
+        if (slots[d].stream) (void)hipStreamDestroy(slots[d].stream);
+        for (void *p : {slots[d].t, slots[d].v, slots[d].periods, slots[d].out, slots[d].work})
+            if (p) (void)hipFree(p);
+    }
+}
+
+// kind 0 = PDM (v = x), 1 = StringLength (v = m)
+int phase_multi(int kind, const double *t, const double *v, int64_t n, const double *periods,
+                int64_t n_periods, int nb, int nc, double sigma, double *out, const int *devices,
+                int n_devices, std::vector<PhaseSlot> &slots) {
+    const int64_t slab = (n_periods + n_devices - 1) / n_devices;
+    for (int d = 0; d < n_devices; ++d) {
+        const int64_t p0 = (int64_t)d * slab;
+        const int64_t cnt = p0 >= n_periods ? 0 : (n_periods - p0 < slab ? n_periods - p0 : slab);
+        if (cnt == 0) continue;
+        PDC_TRY(use_device(devices[d]));
+        PhaseSlot &s = slots[d];
+        PDC_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        PDC_HIP(hipMalloc(&s.t, (size_t)(n * 8 + 8)));
+        PDC_HIP(hipMalloc(&s.v, (size_t)(n * 8 + 8)));
+        PDC_HIP(hipMalloc(&s.periods, (size_t)(cnt * 8)));
+        PDC_HIP(hipMalloc(&s.out, (size_t)(cnt * 8)));
+        PDC_HIP(hipMemcpyAsync(s.t, t, n * 8, hipMemcpyHostToDevice, s.stream));
+        PDC_HIP(hipMemcpyAsync(s.v, v, n * 8, hipMemcpyHostToDevice, s.stream));
+        PDC_HIP(hipMemcpyAsync(s.periods, periods + p0, cnt * 8, hipMemcpyHostToDevice, s.stream));
+        if (kind == 0) {
+            PDC_TRY(pdc_pdm_scan_dev(devices[d], s.stream, (double *)s.t, (double *)s.v, n,
+                                     (double *)s.periods, cnt, nb, nc, sigma, (double *)s.out));
+        } else {
+            const int64_t wb = pdc_stringlength_work_bytes(n, cnt);
+            PDC_REQUIRE(wb >= 0, "stringlength_multi: bad size");
+            PDC_HIP(hipMalloc(&s.work, (size_t)(wb + 8)));
+            PDC_TRY(pdc_stringlength_scan_dev(devices[d], s.stream, (double *)s.t, (double *)s.v, n,
+                                              (double *)s.periods, cnt, (double *)s.out, s.work, wb));
+        }
+        PDC_HIP(hipMemcpyAsync(out + p0, s.out, cnt * 8, hipMemcpyDeviceToHost, s.stream));
+    }
+    for (int d = 0; d < n_devices; ++d) {
+        if (!slots[d].stream) continue;
+        PDC_TRY(use_device(devices[d]));
+        PDC_HIP(hipStreamSynchronize(slots[d].stream));
+    }
+    return PDC_OK;
+}
+
+int phase_multi_entry(int kind, const char *who, const double *t, const double *v, int64_t n,
+                      const double *periods, int64_t n_periods, int nb, int nc, double sigma,
+                      double *out, const int *devices, int n_devices) {
+    PDC_REQUIRE(t && v && devices && (periods || n_periods == 0) && (out || n_periods == 0),
+                "%s: NULL argument", who);
+    PDC_REQUIRE(n >= 0 && n_periods >= 0 && n_devices >= 1 && n_devices <= 64, "%s: bad size", who);
+    if (n_periods == 0) return PDC_OK;
+    std::vector<PhaseSlot> slots(n_devices);
+    const int rc = phase_multi(kind, t, v, n, periods, n_periods, nb, nc, sigma, out, devices,
+                               n_devices, slots);
+    free_slots(slots, devices);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int pdc_pdm_scan_multi(const double *t, const double *x, int64_t n, const double *periods,
+                                  int64_t n_periods, int nb, int nc, double sigma, double *theta_out,
+                                  const int *devices, int n_devices) {
+    return phase_multi_entry(0, "pdm_multi", t, x, n, periods, n_periods, nb, nc, sigma, theta_out,
+                             devices, n_devices);
+}
+
+extern "C" int pdc_stringlength_scan_multi(const double *t, const double *m, int64_t n,
+                                           const double *periods, int64_t n_periods, double *ell_out,
+                                           const int *devices, int n_devices) {
+    return phase_multi_entry(1, "stringlength_multi", t, m, n, periods, n_periods, 0, 0, 0.0, ell_out,
+                             devices, n_devices);
+}

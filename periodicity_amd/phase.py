@@ -80,13 +80,17 @@ class StringLength(object):
         (``phase.py:41-43``) so that code reading ``.cores`` keeps working.
     device: int, keyword-only
         GPU ordinal.
+    devices: sequence of int, keyword-only
+        Several GPUs of this node: the period grid is cut into one contiguous slab per entry —
+        the GPU counterpart of upstream's ``Pool(cores)`` fan-out (``phase.py:69-70``).
     """
 
-    def __init__(self, dphi=0.1, n_periods=1000, cores=None, *, device=None):
+    def __init__(self, dphi=0.1, n_periods=1000, cores=None, *, device=None, devices=None):
         self.dphi = dphi
         self.n_periods = n_periods
         self.cores = MAX_CORES if cores is None or cores > MAX_CORES else cores
         self.device = device
+        self.devices = None if devices is None else tuple(devices)
 
     def _stringlength(self, period):
         """Length of the closed (phase, magnitude) polygon at one trial period — the seam of
@@ -108,7 +112,8 @@ class StringLength(object):
         self.m = TSeries(times, _quarter_scaled(np.asarray(signal.values, dtype=float)),
                          assume_sorted=True)
         periods = _string_periods(signal.baseline, self.dphi, self.n_periods)
-        lengths = _cabi.stringlength_scan(times, self.m.values, periods, device=self.device)
+        lengths = _cabi.stringlength_scan(times, self.m.values, periods, device=self.device,
+                                          devices=self.devices)
         self.periodogram = FSeries(1 / periods, lengths)
         return self.periodogram
 
@@ -133,10 +138,13 @@ class PDM(object):
         Stored but unused on the GPU.
     device: int, keyword-only
         GPU ordinal.
+    devices: sequence of int, keyword-only
+        Several GPUs of this node, one contiguous slab of the period grid each (upstream's
+        ``Pool(cores)``, ``phase.py:182-186``).
     """
 
     def __init__(self, nb=5, nc=2, p_min=None, p_max=None, n_periods=1000, oversample=1,
-                 do_subharmonic=False, cores=None, *, device=None):
+                 do_subharmonic=False, cores=None, *, device=None, devices=None):
         self.nb, self.nc = nb, nc
         self.p_min, self.p_max = p_min, p_max
         self.n_periods = n_periods
@@ -144,10 +152,11 @@ class PDM(object):
         self.do_subharmonic = do_subharmonic
         self.cores = cores
         self.device = device
+        self.devices = None if devices is None else tuple(devices)
 
     def _scan(self, periods):
         return _cabi.pdm_scan(self.t, self.x, periods, self.nb, self.nc, self.sigma,
-                              device=self.device)
+                              device=self.device, devices=self.devices)
 
     def _pdm(self, period):
         """Stellingwerf's theta at one trial period — the seam of ``phase.py:128-149``."""

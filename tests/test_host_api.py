@@ -94,9 +94,9 @@ def oracle_backend(monkeypatch):
     monkeypatch.setattr(_cabi, "gls_scan", gls_scan)
     monkeypatch.setattr(_cabi, "gls_scan_batch", gls_scan_batch)
     monkeypatch.setattr(_cabi, "pdm_scan",
-                        lambda t, x, p, nb, nc, sigma, device=None: so.pdm_scan(t, x, np.asarray(p), nb, nc))
+                        lambda t, x, p, nb, nc, sigma, device=None, devices=None: so.pdm_scan(t, x, np.asarray(p), nb, nc))
     monkeypatch.setattr(_cabi, "stringlength_scan",
-                        lambda t, m, p, device=None: so.stringlength_scan(t, m, np.asarray(p)))
+                        lambda t, m, p, device=None, devices=None: so.stringlength_scan(t, m, np.asarray(p)))
 
 
 def curve(n=400, seed=2):

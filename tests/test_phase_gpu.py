@@ -197,3 +197,25 @@ def test_phase_scans_full_size_c5():
     np.testing.assert_allclose(ell[pick], co.stringlength_scan(t, m, sl_periods[pick]), rtol=RTOL)
     # the closed polygon is at least twice the phase span plus twice the value span
     assert ell.min() >= 2 * (m.max() - m.min())
+
+
+def test_period_grid_sharded_over_device_slots():
+    """pdc_pdm_scan_multi / pdc_stringlength_scan_multi cut the period grid into one contiguous slab
+    per listed device (listing device 0 three times runs three slabs on three streams): results are
+    bit-identical to the single launch, including a grid shorter than the device list."""
+    rng = np.random.default_rng(8)
+    t = np.sort(rng.uniform(0, 60.0, 1500))
+    x = np.sin(2 * np.pi * t / 4.4) + 0.2 * rng.standard_normal(t.size)
+    m = (x - x.max()) / (2 * (x.max() - x.min())) + 0.25
+    for n_periods in (1000, 7, 2):
+        periods = np.linspace(0.7, 30.0, n_periods)
+        one = _cabi.pdm_scan(t, x, periods, 5, 2, np.var(x, ddof=1))
+        many = _cabi.pdm_scan(t, x, periods, 5, 2, np.var(x, ddof=1), devices=(0, 0, 0))
+        assert np.array_equal(one, many, equal_nan=True)
+        one = _cabi.stringlength_scan(t, m, periods)
+        many = _cabi.stringlength_scan(t, m, periods, devices=(0, 0, 0))
+        assert np.array_equal(one, many)
+    pdm = PDM(p_min=0.7, p_max=30.0, n_periods=300, devices=(0, 0))
+    assert np.array_equal(pdm(TSeries(t, x)).values, PDM(p_min=0.7, p_max=30.0, n_periods=300)(TSeries(t, x)).values)
+    sl = StringLength(n_periods=300, devices=(0, 0))
+    assert np.array_equal(sl(TSeries(t, x)).values, StringLength(n_periods=300)(TSeries(t, x)).values)
