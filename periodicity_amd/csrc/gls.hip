@@ -33,7 +33,7 @@ using namespace pdc;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kChunk = 256;  // samples staged in LDS per step (12 KiB)
+constexpr int kChunk = 128;  // samples staged in LDS per step (records 6 KiB + rotation tables 34 KiB)
 constexpr int kPrepBlock = 1024;
 
 // *_U: all weights equal (err=None upstream, spectral.py:99-100): the weight factors out of four of
@@ -135,9 +135,9 @@ __global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
             wy = w * (y[i] - ybar);
         }
         double2 *r = reinterpret_cast<double2 *>(rec + i * 6);
-        r[0] = make_double2(tp, wy);
-        r[1] = make_double2(w, cd);
-        r[2] = make_double2(sd, cd + cd);
+        r[0] = make_double2(wy, w);
+        r[1] = make_double2(cd, sd);
+        r[2] = make_double2(cd + cd, tp);
     }
     yy = block_sum<kPrepBlock>(yy, red);
     wsum = block_sum<kPrepBlock>(wsum, red);
@@ -205,9 +205,9 @@ __global__ __launch_bounds__(kBlock) void gls_prep_wide_b(WidePrepArgs a) {
         sincos_cycles(frac_product(a.p.delta, tp), sd, cd);
         const double rw = a.p.dy ? sqrt(w) : w;  // weighted scan: sqrt(w) and sqrt(w) y
         double2 *r = reinterpret_cast<double2 *>(a.p.rec + i * 6);
-        r[0] = make_double2(tp, a.p.dy ? rw * yc : wy);
-        r[1] = make_double2(rw, cd);
-        r[2] = make_double2(sd, cd + cd);
+        r[0] = make_double2(a.p.dy ? rw * yc : wy, rw);
+        r[1] = make_double2(cd, sd);
+        r[2] = make_double2(cd + cd, tp);
     }
     yy = block_sum<kBlock>(yy, red);
     wsum = block_sum<kBlock>(wsum, red);
@@ -248,7 +248,11 @@ __device__ __forceinline__ double gls_power(double Sh, double Ch, double S, doub
 // order before the epilogue, so results do not depend on timing.
 template <int K, int MODE, int SPLIT>
 __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(GlsArgs a) {
-    __shared__ double2 stage[kChunk * 3 + 3];  // + one record of padding for the read-ahead
+    constexpr int FT = kBlock / SPLIT;        // frequency-owning threads per workgroup
+    constexpr int COLS = FT / 64;             // 64-lane columns of the tile
+    __shared__ double2 stage[(kChunk + 1) * 3];   // records; + one of padding for the read-ahead
+    __shared__ double2 tab[kChunk + 1][16];       // per sample: {sin, cos}(8 a Theta), a < 8 | (b Theta), b < 8
+    __shared__ double2 basec[kChunk + 1][COLS];   // per sample: {sin, cos} at the first bin of each column
     __shared__ double red_v[4];
     __shared__ long long red_i[4];
     const int tid = threadIdx.x;
@@ -264,12 +268,14 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
 
     const int64_t off = a.offsets ? a.offsets[curve] : 0;
     const int64_t n = a.offsets ? a.offsets[curve + 1] - off : a.n_total;
-    constexpr int FT = kBlock / SPLIT;        // frequency-owning threads per workgroup
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), part = wave % SPLIT;
-    // first local frequency of this thread
-    const int64_t jl = (tile * FT + (wave / SPLIT) * 64 + (tid & 63)) * (int64_t)K;
+    const int col = wave / SPLIT, lane = tid & 63;
+    // first local frequency of the tile and of this thread
+    const int64_t jt = tile * FT * (int64_t)K;
+    const int64_t jl = jt + (col * 64 + lane) * (int64_t)K;
     // numpy's arange fill rule: start + i*delta, two roundings (no fma)
-    const double fb = __dadd_rn(a.f0, __dmul_rn((double)(a.j_begin + jl), a.delta));
+    const double f_tile = __dadd_rn(a.f0, __dmul_rn((double)(a.j_begin + jt), a.delta));
+    const double kdelta = (double)K * a.delta;  // spacing of the threads' first frequencies (exact)
 
     double Sh[K], Ch[K], S[K], C[K], SS[K], SC[K];
 #pragma unroll
@@ -278,50 +284,99 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     const double2 *src = reinterpret_cast<const double2 *>(a.rec + off * 6);
     const int64_t n2 = n * 3;
     const double2 zero2 = make_double2(0.0, 0.0);
-    double2 p0, p1, p2;
+    constexpr int kStage2 = kChunk * 3;  // double2 words per chunk (<= 2 per thread)
+    double2 p0, p1;
     {
         const int64_t i0 = tid;
         p0 = i0 < n2 ? src[i0] : zero2;
-        p1 = i0 + kBlock < n2 ? src[i0 + kBlock] : zero2;
-        p2 = i0 + 2 * kBlock < n2 ? src[i0 + 2 * kBlock] : zero2;
+        p1 = (tid + kBlock < kStage2 && i0 + kBlock < n2) ? src[i0 + kBlock] : zero2;
     }
+    // plane rotation of {sin, cos} pairs: angle(x) + angle(y)
+    auto rot = [](const double2 x, const double2 y) {
+        return make_double2(__builtin_fma(x.x, y.y, x.y * y.x), __builtin_fma(x.y, y.y, -(x.x * y.x)));
+    };
+    const int slot_a = lane >> 3, slot_b = 8 + (lane & 7);
     for (int64_t base = 0; base < n; base += kChunk) {
         __syncthreads();  // everyone is done with the previous chunk
         stage[tid] = p0;
-        stage[tid + kBlock] = p1;
-        stage[tid + 2 * kBlock] = p2;
+        if (tid + kBlock < kStage2) stage[tid + kBlock] = p1;
         __syncthreads();
         if (base + kChunk < n) {  // prefetch the next chunk while this one is consumed
             const int64_t i0 = (base + kChunk) * 3 + tid;
             p0 = i0 < n2 ? src[i0] : zero2;
-            p1 = i0 + kBlock < n2 ? src[i0 + kBlock] : zero2;
-            p2 = i0 + 2 * kBlock < n2 ? src[i0 + 2 * kBlock] : zero2;
+            p1 = (tid + kBlock < kStage2 && i0 + kBlock < n2) ? src[i0 + kBlock] : zero2;
         }
+        // ---- per-sample rotation tables (two threads per sample) ------------------------------------
+        // Thread (col, lane) starts at phase theta_tile + (64 col + 8 a + b) Theta with a = lane / 8,
+        // b = lane % 8 and Theta = 2 pi K delta t': its seed is two plane rotations of the column's
+        // base instead of a sincos.  Tables come from two direct sincos (Theta, 8 Theta) and
+        // rotation chains of length 7; the base (scaled by sqrt(w) where the sums want it) from one.
+        {
+            const int il = tid >> 1;
+            const double2 r0 = stage[il * 3], r2 = stage[il * 3 + 2];
+            const double tp = r2.y;
+            double2 step1, chain;  // the thread's unit angle and its running multiple
+            double2 first;         // role 0: base of column 0; role 1: 64 Theta
+            if ((tid & 1) == 0) {
+                sincos_cycles(frac_product(kdelta, tp), step1.x, step1.y);
+            } else {
+                sincos_cycles(frac_product(8.0 * kdelta, tp), step1.x, step1.y);
+            }
+            const int row0 = (tid & 1) ? 0 : 8;
+            tab[il][row0] = make_double2(0.0, 1.0);
+            tab[il][row0 + 1] = step1;
+            chain = step1;
+#pragma unroll
+            for (int q = 2; q < 8; ++q) {
+                chain = rot(chain, step1);
+                tab[il][row0 + q] = chain;
+            }
+            if ((tid & 1) == 0) {
+                sincos_cycles(frac_product(f_tile, tp), first.x, first.y);
+                if (MODE == MODE_FIT_MEAN || MODE == MODE_NO_MEAN) {
+                    // carry u = sqrt(w) sin, v = sqrt(w) cos: rotations and the recurrence are linear,
+                    // and every sum becomes one fma (the record holds sqrt(w) and sqrt(w) y)
+                    first.x *= r0.y;
+                    first.y *= r0.y;
+                }
+            } else {
+                first = rot(chain, step1);  // 64 Theta
+            }
+            // role 1 builds the column bases: it needs role 0's base (neighbouring lane)
+            double2 b0;
+            b0.x = __shfl_xor(first.x, 1, 64);
+            b0.y = __shfl_xor(first.y, 1, 64);
+            if (tid & 1) {
+                basec[il][0] = b0;
+#pragma unroll
+                for (int q = 1; q < COLS; ++q) {
+                    b0 = rot(b0, first);
+                    basec[il][q] = b0;
+                }
+            }
+        }
+        __syncthreads();
         const int cnt = (int)((n - base) < kChunk ? (n - base) : kChunk);
         const double *recs = reinterpret_cast<const double *>(stage);
         const int i_end = cnt < (part + 1) * (kChunk / SPLIT) ? cnt : (part + 1) * (kChunk / SPLIT);
-        // software pipeline: the record of sample i+1 is read from LDS while sample i is processed
-        // (the stage buffer is padded by one record so the last read needs no branch)
+        // software pipeline: everything sample i+1 needs is read from LDS while sample i is processed
+        // (the buffers are padded by one row so the last read-ahead needs no branch)
         const int i_beg = part * (kChunk / SPLIT);
-        // {t, wy} and {w, cos} are read ahead; {sin, 2cos} is only needed after the seed sincos, whose
-        // ~130 cycles cover its latency, so it is read in place (keeps the K = 16 tile at 256 VGPRs)
+        double2 qb = basec[i_beg][col], qa = tab[i_beg][slot_a], qt = tab[i_beg][slot_b];
         double2 q0 = *reinterpret_cast<const double2 *>(recs + i_beg * 6);
         double2 q1 = *reinterpret_cast<const double2 *>(recs + i_beg * 6 + 2);
         for (int i = i_beg; i < i_end; ++i) {
             const double2 r0 = q0, r1 = q1;
-            const double2 r2 = *reinterpret_cast<const double2 *>(recs + i * 6 + 4);
+            const double2 x1 = rot(qb, qa);
+            const double2 x2 = rot(x1, qt);
+            const double cd2 = recs[i * 6 + 4];
+            qb = basec[i + 1][col];
+            qa = tab[i + 1][slot_a];
+            qt = tab[i + 1][slot_b];
             q0 = *reinterpret_cast<const double2 *>(recs + (i + 1) * 6);
             q1 = *reinterpret_cast<const double2 *>(recs + (i + 1) * 6 + 2);
-            const double t = r0.x, wy = r0.y, w = r1.x, cd = r1.y, sd = r2.x, cd2 = r2.y;
-            // k = 0: one software sincos at this thread's first frequency
-            double s, c;
-            sincos_cycles_half(frac_product(fb, t), s, c);
-            if (MODE == MODE_FIT_MEAN || MODE == MODE_NO_MEAN) {
-                // carry u = sqrt(w) sin, v = sqrt(w) cos: rotation and recurrence are linear, and
-                // every sum becomes one fma (w = sqrt(w) here, wy = sqrt(w) y)
-                s *= w;
-                c *= w;
-            }
+            const double wy = r0.x, w = r0.y, cd = r1.x, sd = r1.y;
+            double s = x2.x, c = x2.y;
             double sp = 0.0, cp = 0.0;  // previous step of the recurrence
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -364,13 +419,14 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
             // keep the read-ahead in registers until here: without this the compiler re-issues the
             // loads at the top of the next trip and waits for them on the spot
             asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q1.x), "+v"(q1.y));
+            asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qa.x), "+v"(qa.y), "+v"(qt.x), "+v"(qt.y));
         }
     }
 
     if (SPLIT > 1) {
         // fold the partial sums of parts 1..S-1 into part 0, one frequency at a time, through the
-        // staging buffer (6 doubles per contributing thread)
-        double *xch = reinterpret_cast<double *>(stage);
+        // rotation-table buffer (6 doubles per contributing thread)
+        double *xch = reinterpret_cast<double *>(tab);
         const int slot = ((wave / SPLIT) * (SPLIT - 1) + (part - 1)) * 64 + (tid & 63);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
