@@ -67,6 +67,10 @@ PROTOTYPES = {
 
 
 def library_path():
+    """The in-tree HIP library; ``PDC_LIBRARY`` names another build of it (kernel A/B experiments)."""
+    override = os.environ.get("PDC_LIBRARY")
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 

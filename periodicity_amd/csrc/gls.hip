@@ -28,6 +28,11 @@
 
 #include <cstdlib>
 
+#ifndef PDC_AB
+#define PDC_AB 2
+#endif
+#define PDC_MERGED (PDC_AB == 2 || PDC_AB == 4 || PDC_AB == 5)
+
 using namespace pdc;
 
 namespace {
@@ -250,9 +255,17 @@ template <int K, int MODE, int SPLIT>
 __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(GlsArgs a) {
     constexpr int FT = kBlock / SPLIT;        // frequency-owning threads per workgroup
     constexpr int COLS = FT / 64;             // 64-lane columns of the tile
+#if PDC_MERGED
+    constexpr int kChunk = (SPLIT == 1 || PDC_AB == 5) ? 64 : 128;  // samples staged in LDS per step
+    __shared__ double2 stage[(kChunk + 1) * 3];    // records; + one of padding for the read-ahead
+    // per sample: {sin, cos} of theta_tile + 8 q Theta, q < 8 COLS (the seed of lanes 8q .. 8q+7 before
+    // their own offset), scaled by sqrt(w) where the sums want it | {sin, cos}(b Theta), b < 8
+    __shared__ double2 tab[kChunk + 1][COLS * 8 + 8 + 1];  // + 1: rows start 16 B apart modulo 128 B (bank spread)
+#else
     __shared__ double2 stage[(kChunk + 1) * 3];   // records; + one of padding for the read-ahead
     __shared__ double2 tab[kChunk + 1][16];       // per sample: {sin, cos}(8 a Theta), a < 8 | (b Theta), b < 8
     __shared__ double2 basec[kChunk + 1][COLS];   // per sample: {sin, cos} at the first bin of each column
+#endif
     __shared__ double red_v[4];
     __shared__ long long red_i[4];
     const int tid = threadIdx.x;
@@ -295,7 +308,15 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     auto rot = [](const double2 x, const double2 y) {
         return make_double2(__builtin_fma(x.x, y.y, x.y * y.x), __builtin_fma(x.y, y.y, -(x.x * y.x)));
     };
+#if PDC_MERGED
+#if PDC_AB == 4
+    const int slot_a = col * 8, slot_b = COLS * 8;
+#else
+    const int slot_a = col * 8 + (lane >> 3), slot_b = COLS * 8 + (lane & 7);
+#endif
+#else
     const int slot_a = lane >> 3, slot_b = 8 + (lane & 7);
+#endif
     for (int64_t base = 0; base < n; base += kChunk) {
         __syncthreads();  // everyone is done with the previous chunk
         stage[tid] = p0;
@@ -311,6 +332,47 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         // b = lane % 8 and Theta = 2 pi K delta t': its seed is two plane rotations of the column's
         // base instead of a sincos.  Tables come from two direct sincos (Theta, 8 Theta) and
         // rotation chains of length 7; the base (scaled by sqrt(w) where the sums want it) from one.
+#if PDC_MERGED
+        if (tid < 2 * kChunk) {
+            const int il = tid >> 1;
+            const double2 r0 = stage[il * 3], r2 = stage[il * 3 + 2];
+            const double tp = r2.y;
+            double2 step1, cur;
+            if ((tid & 1) == 0) {
+                // lane offsets b Theta, b < 8; and the tile's base phase for the neighbour
+                sincos_cycles(frac_product(kdelta, tp), step1.x, step1.y);
+                tab[il][COLS * 8] = make_double2(0.0, 1.0);
+                tab[il][COLS * 8 + 1] = step1;
+                cur = step1;
+#pragma unroll
+                for (int q = 2; q < 8; ++q) {
+                    cur = rot(cur, step1);
+                    tab[il][COLS * 8 + q] = cur;
+                }
+                sincos_cycles(frac_product(f_tile, tp), cur.x, cur.y);
+                if (MODE == MODE_FIT_MEAN || MODE == MODE_NO_MEAN) {
+                    // carry u = sqrt(w) sin, v = sqrt(w) cos: rotations and the recurrence are linear,
+                    // and every sum becomes one fma (the record holds sqrt(w) and sqrt(w) y)
+                    cur.x *= r0.y;
+                    cur.y *= r0.y;
+                }
+            } else {
+                sincos_cycles(frac_product(8.0 * kdelta, tp), step1.x, step1.y);
+            }
+            // the odd thread walks the base in steps of 8 Theta
+            double2 b0;
+            b0.x = __shfl_xor(cur.x, 1, 64);
+            b0.y = __shfl_xor(cur.y, 1, 64);
+            if (tid & 1) {
+                tab[il][0] = b0;
+#pragma unroll
+                for (int q = 1; q < COLS * 8; ++q) {
+                    b0 = rot(b0, step1);
+                    tab[il][q] = b0;
+                }
+            }
+        }
+#else
         {
             const int il = tid >> 1;
             const double2 r0 = stage[il * 3], r2 = stage[il * 3 + 2];
@@ -355,6 +417,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
                 }
             }
         }
+#endif
         __syncthreads();
         const int cnt = (int)((n - base) < kChunk ? (n - base) : kChunk);
         const double *recs = reinterpret_cast<const double *>(stage);
@@ -362,15 +425,26 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         // software pipeline: everything sample i+1 needs is read from LDS while sample i is processed
         // (the buffers are padded by one row so the last read-ahead needs no branch)
         const int i_beg = part * (kChunk / SPLIT);
+#if PDC_MERGED
+        double2 qa = tab[i_beg][slot_a], qt = tab[i_beg][slot_b];
+        double q2 = recs[i_beg * 6 + 4];
+#else
         double2 qb = basec[i_beg][col], qa = tab[i_beg][slot_a], qt = tab[i_beg][slot_b];
+#endif
         double2 q0 = *reinterpret_cast<const double2 *>(recs + i_beg * 6);
         double2 q1 = *reinterpret_cast<const double2 *>(recs + i_beg * 6 + 2);
         for (int i = i_beg; i < i_end; ++i) {
             const double2 r0 = q0, r1 = q1;
+#if PDC_MERGED
+            const double2 x2 = rot(qa, qt);
+            const double cd2 = q2;
+            q2 = recs[(i + 1) * 6 + 4];
+#else
             const double2 x1 = rot(qb, qa);
             const double2 x2 = rot(x1, qt);
             const double cd2 = recs[i * 6 + 4];
             qb = basec[i + 1][col];
+#endif
             qa = tab[i + 1][slot_a];
             qt = tab[i + 1][slot_b];
             q0 = *reinterpret_cast<const double2 *>(recs + (i + 1) * 6);
@@ -419,7 +493,11 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
             // keep the read-ahead in registers until here: without this the compiler re-issues the
             // loads at the top of the next trip and waits for them on the spot
             asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q1.x), "+v"(q1.y));
+#if PDC_MERGED
+            asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qt.x), "+v"(qt.y), "+v"(q2));
+#elif PDC_AB != 3
             asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qa.x), "+v"(qa.y), "+v"(qt.x), "+v"(qt.y));
+#endif
         }
     }
 
