@@ -6,18 +6,22 @@
 //
 // Decomposition
 //   gls_prep_kernel   one workgroup per light curve: weights (spectral.py:99-108), YY (:120) and
-//                     one 48-byte record per sample {t - t0, sqrt(w)*y, sqrt(w), cos(2 pi delta t'),
-//                     sin(2 pi delta t'), 2 cos(2 pi delta t')} ({.., w*y, w, ..} when all weights
-//                     are equal or the caller supplies them).
+//                     one 48-byte record per sample {sqrt(w)*y, sqrt(w), cos(2 pi delta t'),
+//                     sin(2 pi delta t'), 2 cos(2 pi delta t'), t' = t - t0} ({w*y, w, ..} when all
+//                     weights are equal or the caller supplies them).
 //   gls_scan_kernel   each thread owns K consecutive trial frequencies; the workgroup streams the
 //                     curve's records once through LDS (coalesced 16-byte loads, register
-//                     prefetch of the next chunk) and every lane reads each record as an LDS
-//                     broadcast.  Per (sample, thread): ONE software sincos at the tile's first
-//                     frequency (phase carried in cycles with an exact fma product), then one
-//                     plane rotation by the per-sample angle 2 pi delta t' and K-2 steps of the
-//                     three-term recurrence x[k+1] = 2cos(theta) x[k] - x[k-1] walk the uniform
-//                     grid; 6 running sums per frequency (Sh, Ch, S, C, sum w s^2, sum w s c —
-//                     the 2-omega sums follow from the double-angle identities).  The epilogue
+//                     prefetch of the next chunk).  Thread L of a tile starts at phase
+//                     theta_tile + L Theta, Theta = 2 pi K delta t': per chunk the workgroup builds,
+//                     with three software sincos per SAMPLE (phase carried in cycles with an exact
+//                     fma product) and short rotation chains, the LDS tables {sin, cos}(theta_tile
+//                     + 8 q Theta) and {sin, cos}(b Theta), b < 8, so that the seed of a (sample,
+//                     thread) is ONE plane rotation of two table entries.  Then one rotation by
+//                     the per-sample angle 2 pi delta t' and K-2 steps of the three-term
+//                     recurrence x[k+1] = 2cos(theta) x[k] - x[k-1] walk the uniform grid; 6
+//                     running sums per frequency (Sh, Ch, S, C, sum w s^2, sum w s c — the
+//                     2-omega sums follow from the double-angle identities), each one fma because
+//                     sin/cos are carried pre-multiplied by sqrt(w).  The epilogue
 //                     (spectral.py:113-132) is fused, so only power[nf] is written.
 //   gls_peak_kernel   NaN-aware max / argmax per curve from per-workgroup partials.
 //
@@ -28,17 +32,11 @@
 
 #include <cstdlib>
 
-#ifndef PDC_AB
-#define PDC_AB 2
-#endif
-#define PDC_MERGED (PDC_AB == 2 || PDC_AB == 4 || PDC_AB == 5)
-
 using namespace pdc;
 
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kChunk = 128;  // samples staged in LDS per step (records 6 KiB + rotation tables 34 KiB)
 constexpr int kPrepBlock = 1024;
 
 // *_U: all weights equal (err=None upstream, spectral.py:99-100): the weight factors out of four of
@@ -255,17 +253,11 @@ template <int K, int MODE, int SPLIT>
 __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(GlsArgs a) {
     constexpr int FT = kBlock / SPLIT;        // frequency-owning threads per workgroup
     constexpr int COLS = FT / 64;             // 64-lane columns of the tile
-#if PDC_MERGED
-    constexpr int kChunk = (SPLIT == 1 || PDC_AB == 5) ? 64 : 128;  // samples staged in LDS per step
+    constexpr int kChunk = SPLIT == 1 ? 64 : 128;  // samples staged in LDS per step
     __shared__ double2 stage[(kChunk + 1) * 3];    // records; + one of padding for the read-ahead
     // per sample: {sin, cos} of theta_tile + 8 q Theta, q < 8 COLS (the seed of lanes 8q .. 8q+7 before
     // their own offset), scaled by sqrt(w) where the sums want it | {sin, cos}(b Theta), b < 8
     __shared__ double2 tab[kChunk + 1][COLS * 8 + 8 + 1];  // + 1: rows start 16 B apart modulo 128 B (bank spread)
-#else
-    __shared__ double2 stage[(kChunk + 1) * 3];   // records; + one of padding for the read-ahead
-    __shared__ double2 tab[kChunk + 1][16];       // per sample: {sin, cos}(8 a Theta), a < 8 | (b Theta), b < 8
-    __shared__ double2 basec[kChunk + 1][COLS];   // per sample: {sin, cos} at the first bin of each column
-#endif
     __shared__ double red_v[4];
     __shared__ long long red_i[4];
     const int tid = threadIdx.x;
@@ -308,15 +300,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     auto rot = [](const double2 x, const double2 y) {
         return make_double2(__builtin_fma(x.x, y.y, x.y * y.x), __builtin_fma(x.y, y.y, -(x.x * y.x)));
     };
-#if PDC_MERGED
-#if PDC_AB == 4
-    const int slot_a = col * 8, slot_b = COLS * 8;
-#else
     const int slot_a = col * 8 + (lane >> 3), slot_b = COLS * 8 + (lane & 7);
-#endif
-#else
-    const int slot_a = lane >> 3, slot_b = 8 + (lane & 7);
-#endif
     for (int64_t base = 0; base < n; base += kChunk) {
         __syncthreads();  // everyone is done with the previous chunk
         stage[tid] = p0;
@@ -329,10 +313,11 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         }
         // ---- per-sample rotation tables (two threads per sample) ------------------------------------
         // Thread (col, lane) starts at phase theta_tile + (64 col + 8 a + b) Theta with a = lane / 8,
-        // b = lane % 8 and Theta = 2 pi K delta t': its seed is two plane rotations of the column's
-        // base instead of a sincos.  Tables come from two direct sincos (Theta, 8 Theta) and
-        // rotation chains of length 7; the base (scaled by sqrt(w) where the sums want it) from one.
-#if PDC_MERGED
+        // b = lane % 8 and Theta = 2 pi K delta t': its seed is tab[8 col + a] rotated by tab[8 COLS + b]
+        // instead of a sincos.  The even thread of a sample makes {sin, cos}(b Theta) (one sincos, a
+        // chain of 6 rotations) and the tile's base phase (one sincos, scaled by sqrt(w) where the
+        // sums want it); the odd thread walks that base in steps of 8 Theta (one sincos, 8 COLS - 1
+        // rotations).
         if (tid < 2 * kChunk) {
             const int il = tid >> 1;
             const double2 r0 = stage[il * 3], r2 = stage[il * 3 + 2];
@@ -372,52 +357,6 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
                 }
             }
         }
-#else
-        {
-            const int il = tid >> 1;
-            const double2 r0 = stage[il * 3], r2 = stage[il * 3 + 2];
-            const double tp = r2.y;
-            double2 step1, chain;  // the thread's unit angle and its running multiple
-            double2 first;         // role 0: base of column 0; role 1: 64 Theta
-            if ((tid & 1) == 0) {
-                sincos_cycles(frac_product(kdelta, tp), step1.x, step1.y);
-            } else {
-                sincos_cycles(frac_product(8.0 * kdelta, tp), step1.x, step1.y);
-            }
-            const int row0 = (tid & 1) ? 0 : 8;
-            tab[il][row0] = make_double2(0.0, 1.0);
-            tab[il][row0 + 1] = step1;
-            chain = step1;
-#pragma unroll
-            for (int q = 2; q < 8; ++q) {
-                chain = rot(chain, step1);
-                tab[il][row0 + q] = chain;
-            }
-            if ((tid & 1) == 0) {
-                sincos_cycles(frac_product(f_tile, tp), first.x, first.y);
-                if (MODE == MODE_FIT_MEAN || MODE == MODE_NO_MEAN) {
-                    // carry u = sqrt(w) sin, v = sqrt(w) cos: rotations and the recurrence are linear,
-                    // and every sum becomes one fma (the record holds sqrt(w) and sqrt(w) y)
-                    first.x *= r0.y;
-                    first.y *= r0.y;
-                }
-            } else {
-                first = rot(chain, step1);  // 64 Theta
-            }
-            // role 1 builds the column bases: it needs role 0's base (neighbouring lane)
-            double2 b0;
-            b0.x = __shfl_xor(first.x, 1, 64);
-            b0.y = __shfl_xor(first.y, 1, 64);
-            if (tid & 1) {
-                basec[il][0] = b0;
-#pragma unroll
-                for (int q = 1; q < COLS; ++q) {
-                    b0 = rot(b0, first);
-                    basec[il][q] = b0;
-                }
-            }
-        }
-#endif
         __syncthreads();
         const int cnt = (int)((n - base) < kChunk ? (n - base) : kChunk);
         const double *recs = reinterpret_cast<const double *>(stage);
@@ -425,26 +364,15 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         // software pipeline: everything sample i+1 needs is read from LDS while sample i is processed
         // (the buffers are padded by one row so the last read-ahead needs no branch)
         const int i_beg = part * (kChunk / SPLIT);
-#if PDC_MERGED
         double2 qa = tab[i_beg][slot_a], qt = tab[i_beg][slot_b];
         double q2 = recs[i_beg * 6 + 4];
-#else
-        double2 qb = basec[i_beg][col], qa = tab[i_beg][slot_a], qt = tab[i_beg][slot_b];
-#endif
         double2 q0 = *reinterpret_cast<const double2 *>(recs + i_beg * 6);
         double2 q1 = *reinterpret_cast<const double2 *>(recs + i_beg * 6 + 2);
         for (int i = i_beg; i < i_end; ++i) {
             const double2 r0 = q0, r1 = q1;
-#if PDC_MERGED
             const double2 x2 = rot(qa, qt);
             const double cd2 = q2;
             q2 = recs[(i + 1) * 6 + 4];
-#else
-            const double2 x1 = rot(qb, qa);
-            const double2 x2 = rot(x1, qt);
-            const double cd2 = recs[i * 6 + 4];
-            qb = basec[i + 1][col];
-#endif
             qa = tab[i + 1][slot_a];
             qt = tab[i + 1][slot_b];
             q0 = *reinterpret_cast<const double2 *>(recs + (i + 1) * 6);
@@ -493,11 +421,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
             // keep the read-ahead in registers until here: without this the compiler re-issues the
             // loads at the top of the next trip and waits for them on the spot
             asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q1.x), "+v"(q1.y));
-#if PDC_MERGED
             asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qt.x), "+v"(qt.y), "+v"(q2));
-#elif PDC_AB != 3
-            asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qa.x), "+v"(qa.y), "+v"(qt.x), "+v"(qt.y));
-#endif
         }
     }
 
