@@ -364,21 +364,31 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         // software pipeline: everything sample i+1 needs is read from LDS while sample i is processed
         // (the buffers are padded by one row so the last read-ahead needs no branch)
         const int i_beg = part * (kChunk / SPLIT);
-        double2 qa = tab[i_beg][slot_a], qt = tab[i_beg][slot_b];
-        double q2 = recs[i_beg * 6 + 4];
-        double2 q0 = *reinterpret_cast<const double2 *>(recs + i_beg * 6);
-        double2 q1 = *reinterpret_cast<const double2 *>(recs + i_beg * 6 + 2);
-        for (int i = i_beg; i < i_end; ++i) {
-            const double2 r0 = q0, r1 = q1;
-            const double2 x2 = rot(qa, qt);
-            const double cd2 = q2;
-            q2 = recs[(i + 1) * 6 + 4];
-            qa = tab[i + 1][slot_a];
-            qt = tab[i + 1][slot_b];
-            q0 = *reinterpret_cast<const double2 *>(recs + (i + 1) * 6);
-            q1 = *reinterpret_cast<const double2 *>(recs + (i + 1) * 6 + 2);
-            const double wy = r0.x, w = r0.y, cd = r1.x, sd = r1.y;
-            double s = x2.x, c = x2.y;
+        // Two samples per trip with two register sets (A, B) that swap roles, so the read-ahead costs
+        // no register copies.
+        struct Ahead {
+            double2 rec0, rec1, qa, qt;  // {sqrt(w) y, sqrt(w)}, {cos, sin}(2 pi delta t'), table entries
+            double cd2;
+        };
+        auto fetch = [&](const int i) {
+            Ahead h;
+            h.qa = tab[i][slot_a];
+            h.qt = tab[i][slot_b];
+            h.rec0 = *reinterpret_cast<const double2 *>(recs + i * 6);
+            h.rec1 = *reinterpret_cast<const double2 *>(recs + i * 6 + 2);
+            h.cd2 = recs[i * 6 + 4];
+            return h;
+        };
+        // keep a read-ahead in registers until here: without this the compiler re-issues the loads at
+        // the point of use and waits for them on the spot
+        auto pin = [](Ahead &h) {
+            asm volatile("" : "+v"(h.rec0.x), "+v"(h.rec0.y), "+v"(h.rec1.x), "+v"(h.rec1.y));
+            asm volatile("" : "+v"(h.qa.x), "+v"(h.qa.y), "+v"(h.qt.x), "+v"(h.qt.y), "+v"(h.cd2));
+        };
+        auto accumulate = [&](const Ahead &h) {
+            const double2 seed = rot(h.qa, h.qt);
+            const double wy = h.rec0.x, w = h.rec0.y, cd = h.rec1.x, sd = h.rec1.y, cd2 = h.cd2;
+            double s = seed.x, c = seed.y;
             double sp = 0.0, cp = 0.0;  // previous step of the recurrence
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -418,11 +428,18 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
                     s = sn;
                 }
             }
-            // keep the read-ahead in registers until here: without this the compiler re-issues the
-            // loads at the top of the next trip and waits for them on the spot
-            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q1.x), "+v"(q1.y));
-            asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qt.x), "+v"(qt.y), "+v"(q2));
+        };
+        Ahead A = fetch(i_beg);
+        int i = i_beg;
+        for (; i + 1 < i_end; i += 2) {
+            Ahead B = fetch(i + 1);
+            accumulate(A);
+            pin(B);
+            A = fetch(i + 2);  // (row i_end <= kChunk exists: the buffers are padded by one row)
+            accumulate(B);
+            pin(A);
         }
+        if (i < i_end) accumulate(A);
     }
 
     if (SPLIT > 1) {
@@ -723,8 +740,8 @@ __global__ __launch_bounds__(64) void gls_peak_kernel(const double *blk_max, con
 }
 
 // Tile shape (K frequencies per thread, S waves per frequency tile).  Cost model: a wave executes
-// ~(38 + 9K) VALU instructions per sample and handles 1/S of the samples; the waves on one SIMD
-// share its issue slots, so time ~ ceil(waves / 1024) * (38 + 9K) / S (up to a constant): few large
+// ~(12 + 8K) VALU instructions per sample and handles 1/S of the samples; the waves on one SIMD
+// share its issue slots, so time ~ ceil(waves / 1024) * (12 + 8K) / S (up to a constant): few large
 // tiles when the grid fills the chip, many small ones when it does not.  A lone wave per SIMD cannot
 // hide its own LDS/dependency stalls (+10 %).  PDC_GLS_K / PDC_GLS_S override for experiments.
 void tile_shape(int64_t n_curves, int64_t nf, int *K_out, int *S_out) {
@@ -738,7 +755,7 @@ void tile_shape(int64_t n_curves, int64_t nf, int *K_out, int *S_out) {
             if (envS && S != envS) continue;
             const double waves = (double)n_curves * (double)((nf + 64 * K - 1) / (64 * K)) * S;
             const double rounds = __builtin_ceil(waves / 1024.0);
-            double cost = rounds * (38.0 + 9.0 * K) / S;
+            double cost = rounds * (12.0 + 8.0 * K) / S;
             if (waves / 1024.0 <= 1.0) cost *= 1.10;
             cost *= 1.0 + 0.02 * (S > 2 ? S - 2 : 2 - S);  // measured: two waves per tile is the sweet spot
             if (cost < best) {
