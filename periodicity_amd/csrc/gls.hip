@@ -254,7 +254,9 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     constexpr int FT = kBlock / SPLIT;        // frequency-owning threads per workgroup
     constexpr int COLS = FT / 64;             // 64-lane columns of the tile
     constexpr int kChunk = SPLIT == 1 ? 64 : 128;  // samples staged in LDS per step
-    __shared__ double2 stage[(kChunk + 1) * 3];    // records; + one of padding for the read-ahead
+    // records of the current and of the next chunk (filled by LDS-direct loads while the current one is
+    // consumed); + one record of padding each for the read-ahead
+    __shared__ double2 stage2[2][(kChunk + 1) * 3];
     // per sample: {sin, cos} of theta_tile + 8 q Theta, q < 8 COLS (the seed of lanes 8q .. 8q+7 before
     // their own offset), scaled by sqrt(w) where the sums want it | {sin, cos}(b Theta), b < 8
     __shared__ double2 tab[kChunk + 1][COLS * 8 + 8 + 1];  // + 1: rows start 16 B apart modulo 128 B (bank spread)
@@ -288,29 +290,32 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
 
     const double2 *src = reinterpret_cast<const double2 *>(a.rec + off * 6);
     const int64_t n2 = n * 3;
-    const double2 zero2 = make_double2(0.0, 0.0);
-    constexpr int kStage2 = kChunk * 3;  // double2 words per chunk (<= 2 per thread)
-    double2 p0, p1;
-    {
-        const int64_t i0 = tid;
-        p0 = i0 < n2 ? src[i0] : zero2;
-        p1 = (tid + kBlock < kStage2 && i0 + kBlock < n2) ? src[i0 + kBlock] : zero2;
-    }
+    constexpr int kStage2 = kChunk * 3;  // double2 words per chunk
+    // global -> LDS without passing through registers (global_load_lds_dwordx4: lane l of a wave
+    // deposits its 16 bytes at the wave's LDS base + 16 l), one 64-word segment per wave and step
+    auto request = [&](const int64_t first_sample, const int buf) {
+#pragma unroll
+        for (int seg = 0; seg < (kStage2 / 64 + 3) / 4; ++seg) {
+            const int word = (seg * 4 + wave) * 64;
+            const int64_t i0 = first_sample * 3 + word + lane;
+            if (word < kStage2 && i0 < n2)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + i0),
+                    (__attribute__((address_space(3))) void *)(&stage2[buf][word]), 16, 0, 0);
+        }
+    };
     // plane rotation of {sin, cos} pairs: angle(x) + angle(y)
     auto rot = [](const double2 x, const double2 y) {
         return make_double2(__builtin_fma(x.x, y.y, x.y * y.x), __builtin_fma(x.y, y.y, -(x.x * y.x)));
     };
     const int slot_a = col * 8 + (lane >> 3), slot_b = COLS * 8 + (lane & 7);
-    for (int64_t base = 0; base < n; base += kChunk) {
-        __syncthreads();  // everyone is done with the previous chunk
-        stage[tid] = p0;
-        if (tid + kBlock < kStage2) stage[tid + kBlock] = p1;
-        __syncthreads();
-        if (base + kChunk < n) {  // prefetch the next chunk while this one is consumed
-            const int64_t i0 = (base + kChunk) * 3 + tid;
-            p0 = i0 < n2 ? src[i0] : zero2;
-            p1 = (tid + kBlock < kStage2 && i0 + kBlock < n2) ? src[i0 + kBlock] : zero2;
-        }
+    request(0, 0);
+    int buf = 0;
+    for (int64_t base = 0; base < n; base += kChunk, buf ^= 1) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of the chunk has landed
+        __syncthreads();                     // ... and everyone is done with the previous chunk
+        if (base + kChunk < n) request(base + kChunk, buf ^ 1);
+        const double2 *stage = stage2[buf];
         // ---- per-sample rotation tables (two threads per sample) ------------------------------------
         // Thread (col, lane) starts at phase theta_tile + (64 col + 8 a + b) Theta with a = lane / 8,
         // b = lane % 8 and Theta = 2 pi K delta t': its seed is tab[8 col + a] rotated by tab[8 COLS + b]
