@@ -7,11 +7,11 @@
 // Decomposition
 //   gls_prep_kernel   one workgroup per light curve: weights (spectral.py:99-108), YY (:120) and
 //                     one 48-byte record per sample {sqrt(w)*y, sqrt(w), cos(2 pi delta t'),
-//                     sin(2 pi delta t'), 2 cos(2 pi delta t'), t' = t - t0} ({w*y, w, ..} when all
-//                     weights are equal or the caller supplies them).
-//   gls_scan_kernel   each thread owns K consecutive trial frequencies; the workgroup streams the
-//                     curve's records once through LDS (coalesced 16-byte loads, register
-//                     prefetch of the next chunk).  Thread L of a tile starts at phase
+//                     sin(2 pi delta t'), 2 cos(2 pi delta t'), t' = t - t0} ({w, w, ..} for the raw
+//                     trig sums, whose weights the caller supplies).
+//   gls_scan_kernel   each thread owns K consecutive trial frequencies.  A wave reads the curve's
+//                     records through the scalar cache (they are wave-uniform: s_load, SGPR
+//                     operands of the fmas).  Thread L of a tile starts at phase
 //                     theta_tile + L Theta, Theta = 2 pi K delta t': per chunk the workgroup builds,
 //                     with three software sincos per SAMPLE (phase carried in cycles with an exact
 //                     fma product) and short rotation chains, the LDS tables {sin, cos}(theta_tile
@@ -39,11 +39,8 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kPrepBlock = 1024;
 
-// *_U: all weights equal (err=None upstream, spectral.py:99-100): the weight factors out of four of
-// the six sums, which saves one multiply per (sample, frequency).
-enum Mode { MODE_FIT_MEAN = 0, MODE_NO_MEAN = 1, MODE_RAW = 2, MODE_FIT_MEAN_U = 3, MODE_NO_MEAN_U = 4 };
-constexpr bool mode_fits_mean(int m) { return m == MODE_FIT_MEAN || m == MODE_FIT_MEAN_U; }
-constexpr bool mode_uniform(int m) { return m == MODE_FIT_MEAN_U || m == MODE_NO_MEAN_U; }
+enum Mode { MODE_FIT_MEAN = 0, MODE_NO_MEAN = 1, MODE_RAW = 2 };
+constexpr bool mode_fits_mean(int m) { return m == MODE_FIT_MEAN; }
 
 struct GlsArgs {
     const double *rec;       // [n_total][6]
@@ -133,7 +130,7 @@ __global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
         }
         double sd, cd;
         sincos_cycles(frac_product(a.delta, tp), sd, cd);
-        if (!a.raw && dy) {  // weighted scan: the kernel carries sqrt(w) sin / sqrt(w) cos
+        if (!a.raw) {  // the kernel carries sqrt(w) sin / sqrt(w) cos
             w = sqrt(w);
             wy = w * (y[i] - ybar);
         }
@@ -206,9 +203,9 @@ __global__ __launch_bounds__(kBlock) void gls_prep_wide_b(WidePrepArgs a) {
         wsum += w;
         double sd, cd;
         sincos_cycles(frac_product(a.p.delta, tp), sd, cd);
-        const double rw = a.p.dy ? sqrt(w) : w;  // weighted scan: sqrt(w) and sqrt(w) y
+        const double rw = sqrt(w);  // the scan carries sqrt(w) sin / sqrt(w) cos
         double2 *r = reinterpret_cast<double2 *>(a.p.rec + i * 6);
-        r[0] = make_double2(a.p.dy ? rw * yc : wy, rw);
+        r[0] = make_double2(rw * yc, rw);
         r[1] = make_double2(cd, sd);
         r[2] = make_double2(cd + cd, tp);
     }
@@ -253,10 +250,7 @@ template <int K, int MODE, int SPLIT>
 __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(GlsArgs a) {
     constexpr int FT = kBlock / SPLIT;        // frequency-owning threads per workgroup
     constexpr int COLS = FT / 64;             // 64-lane columns of the tile
-    constexpr int kChunk = SPLIT == 1 ? 64 : 128;  // samples staged in LDS per step
-    // records of the current and of the next chunk (filled by LDS-direct loads while the current one is
-    // consumed); + one record of padding each for the read-ahead
-    __shared__ double2 stage2[2][(kChunk + 1) * 3];
+    constexpr int kChunk = SPLIT == 1 ? 64 : 128;  // samples per rotation-table chunk
     // per sample: {sin, cos} of theta_tile + 8 q Theta, q < 8 COLS (the seed of lanes 8q .. 8q+7 before
     // their own offset), scaled by sqrt(w) where the sums want it | {sin, cos}(b Theta), b < 8
     __shared__ double2 tab[kChunk + 1][COLS * 8 + 8 + 1];  // + 1: rows start 16 B apart modulo 128 B (bank spread)
@@ -288,34 +282,13 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
 #pragma unroll
     for (int k = 0; k < K; ++k) Sh[k] = Ch[k] = S[k] = C[k] = SS[k] = SC[k] = 0.0;
 
-    const double2 *src = reinterpret_cast<const double2 *>(a.rec + off * 6);
-    const int64_t n2 = n * 3;
-    constexpr int kStage2 = kChunk * 3;  // double2 words per chunk
-    // global -> LDS without passing through registers (global_load_lds_dwordx4: lane l of a wave
-    // deposits its 16 bytes at the wave's LDS base + 16 l), one 64-word segment per wave and step
-    auto request = [&](const int64_t first_sample, const int buf) {
-#pragma unroll
-        for (int seg = 0; seg < (kStage2 / 64 + 3) / 4; ++seg) {
-            const int word = (seg * 4 + wave) * 64;
-            const int64_t i0 = first_sample * 3 + word + lane;
-            if (word < kStage2 && i0 < n2)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + i0),
-                    (__attribute__((address_space(3))) void *)(&stage2[buf][word]), 16, 0, 0);
-        }
-    };
     // plane rotation of {sin, cos} pairs: angle(x) + angle(y)
     auto rot = [](const double2 x, const double2 y) {
         return make_double2(__builtin_fma(x.x, y.y, x.y * y.x), __builtin_fma(x.y, y.y, -(x.x * y.x)));
     };
     const int slot_a = col * 8 + (lane >> 3), slot_b = COLS * 8 + (lane & 7);
-    request(0, 0);
-    int buf = 0;
-    for (int64_t base = 0; base < n; base += kChunk, buf ^= 1) {
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's share of the chunk has landed
-        __syncthreads();                     // ... and everyone is done with the previous chunk
-        if (base + kChunk < n) request(base + kChunk, buf ^ 1);
-        const double2 *stage = stage2[buf];
+    for (int64_t base = 0; base < n; base += kChunk) {
+        __syncthreads();  // everyone is done with the previous chunk's tables
         // ---- per-sample rotation tables (two threads per sample) ------------------------------------
         // Thread (col, lane) starts at phase theta_tile + (64 col + 8 a + b) Theta with a = lane / 8,
         // b = lane % 8 and Theta = 2 pi K delta t': its seed is tab[8 col + a] rotated by tab[8 COLS + b]
@@ -325,8 +298,10 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         // rotations).
         if (tid < 2 * kChunk) {
             const int il = tid >> 1;
-            const double2 r0 = stage[il * 3], r2 = stage[il * 3 + 2];
-            const double tp = r2.y;
+            // (rows past the end of the curve are never accumulated; they only need finite input)
+            const bool live = base + il < n;
+            const double tp = live ? a.rec[(off + base + il) * 6 + 5] : 0.0;
+            const double sqw = live ? a.rec[(off + base + il) * 6 + 1] : 0.0;
             double2 step1, cur;
             if ((tid & 1) == 0) {
                 // lane offsets b Theta, b < 8; and the tile's base phase for the neighbour
@@ -343,8 +318,8 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
                 if (MODE == MODE_FIT_MEAN || MODE == MODE_NO_MEAN) {
                     // carry u = sqrt(w) sin, v = sqrt(w) cos: rotations and the recurrence are linear,
                     // and every sum becomes one fma (the record holds sqrt(w) and sqrt(w) y)
-                    cur.x *= r0.y;
-                    cur.y *= r0.y;
+                    cur.x *= sqw;
+                    cur.y *= sqw;
                 }
             } else {
                 sincos_cycles(frac_product(8.0 * kdelta, tp), step1.x, step1.y);
@@ -364,50 +339,43 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         }
         __syncthreads();
         const int cnt = (int)((n - base) < kChunk ? (n - base) : kChunk);
-        const double *recs = reinterpret_cast<const double *>(stage);
         const int i_end = cnt < (part + 1) * (kChunk / SPLIT) ? cnt : (part + 1) * (kChunk / SPLIT);
-        // software pipeline: everything sample i+1 needs is read from LDS while sample i is processed
-        // (the buffers are padded by one row so the last read-ahead needs no branch)
         const int i_beg = part * (kChunk / SPLIT);
-        // Two samples per trip with two register sets (A, B) that swap roles, so the read-ahead costs
-        // no register copies.
+        // Software pipeline: everything sample i+1 needs is requested while sample i is accumulated;
+        // two samples per trip with two register sets (A, B) that swap roles, so the read-ahead costs
+        // no register copies.  The record fields are wave-uniform: they come through the scalar
+        // cache (s_load, constant address space) and feed the fmas as SGPR operands - no LDS or VGPR
+        // traffic for them; the two table entries are LDS reads.  Scalar loads return out of order,
+        // so the wait for set A (lgkmcnt(0)) sits right before the request for set B goes out.
+        // (The read-ahead touches up to two records past the curve and one padding table row.)
+        using d4 = double __attribute__((ext_vector_type(4)));
+        using cd4 = __attribute__((address_space(4))) const d4;
+        using cdbl = __attribute__((address_space(4))) const double;
+        const cd4 *srec = reinterpret_cast<const cd4 *>(reinterpret_cast<uintptr_t>(a.rec + (off + base) * 6));
         struct Ahead {
-            double2 rec0, rec1, qa, qt;  // {sqrt(w) y, sqrt(w)}, {cos, sin}(2 pi delta t'), table entries
+            d4 r;  // {sqrt(w) y, sqrt(w), cos, sin (2 pi delta t')}
             double cd2;
+            double2 qa, qt;
         };
         auto fetch = [&](const int i) {
             Ahead h;
             h.qa = tab[i][slot_a];
             h.qt = tab[i][slot_b];
-            h.rec0 = *reinterpret_cast<const double2 *>(recs + i * 6);
-            h.rec1 = *reinterpret_cast<const double2 *>(recs + i * 6 + 2);
-            h.cd2 = recs[i * 6 + 4];
+            const cd4 *rp = reinterpret_cast<const cd4 *>(reinterpret_cast<const cdbl *>(srec) + i * 6);
+            h.r = rp[0];
+            h.cd2 = reinterpret_cast<const cdbl *>(rp)[4];
             return h;
-        };
-        // keep a read-ahead in registers until here: without this the compiler re-issues the loads at
-        // the point of use and waits for them on the spot
-        auto pin = [](Ahead &h) {
-            asm volatile("" : "+v"(h.rec0.x), "+v"(h.rec0.y), "+v"(h.rec1.x), "+v"(h.rec1.y));
-            asm volatile("" : "+v"(h.qa.x), "+v"(h.qa.y), "+v"(h.qt.x), "+v"(h.qt.y), "+v"(h.cd2));
         };
         auto accumulate = [&](const Ahead &h) {
             const double2 seed = rot(h.qa, h.qt);
-            const double wy = h.rec0.x, w = h.rec0.y, cd = h.rec1.x, sd = h.rec1.y, cd2 = h.cd2;
+            const double wy = h.r[0], w = h.r[1], cd = h.r[2], sd = h.r[3], cd2 = h.cd2;
             double s = seed.x, c = seed.y;
             double sp = 0.0, cp = 0.0;  // previous step of the recurrence
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 Sh[k] = __builtin_fma(wy, s, Sh[k]);
                 Ch[k] = __builtin_fma(wy, c, Ch[k]);
-                if (mode_uniform(MODE)) {
-                    // equal weights: accumulate the bare trig sums, scale once in the epilogue
-                    if (mode_fits_mean(MODE)) {
-                        S[k] += s;
-                        C[k] += c;
-                    }
-                    SS[k] = __builtin_fma(s, s, SS[k]);
-                    SC[k] = __builtin_fma(s, c, SC[k]);
-                } else if (MODE != MODE_RAW) {
+                if (MODE != MODE_RAW) {
                     if (MODE == MODE_FIT_MEAN) {
                         S[k] = __builtin_fma(w, s, S[k]);
                         C[k] = __builtin_fma(w, c, C[k]);
@@ -437,12 +405,16 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         Ahead A = fetch(i_beg);
         int i = i_beg;
         for (; i + 1 < i_end; i += 2) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): set A has arrived
             Ahead B = fetch(i + 1);
+            __builtin_amdgcn_sched_barrier(0);
             accumulate(A);
-            pin(B);
-            A = fetch(i + 2);  // (row i_end <= kChunk exists: the buffers are padded by one row)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            A = fetch(i + 2);
+            __builtin_amdgcn_sched_barrier(0);
             accumulate(B);
-            pin(A);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (i < i_end) accumulate(A);
     }
@@ -496,13 +468,6 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     for (int k = 0; k < K; ++k) {
         const int64_t j = jl + k;
         if (owner && j < a.nf) {
-            if (mode_uniform(MODE)) {  // w = (1/1)/W for every sample
-                const double w0 = 1.0 / Werr;
-                S[k] *= w0;
-                C[k] *= w0;
-                SS[k] *= w0;
-                SC[k] *= w0;
-            }
             const double p = gls_power<MODE>(Sh[k], Ch[k], S[k], C[k], SS[k], SC[k], YY, Wsum,
                                              Werr, a.psd);
             if (a.power) a.power[curve * a.nf + j] = p;
@@ -577,8 +542,7 @@ template <bool FIT_MEAN, bool UNI>
 __global__ __launch_bounds__(kShBlock) void gls_shared_kernel(SharedArgs a) {
     constexpr int RT = UNI ? kShCurvesU : kShCurvesW;
     constexpr int NW = UNI ? 1 : RT;  // sets of weight-only sums
-    constexpr int MODE = FIT_MEAN ? (UNI ? MODE_FIT_MEAN_U : MODE_FIT_MEAN)
-                                  : (UNI ? MODE_NO_MEAN_U : MODE_NO_MEAN);
+    constexpr int MODE = FIT_MEAN ? MODE_FIT_MEAN : MODE_NO_MEAN;
     __shared__ double2 trig_sc[kShChunk + 2][64];  // {sin, cos}; + rows for the read-ahead
     __shared__ double2 trig_qq[kShChunk + 2][64];  // {sin^2, sin cos}
     const int lane = threadIdx.x & 63;
@@ -930,11 +894,9 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     const int64_t G = a.n_curves * a.tiles;
     const dim3 grid((unsigned)(((G + 7) / 8) * 8));
     if (mode == MODE_FIT_MEAN) {
-        if (d_dy) launch_scan<MODE_FIT_MEAN>(K, S, grid, st, a);
-        else launch_scan<MODE_FIT_MEAN_U>(K, S, grid, st, a);
+        launch_scan<MODE_FIT_MEAN>(K, S, grid, st, a);
     } else if (mode == MODE_NO_MEAN) {
-        if (d_dy) launch_scan<MODE_NO_MEAN>(K, S, grid, st, a);
-        else launch_scan<MODE_NO_MEAN_U>(K, S, grid, st, a);
+        launch_scan<MODE_NO_MEAN>(K, S, grid, st, a);
     } else {
         launch_scan<MODE_RAW>(K, S, grid, st, a);
     }
