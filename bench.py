@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR = 50.0          # algorithmic fp64 flop per (sample, frequency) pair
 PEAK_FP64_VECTOR_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz (MI355X, spec)
-VALU_INSTR_PER_PAIR = 8.61      # gls_scan_kernel<16,0,2>: SQ_INSTS_VALU 1.345e10 per launch / 1.5625e9 wave-pairs
+VALU_INSTR_PER_PAIR = 8.56      # gls_scan_kernel<16,0,2>: SQ_INSTS_VALU 1.338e10 per launch / 1.5625e9 wave-pairs
 FP64_ISSUE_CEILING_NS = 1.93    # tools/ubench/fp64_rate.hip: ns per wave-instr per SIMD, 2 waves/SIMD
 N_SAMPLES = 100_000
 NF_PER_GPU = 1_000_000
@@ -265,7 +265,7 @@ def main():
                          "note": "fp64 vector-ALU bound (software sincos + recurrences; no fp64 "
                                  "transcendental unit, not a contraction): achieved = 50 "
                                  "algorithmic flop/pair (SURVEY 8d) x pairs per launch / HIP-event "
-                                 "time. The recurrence kernel EXECUTES 8.61 VALU instr/pair "
+                                 "time. The recurrence kernel EXECUTES 8.56 VALU instr/pair "
                                  "(SQ_INSTS_VALU, profiles/r01_gls_scan_c2_pmc.csv), so frac exceeds the direct-evaluation roofline; "
                                  "valu_issue compares its issue rate with the measured v_fma_f64 "
                                  "ceiling at 2 waves/SIMD (profiles/r01_ubench_fp64_rate.txt)"},
