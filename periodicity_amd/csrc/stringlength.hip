@@ -428,32 +428,44 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                         make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
                 if (lane == 63) fine_w[kWFine] = incl;  // == cnt
                 wave_sync();
+                // Every sample knows its fine bucket [b0, b1) of the sorted range; its final slot is b0 +
+                // (number of bucket members that sort before it).  First pass: members are parked in
+                // arrival order; second pass: each sample counts its predecessors (a wave-uniform loop
+                // over the fullest bucket, <= kWInsertMax trips, no divergent per-lane sorting) and moves
+                // to its slot.  Ties in phase fall back to the sample index (stable sort).
+                unsigned eb0[kRPer], eb1[kRPer];
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) {
+                    const int s = lane + e * 64;
+                    eb0[e] = eb1[e] = 0u;
+                    if (s < cnt) {
+                        eb0[e] = fine_w[ef[e]];
+                        eb1[e] = fine_w[ef[e] + 1];
+                        keys_w[eb0[e] + er[e]] = ek[e];
+                        idx_w[eb0[e] + er[e]] = (IdxT)ei[e];
+                    }
+                }
+                wave_sync();
+                unsigned before[kRPer];
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) before[e] = 0u;
+                for (unsigned j = 0; __any(mx > j); ++j) {
+#pragma unroll
+                    for (int e = 0; e < kRPer; ++e) {
+                        const unsigned y = eb0[e] + j;
+                        if (y < eb1[e]) {
+                            const unsigned long long ky = keys_w[y];
+                            if (ky < ek[e] || (ky == ek[e] && (unsigned)idx_w[y] < ei[e])) ++before[e];
+                        }
+                    }
+                }
+                wave_sync();
 #pragma unroll
                 for (int e = 0; e < kRPer; ++e) {
                     const int s = lane + e * 64;
                     if (s < cnt) {
-                        const unsigned pos = fine_w[ef[e]] + er[e];
-                        keys_w[pos] = ek[e];
-                        idx_w[pos] = (IdxT)ei[e];
-                    }
-                }
-                wave_sync();
-                // finish: each lane orders its kCPL fine buckets by (bits, index)
-#pragma unroll
-                for (int q = 0; q < kCPL; ++q) {
-                    const int f = lane * kCPL + q;
-                    const int s0 = (int)fine_w[f], s1 = (int)fine_w[f + 1];
-                    for (int x = s0 + 1; x < s1; ++x) {
-                        const unsigned long long kx = keys_w[x];
-                        const IdxT ix = idx_w[x];
-                        int y = x - 1;
-                        while (y >= s0 && (keys_w[y] > kx || (keys_w[y] == kx && idx_w[y] > ix))) {
-                            keys_w[y + 1] = keys_w[y];
-                            idx_w[y + 1] = idx_w[y];
-                            --y;
-                        }
-                        keys_w[y + 1] = kx;
-                        idx_w[y + 1] = ix;
+                        keys_w[eb0[e] + before[e]] = ek[e];
+                        idx_w[eb0[e] + before[e]] = (IdxT)ei[e];
                     }
                 }
                 wave_sync();
