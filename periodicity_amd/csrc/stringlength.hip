@@ -24,8 +24,9 @@
 //        (a contiguous piece of order[], ~192-230 samples).  Each wave takes ranges r = wave,
 //        wave+16, ...: exact fold of its <= 256 samples (t[] is L2-resident), rank inside <= 256
 //        fine buckets (a power-of-two refinement of the coarse index, so both are exact and
-//        consistent; wave-private LDS counters), wave-level exclusive scan, placement,
-//        insertion-sort finish per fine bucket (mean occupancy < 1), segment sum with the previous
+//        consistent; wave-private LDS counters), wave-level exclusive scan, placement, then every
+//        sample counts the members of its fine bucket that sort before it (a wave-uniform loop
+//        over the fullest bucket, mean occupancy < 1) and moves to its slot, segment sum with the previous
 //        point taken from the neighbouring lane, and a 4-double summary (first/last point).
 //   P3b  ranges a wave cannot take (more than 256 samples, or a fine bucket fuller than 16:
 //        clustered phases from evenly sampled data at a commensurate period) are bitonic-sorted by
@@ -47,7 +48,7 @@ constexpr int kRCap = 256;       // samples a wave sorts by itself (4 per lane)
 constexpr int kRPer = kRCap / 64;
 constexpr int kWFine = 256;      // fine buckets per wave range
 constexpr int kCPL = kWFine / 64; // fine counters per lane (multiple of 4)
-constexpr int kWInsertMax = 16;  // fullest fine bucket the insertion-sort finish accepts
+constexpr int kWInsertMax = 16;  // fullest fine bucket the predecessor-counting finish accepts
 constexpr int kDCap = 2048;      // workgroup-level (deferred) LDS sort capacity
 constexpr int kMaxRanges = 1024; // ranges per slice
 constexpr int kMaxGrid = 1024;
