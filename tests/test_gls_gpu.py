@@ -380,3 +380,40 @@ def test_full_size_c4_on_one_gpu_both_paths():
     pick = np.unique(np.concatenate([rng.integers(0, nf, 6), [peak]]))
     exact = co.gls_power_exact(t, y, dy, f0 + delta * pick)
     assert np.max(np.abs(power[pick] - exact) / np.abs(exact)) <= RTOL
+
+
+_SHAPE_CHECK = """
+import numpy as np
+from oracle import c_oracle as co
+from periodicity_amd import _cabi
+rng = np.random.default_rng(5)
+for n, nf, fit_mean, with_dy in [(777, 3001, True, True), (130, 517, False, True), (64, 2049, True, False)]:
+    t = np.sort(rng.uniform(0, 80.0, n)) + 2454900.5
+    y = np.sin(2 * np.pi * t / 7.7) + 0.3 * rng.standard_normal(n)
+    dy = rng.uniform(0.1, 0.4, n) if with_dy else None
+    f0, delta = 0.004, 0.00037
+    freq = f0 + delta * np.arange(nf)
+    got = _cabi.gls_scan(t, y, dy, f0, delta, nf, fit_mean)
+    want = np.asarray(co.gls_power_exact(t, y, dy, freq, fit_mean))
+    ok = np.abs(want) > 1e-13 * np.nanmax(np.abs(want))
+    rel = np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok]))
+    assert rel < 1e-6, (n, nf, rel)
+    S, C = _cabi.trig_sums(t, y, f0, delta, nf)
+    Se, Ce = co.trig_sums_exact(t, y, freq)
+    assert np.max(np.abs(S - Se)) < 1e-9 * n and np.max(np.abs(C - Ce)) < 1e-9 * n
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("K,S", [(4, 1), (8, 1), (16, 1), (4, 2), (8, 4), (16, 4)])
+def test_every_tile_shape_is_exact(K, S):
+    """The launcher picks (K frequencies per thread, S waves per tile) from a cost model; every
+    instantiation must give Tier-E results, including the ones the model rarely picks.  The
+    override is read once per process, hence the child interpreter."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PDC_GLS_K=str(K), PDC_GLS_S=str(S))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _SHAPE_CHECK], env=env, cwd=root, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
