@@ -370,12 +370,21 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                 unsigned long long ek[kRPer];
                 unsigned ei[kRPer], er[kRPer];
                 int ef[kRPer];
+                // all gathers of t[] through the permutation first (one L2 round trip for the four of them,
+                // not one per element: the LDS atomics below would otherwise fence them apart)
+                double et[kRPer];
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) {
+                    const int s = lane + e * 64;
+                    ei[e] = s < cnt ? (unsigned)order[s_lo + s] : (unsigned)order[s_lo];
+                }
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) et[e] = a.t[ei[e]];
 #pragma unroll
                 for (int e = 0; e < kRPer; ++e) {
                     const int s = lane + e * 64;
                     if (s < cnt) {
-                        ei[e] = order[s_lo + s];
-                        const double phi = fold_phase(a.t[ei[e]], period);   // exact sort key
+                        const double phi = fold_phase(et[e], period);   // exact sort key
                         ek[e] = (unsigned long long)__double_as_longlong(phi);
                         int fb;
                         if (nbk <= kWFine) {
@@ -471,32 +480,38 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                 }
                 wave_sync();
                 // segments inside the range
+                // (same for m[]: the four gathers go out together)
+                double sphi[kRPer], sm[kRPer];
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) {
+                    const int j = lane + e * 64;
+                    const int jj = j < cnt ? j : 0;
+                    sphi[e] = __longlong_as_double((long long)keys_w[jj]);
+                    sm[e] = a.m[idx_w[jj]];
+                }
+                // the predecessor of a lane's point sits in the neighbouring lane; lane 0 takes it from
+                // lane 63 of the previous row (carried as a wave-uniform pair), so nothing is re-read
+                double carry_phi = 0.0, carry_m = 0.0, last_phi = 0.0, last_m = 0.0;
 #pragma unroll
                 for (int e = 0; e < kRPer; ++e) {
                     const int j = lane + e * 64;
                     const bool live = j < cnt;
-                    double phi = 0.0, mm = 0.0;
-                    if (live) {
-                        phi = __longlong_as_double((long long)keys_w[j]);
-                        mm = a.m[idx_w[j]];
-                    }
+                    const double phi = live ? sphi[e] : 0.0, mm = live ? sm[e] : 0.0;
                     double pphi = __shfl_up(phi, 1, 64);
                     double pm = __shfl_up(mm, 1, 64);
-                    bool ok = live;
-                    if (lane == 0 && live) {
-                        if (j > 0) {
-                            pphi = __longlong_as_double((long long)keys_w[j - 1]);
-                            pm = a.m[idx_w[j - 1]];
-                        } else {
-                            ok = false;
-                        }
+                    if (lane == 0) {
+                        pphi = carry_phi;
+                        pm = carry_m;
                     }
-                    if (ok) total += hypot(mm - pm, phi - pphi);
+                    if (live && j > 0) total += hypot(mm - pm, phi - pphi);
+                    carry_phi = __shfl(phi, 63, 64);
+                    carry_m = __shfl(mm, 63, 64);
+                    if (e == ((cnt - 1) >> 6)) {  // wave-uniform: the row that holds the range's last point
+                        last_phi = __shfl(phi, (cnt - 1) & 63, 64);
+                        last_m = __shfl(mm, (cnt - 1) & 63, 64);
+                    }
                 }
-                if (lane == 0)
-                    write_summary(r_base + r, __longlong_as_double((long long)keys_w[0]), a.m[idx_w[0]],
-                                  __longlong_as_double((long long)keys_w[cnt - 1]),
-                                  a.m[idx_w[cnt - 1]], cnt);
+                if (lane == 0) write_summary(r_base + r, sphi[0], sm[0], last_phi, last_m, cnt);
                 wave_sync();
             }
             __syncthreads();

@@ -10,7 +10,10 @@ for n, n_per in ((200_000, 2048), (1_000_000, 256)):
     y = np.sin(2 * np.pi * t / 13.7) + 0.1 * rng.standard_normal(n)
     m = so.stringlength_scale(y)
     periods = np.linspace(1.0, 100.0, n_per)
+    _cabi.stringlength_scan(t, m, periods[:8])      # first call pays for HIP start-up and the workspace
+    _cabi.stringlength_scan(t, m, periods)
     t0 = time.perf_counter(); ell = _cabi.stringlength_scan(t, m, periods); dt_sl = time.perf_counter() - t0
+    _cabi.pdm_scan(t, y, periods, 5, 2, np.var(y, ddof=1))
     t0 = time.perf_counter(); th = _cabi.pdm_scan(t, y, periods, 5, 2, np.var(y, ddof=1)); dt_pdm = time.perf_counter() - t0
     pick = np.array([0, n_per // 3, n_per - 1])
     e_sl = np.max(np.abs(ell[pick] - co.stringlength_scan(t, m, periods[pick])) / ell[pick])
