@@ -255,8 +255,19 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
             if (tid < 32) defer[tid] = 0u;
             if (tid == 0) s_fill = 0u;
             __syncthreads();
-            for (int64_t i = tid; i < n; i += kBlock)
-                atomicAdd(&hist[coarse_bucket(a.t[i], period, rp, thr)], 1u);
+            // (four coalesced loads in flight per thread: an LDS atomic between two loads would
+            // otherwise hold the second one back)
+            for (int64_t i0 = tid; i0 < n; i0 += 4 * kBlock) {
+                double tv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kBlock;
+                    tv[u] = i < n ? a.t[i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + (int64_t)u * kBlock < n) atomicAdd(&hist[coarse_bucket(tv[u], period, rp, thr)], 1u);
+            }
             __syncthreads();
             scan_buckets(hist, wave_tot);  // hist[b] = first sorted position of bucket b
             auto end_of = [&](int b) -> int64_t { return b + 1 < kBuckets ? (int64_t)hist[b + 1] : n; };
@@ -313,11 +324,23 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
             const int nranges = (slice_n + kWin - 1) / kWin;
             __syncthreads();  // every thread has read what it needs from the start offsets
             // ---- P2: permutation of the slice, grouped by coarse bucket, in LDS ------------------
-            for (int64_t i = tid; i < n; i += kBlock) {
-                const int b = coarse_bucket(a.t[i], period, rp, thr);
-                if (b >= b0 && b < b1) {
-                    const unsigned pos = atomicAdd(&hist[b], 1u);
-                    order[pos - (unsigned)consumed] = (IdxT)i;
+            for (int64_t i0 = tid; i0 < n; i0 += 4 * kBlock) {
+                double tv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kBlock;
+                    tv[u] = i < n ? a.t[i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kBlock;
+                    if (i < n) {
+                        const int b = coarse_bucket(tv[u], period, rp, thr);
+                        if (b >= b0 && b < b1) {
+                            const unsigned pos = atomicAdd(&hist[b], 1u);
+                            order[pos - (unsigned)consumed] = (IdxT)i;
+                        }
+                    }
                 }
             }
             __syncthreads();  // for b in [b0, b1): hist[b] = END position of bucket b
