@@ -466,14 +466,20 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                 // arrival order; second pass: each sample counts its predecessors (a wave-uniform loop
                 // over the fullest bucket, <= kWInsertMax trips, no divergent per-lane sorting) and moves
                 // to its slot.  Ties in phase fall back to the sample index (stable sort).
+                // (LDS reads of one step are issued together, ahead of the step's LDS writes: the compiler
+                // cannot reorder them across a possibly aliasing store itself)
                 unsigned eb0[kRPer], eb1[kRPer];
 #pragma unroll
                 for (int e = 0; e < kRPer; ++e) {
-                    const int s = lane + e * 64;
-                    eb0[e] = eb1[e] = 0u;
-                    if (s < cnt) {
-                        eb0[e] = fine_w[ef[e]];
-                        eb1[e] = fine_w[ef[e] + 1];
+                    const bool live = lane + e * 64 < cnt;
+                    const int f = live ? ef[e] : 0;
+                    eb0[e] = fine_w[f];
+                    eb1[e] = fine_w[f + 1];
+                    if (!live) eb0[e] = eb1[e] = 0u;
+                }
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) {
+                    if (lane + e * 64 < cnt) {
                         keys_w[eb0[e] + er[e]] = ek[e];
                         idx_w[eb0[e] + er[e]] = (IdxT)ei[e];
                     }
@@ -483,14 +489,18 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
 #pragma unroll
                 for (int e = 0; e < kRPer; ++e) before[e] = 0u;
                 for (unsigned j = 0; __any(mx > j); ++j) {
+                    unsigned long long ky[kRPer];
+                    unsigned iy[kRPer];
 #pragma unroll
                     for (int e = 0; e < kRPer; ++e) {
-                        const unsigned y = eb0[e] + j;
-                        if (y < eb1[e]) {
-                            const unsigned long long ky = keys_w[y];
-                            if (ky < ek[e] || (ky == ek[e] && (unsigned)idx_w[y] < ei[e])) ++before[e];
-                        }
+                        const unsigned y = eb0[e] + j < eb1[e] ? eb0[e] + j : 0u;
+                        ky[e] = keys_w[y];
+                        iy[e] = (unsigned)idx_w[y];
                     }
+#pragma unroll
+                    for (int e = 0; e < kRPer; ++e)
+                        if (eb0[e] + j < eb1[e] && (ky[e] < ek[e] || (ky[e] == ek[e] && iy[e] < ei[e])))
+                            ++before[e];
                 }
                 wave_sync();
 #pragma unroll
