@@ -490,17 +490,21 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                 for (int e = 0; e < kRPer; ++e) before[e] = 0u;
                 for (unsigned j = 0; __any(mx > j); ++j) {
                     unsigned long long ky[kRPer];
-                    unsigned iy[kRPer];
+                    bool tie = false;
 #pragma unroll
                     for (int e = 0; e < kRPer; ++e) {
-                        const unsigned y = eb0[e] + j < eb1[e] ? eb0[e] + j : 0u;
-                        ky[e] = keys_w[y];
-                        iy[e] = (unsigned)idx_w[y];
+                        const bool in = eb0[e] + j < eb1[e];
+                        ky[e] = keys_w[in ? eb0[e] + j : 0u];
+                        if (in && ky[e] < ek[e]) ++before[e];
+                        tie = tie || (in && ky[e] == ek[e] && j != er[e]);  // (slot er[e] is the sample itself)
                     }
+                    if (__any(tie)) {  // equal phases of two different samples (rare): the index decides
 #pragma unroll
-                    for (int e = 0; e < kRPer; ++e)
-                        if (eb0[e] + j < eb1[e] && (ky[e] < ek[e] || (ky[e] == ek[e] && iy[e] < ei[e])))
-                            ++before[e];
+                        for (int e = 0; e < kRPer; ++e) {
+                            const bool in = eb0[e] + j < eb1[e];
+                            if (in && ky[e] == ek[e] && (unsigned)idx_w[eb0[e] + j] < ei[e]) ++before[e];
+                        }
+                    }
                 }
                 wave_sync();
 #pragma unroll
