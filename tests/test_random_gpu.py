@@ -22,12 +22,28 @@ def exact_power_and_sensitivity(t, y, err, freq, fit_mean, psd, eps=1e-12, trial
     want = so.gls_epilogue(Sh, Ch, S2, C2, S, C, YY, fit_mean, psd, e)
     rng = np.random.default_rng(0)
     wobble = np.zeros_like(want)
+    # rank-deficient bins (e.g. two distinct time stamps under a three-parameter fit): the variance of
+    # one rotated basis function, CC or SS of spectral.py:124-127, vanishes together with its
+    # numerator and the term is 0/0 - whatever an implementation returns there is rounding noise
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tan2 = (S2 - 2 * S * C) / (C2 - (C * C - S * S)) if fit_mean else S2 / C2
+        c2w = 1 / np.sqrt(1 + tan2 * tan2)
+        s2w = tan2 * c2w
+        CC = 0.5 * (1 + C2 * c2w + S2 * s2w)
+        SS = 0.5 * (1 - C2 * c2w - S2 * s2w)
+        if fit_mean:
+            cw = np.sqrt(0.5) * np.sqrt(1 + c2w)
+            sw = np.sqrt(0.5) * np.sign(s2w) * np.sqrt(1 - c2w)
+            CC = CC - (C * cw + S * sw) ** 2
+            SS = SS - (S * cw - C * sw) ** 2
+        singular = ~(np.minimum(np.abs(CC), np.abs(SS)) > 1e-10)
     for _ in range(trials):
         moved = [None if a is None else a + eps * rng.choice([-1.0, 1.0], a.shape)
                  for a in (Sh, Ch, S2, C2, S, C)]
         other = so.gls_epilogue(*moved, YY, fit_mean, psd, e)
         with np.errstate(invalid="ignore"):
             wobble = np.fmax(wobble, np.abs(other - want))
+    wobble[singular] = np.inf
     return want, wobble
 
 
