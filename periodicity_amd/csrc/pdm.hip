@@ -151,9 +151,15 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
             add(k, val, inc);
         };
         int i = part * (kChunk / SPLIT);
+        // the pair of the next trip is read before this trip's histogram atomics go out (the compiler
+        // cannot move an LDS read above a possibly aliasing LDS atomic by itself); the staging area
+        // is followed by the histograms, so reading one pair past the chunk is harmless
+        double2 na = stage[i], nb2 = stage[i + 1];
         for (; i + 1 < i_end; i += 2) {
             // both fast bins first: two independent dependency chains back to back
-            const double2 ta = stage[i], tb = stage[i + 1];
+            const double2 ta = na, tb = nb2;
+            na = stage[i + 2];
+            nb2 = stage[i + 3];
             int ka, kb;
             double va = ta.y, vb = tb.y;
             unsigned ia = 1u, ib = 1u;
