@@ -14,7 +14,8 @@
 // One workgroup (1024 threads = 16 waves, one per CU) per trial period, persistent grid.  N
 // (phase, index) pairs do not fit in 160 KB of LDS, so the sort is two-level, linear-time, and
 // keeps only sample INDICES in LDS (16-bit when N < 65536, else 32-bit):
-//   P1   histogram of the phases over 2048 equal coarse buckets (LDS atomics) + exclusive scan.
+//   P1   histogram of the phases over 2048 (8192 for N >= 65536) equal coarse buckets (LDS atomics)
+//        + exclusive scan.
 //        Coarse buckets come from t * (1/period) with the PDM kernel's guard band: the exact IEEE
 //        division runs only when the shortcut lands within its own error of a bucket edge.
 //   P2   the permutation `order[]`, grouped by coarse bucket, for as many consecutive buckets as
@@ -40,7 +41,8 @@ using namespace pdc;
 
 namespace {
 
-constexpr int kBuckets = 2048;   // coarse buckets over [0, 1]
+constexpr int kBuckets = 2048;       // coarse buckets over [0, 1]
+constexpr int kBucketsLarge = 8192;  // ... for N >= 65536, so that a bucket still fits a wave's range
 constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / 64;
 constexpr int kWin = 192;        // sorted positions per range window
@@ -61,7 +63,6 @@ struct Lds {
     // the coarse histogram is only alive in P1/P2 and the wave scratch only in P3: they share LDS
     static constexpr int fixed = kWaves * wave_bytes + (kMaxRanges + 8) * 4 + 128;
     static constexpr int capacity = (kLdsTotal - fixed - 1024) / (int)sizeof(IdxT);  // slice size
-    static_assert(kWaves * wave_bytes >= kBuckets * 4, "histogram must fit in the wave scratch");
     static_assert(kWaves * wave_bytes >= kDCap * (8 + (int)sizeof(IdxT)), "deferred sort must fit");
     static_assert(capacity / kWin + 1 <= kMaxRanges, "range table too small");
     static_assert(capacity < 65536, "slice positions are stored as 16-bit offsets");
@@ -76,6 +77,8 @@ struct SlArgs {
     double *rsum;               // [grid][nr_pad][4]  range summaries
     int *rcnt;                  // [grid][nr_pad]
     int64_t n_pad, nr_pad;
+    unsigned *gorder;           // [grid][n_pad]  samples grouped by coarse bucket (several slices only)
+    unsigned *ghist;            // [grid][kBucketsLarge]  first sorted position of every coarse bucket
 };
 
 __device__ __forceinline__ double fold_phase(double t, double period) {
@@ -91,12 +94,13 @@ __device__ __forceinline__ int scaled_index(double phi, double scale, int last) 
     return (phi != phi) ? last : b;
 }
 
+template <int NB>
 __device__ __forceinline__ int coarse_bucket(double t, double period, double rp, double thr) {
     const double q = t * rp;
-    const double u = (q - __builtin_floor(q)) * (double)kBuckets;
+    const double u = (q - __builtin_floor(q)) * (double)NB;
     const int b = (int)u;
     if (__builtin_fabs((u - (double)b) - 0.5) < thr) return b;
-    return scaled_index(fold_phase(t, period), (double)kBuckets, kBuckets - 1);
+    return scaled_index(fold_phase(t, period), (double)NB, NB - 1);
 }
 
 // LDS traffic between lanes of ONE wave: order the accesses without a workgroup barrier.
@@ -106,10 +110,11 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Exclusive prefix sum of a[0..kBuckets) in place (2 entries per thread).
+// Exclusive prefix sum of a[0..NB) in place (NB / 1024 entries per thread).
+template <int NB>
 __device__ __forceinline__ void scan_buckets(unsigned *a, unsigned *wave_tot) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int per = kBuckets / kBlock;
+    constexpr int per = NB / kBlock;
     unsigned local[per], sum = 0;
 #pragma unroll
     for (int e = 0; e < per; ++e) {
@@ -190,12 +195,13 @@ __device__ __forceinline__ double segment_sum(KeyPtr K, IdxPtr I, int cnt, const
     return total;
 }
 
-template <typename IdxT>
+template <typename IdxT, int NB>
 __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
+    static_assert(kWaves * Lds<IdxT>::wave_bytes >= NB * 4, "histogram must fit in the wave scratch");
     using L = Lds<IdxT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char *wbuf = lds_raw;                                                  // P3a: per-wave scratch
-    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw);                         // P1/P2 alias [kBuckets]
+    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw);                         // P1/P2 alias [NB]
     unsigned long long *bkeys = reinterpret_cast<unsigned long long *>(lds_raw);    // P3b alias [kDCap]
     IdxT *bidx = reinterpret_cast<IdxT *>(bkeys + kDCap);                           // P3b alias [kDCap]
     unsigned short *bndb = reinterpret_cast<unsigned short *>(lds_raw + kWaves * L::wave_bytes);
@@ -211,6 +217,12 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
     unsigned *gi = a.gidx + (int64_t)blockIdx.x * a.n_pad;
     double *rsum = a.rsum + (int64_t)blockIdx.x * a.nr_pad * 4;
     int *rcnt = a.rcnt + (int64_t)blockIdx.x * a.nr_pad;
+    // more samples than one slice holds: the grouping by coarse bucket is done ONCE per period in
+    // global scratch and every slice copies its contiguous piece, instead of a histogram pass and a
+    // selection pass over all samples per slice
+    const bool multi = n > L::capacity;
+    unsigned *gorder = multi ? a.gorder + (int64_t)blockIdx.x * a.n_pad : nullptr;
+    unsigned *ghist = multi ? a.ghist + (int64_t)blockIdx.x * NB : nullptr;
 
     // max |t| once per workgroup (guard band of the bucket shortcut)
     double tmax = 0.0;
@@ -244,16 +256,14 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
     for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
         const double period = a.periods[p];
         const double rp = 1.0 / period;
-        const double thr = 0.5 - (double)kBuckets * (8.9e-16 * tmax * __builtin_fabs(rp) + 8.9e-16);
+        const double thr = 0.5 - (double)NB * (8.9e-16 * tmax * __builtin_fabs(rp) + 8.9e-16);
         double total = 0.0;    // this thread's share of the string length
         int r_base = 0;        // ranges emitted so far
         int64_t consumed = 0;  // samples (in sorted order) already accounted for
 
-        while (consumed < n) {
-            // ---- P1: coarse histogram of ALL samples + exclusive scan -------------------------
-            for (int b = tid; b < kBuckets; b += kBlock) hist[b] = 0u;
-            if (tid < 32) defer[tid] = 0u;
-            if (tid == 0) s_fill = 0u;
+        // ---- P1: coarse histogram of ALL samples + exclusive scan -----------------------------
+        auto histogram = [&]() {
+            for (int b = tid; b < NB; b += kBlock) hist[b] = 0u;
             __syncthreads();
             // (four coalesced loads in flight per thread: an LDS atomic between two loads would
             // otherwise hold the second one back)
@@ -266,15 +276,45 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (i0 + (int64_t)u * kBlock < n) atomicAdd(&hist[coarse_bucket(tv[u], period, rp, thr)], 1u);
+                    if (i0 + (int64_t)u * kBlock < n) atomicAdd(&hist[coarse_bucket<NB>(tv[u], period, rp, thr)], 1u);
             }
             __syncthreads();
-            scan_buckets(hist, wave_tot);  // hist[b] = first sorted position of bucket b
-            auto end_of = [&](int b) -> int64_t { return b + 1 < kBuckets ? (int64_t)hist[b + 1] : n; };
+            scan_buckets<NB>(hist, wave_tot);  // hist[b] = first sorted position of bucket b
+        };
+        if (multi) {
+            histogram();
+            for (int b = tid; b < NB; b += kBlock) ghist[b] = hist[b];
+            __syncthreads();
+            for (int64_t i0 = tid; i0 < n; i0 += 4 * kBlock) {
+                double tv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kBlock;
+                    tv[u] = i < n ? a.t[i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = i0 + (int64_t)u * kBlock;
+                    if (i < n) gorder[atomicAdd(&hist[coarse_bucket<NB>(tv[u], period, rp, thr)], 1u)] = (unsigned)i;
+                }
+            }
+            __syncthreads();
+        }
+
+        while (consumed < n) {
+            if (tid < 32) defer[tid] = 0u;
+            if (tid == 0) s_fill = 0u;
+            if (multi) {
+                for (int b = tid; b < NB; b += kBlock) hist[b] = ghist[b];
+                __syncthreads();
+            } else {
+                histogram();
+            }
+            auto end_of = [&](int b) -> int64_t { return b + 1 < NB ? (int64_t)hist[b + 1] : n; };
             // first bucket that still has unconsumed samples (consumed == its start)
             int b0;
             {
-                int l = 0, h = kBuckets - 1;
+                int l = 0, h = NB - 1;
                 while (l < h) {
                     const int mid = (l + h) >> 1;
                     if (end_of(mid) > consumed) h = mid; else l = mid + 1;
@@ -289,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                 while (P < cnt) P <<= 1;
                 __syncthreads();
                 for (int64_t i = tid; i < n; i += kBlock) {
-                    if (coarse_bucket(a.t[i], period, rp, thr) == b0) {
+                    if (coarse_bucket<NB>(a.t[i], period, rp, thr) == b0) {
                         const unsigned slot = atomicAdd(&s_fill, 1u);
                         gk[slot] = (unsigned long long)__double_as_longlong(fold_phase(a.t[i], period));
                         gi[slot] = (unsigned)i;
@@ -313,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
             // ---- slice = buckets [b0, b1) with at most `capacity` samples -------------------------
             int b1;
             {
-                int l = b0 + 1, h = kBuckets;
+                int l = b0 + 1, h = NB;
                 while (l < h) {
                     const int mid = (l + h + 1) >> 1;
                     if (end_of(mid - 1) - consumed <= L::capacity) l = mid; else h = mid - 1;
@@ -324,6 +364,10 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
             const int nranges = (slice_n + kWin - 1) / kWin;
             __syncthreads();  // every thread has read what it needs from the start offsets
             // ---- P2: permutation of the slice, grouped by coarse bucket, in LDS ------------------
+            if (multi) {
+                for (int sidx = tid; sidx < slice_n; sidx += kBlock) order[sidx] = (IdxT)gorder[consumed + sidx];
+                for (int b = b0 + tid; b < b1; b += kBlock) hist[b] = b + 1 < NB ? ghist[b + 1] : (unsigned)n;
+            } else
             for (int64_t i0 = tid; i0 < n; i0 += 4 * kBlock) {
                 double tv[4];
 #pragma unroll
@@ -335,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                 for (int u = 0; u < 4; ++u) {
                     const int64_t i = i0 + (int64_t)u * kBlock;
                     if (i < n) {
-                        const int b = coarse_bucket(tv[u], period, rp, thr);
+                        const int b = coarse_bucket<NB>(tv[u], period, rp, thr);
                         if (b >= b0 && b < b1) {
                             const unsigned pos = atomicAdd(&hist[b], 1u);
                             order[pos - (unsigned)consumed] = (IdxT)i;
@@ -382,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                 } else {
                     while ((nbk >> shift) + 1 > kWFine) ++shift;
                 }
-                const double fscale = (double)kBuckets * (double)g;
+                const double fscale = (double)NB * (double)g;
                 const int foff = lo_b * g;
                 const int flast = nbk <= kWFine ? nbk * g - 1 : (nbk >> shift);
 #pragma unroll
@@ -413,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
                         if (nbk <= kWFine) {
                             fb = scaled_index(phi, fscale, foff + flast) - foff;
                         } else {
-                            fb = (scaled_index(phi, (double)kBuckets, kBuckets - 1) - lo_b) >> shift;
+                            fb = (scaled_index(phi, (double)NB, NB - 1) - lo_b) >> shift;
                         }
                         fb = fb < 0 ? 0 : (fb > flast ? flast : fb);
                         ef[e] = fb;
@@ -652,13 +696,17 @@ int64_t grid_for(int64_t n_periods) { return n_periods < kMaxGrid ? n_periods : 
 // ranges: one per window of every slice, plus one per slice / oversized bucket
 int64_t range_slots(int64_t n) { return n / kWin + n / 8192 + 64; }
 
+// (the smaller of the two slice capacities: above it the kernel may need the per-period partition)
+bool may_need_partition(int64_t n) { return n > Lds<unsigned>::capacity; }
+
 }  // namespace
 
 extern "C" {
 
 int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) {
     if (n < 0 || n_periods < 0) return -1;
-    return grid_for(n_periods > 0 ? n_periods : 1) * (pad_pow2(n) * 12 + range_slots(n) * 36) + 512;
+    const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
+    return grid_for(n_periods > 0 ? n_periods : 1) * (pad_pow2(n) * 12 + range_slots(n) * 36 + partition) + 512;
 }
 
 int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
@@ -686,20 +734,22 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
     a.rsum = reinterpret_cast<double *>(a.gkeys + grid * a.n_pad);
     a.gidx = reinterpret_cast<unsigned *>(a.rsum + grid * a.nr_pad * 4);
     a.rcnt = reinterpret_cast<int *>(a.gidx + grid * a.n_pad);
+    a.gorder = reinterpret_cast<unsigned *>(a.rcnt + grid * a.nr_pad);
+    a.ghist = a.gorder + (may_need_partition(n) ? grid * a.n_pad : 0);
     hipStream_t st = (hipStream_t)stream;
     if (n < 65536) {
         using L = Lds<unsigned short>;
         const int64_t slice = n < L::capacity ? n : L::capacity;
         const size_t lds = (size_t)L::fixed + (size_t)((slice + 7) & ~(int64_t)7) * 2;
-        PDC_HIP(hipFuncSetAttribute((const void *)sl_scan_kernel<unsigned short>,
+        PDC_HIP(hipFuncSetAttribute((const void *)sl_scan_kernel<unsigned short, kBuckets>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(sl_scan_kernel<unsigned short>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+        hipLaunchKernelGGL((sl_scan_kernel<unsigned short, kBuckets>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     } else {
         using L = Lds<unsigned>;
         const size_t lds = (size_t)L::fixed + (size_t)L::capacity * 4;
-        PDC_HIP(hipFuncSetAttribute((const void *)sl_scan_kernel<unsigned>,
+        PDC_HIP(hipFuncSetAttribute((const void *)sl_scan_kernel<unsigned, kBucketsLarge>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(sl_scan_kernel<unsigned>, dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+        hipLaunchKernelGGL((sl_scan_kernel<unsigned, kBucketsLarge>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     }
     PDC_HIP(hipGetLastError());
     return PDC_OK;
