@@ -19,7 +19,8 @@
 //        Coarse buckets come from t * (1/period) with the PDM kernel's guard band: the exact IEEE
 //        division runs only when the shortcut lands within its own error of a bucket edge.
 //   P2   the permutation `order[]`, grouped by coarse bucket, for as many consecutive buckets as
-//        fit in LDS (a "slice"; N <= ~50k samples need one slice, larger N repeat P1-P3 per slice).
+//        fit in LDS (a "slice"; N <= ~50k samples need one slice; for larger N the grouping is done
+//        once per period in global scratch and every slice copies its contiguous piece).
 //   P3a  WAVE-AUTONOMOUS ranges, no workgroup barrier: the slice's sorted positions are cut into
 //        windows of 192; range r = the coarse buckets whose first sorted position falls in window r
 //        (a contiguous piece of order[], ~192-230 samples).  Each wave takes ranges r = wave,
