@@ -132,8 +132,8 @@ def test_stringlength_clusters_take_the_scratch_path():
 
 
 def test_stringlength_large_n_runs_in_phase_slices():
-    # more samples than one LDS slice holds (50480 16-bit / 23192 32-bit indices): the kernel
-    # repeats histogram + permutation + sort per slice of the phase axis
+    # more samples than one LDS slice holds (50480 16-bit / 23192 32-bit indices): the kernel groups
+    # the samples by coarse bucket once per period in global scratch and sorts slice after slice
     t6, y6 = synth(60_000, 78)                              # 16-bit indices, two slices
     m6 = so.stringlength_scale(y6)
     p6 = np.array([0.9, 13.7, 4000.0])
