@@ -14,6 +14,10 @@
 // [bin][thread] (bank = lane: conflict-free for any mix of bins) and updates it with one
 // ds_add_f64 + one ds_add_u32 per pair.
 //
+// With few trial periods and many samples (the reference's default grid has 1000 periods) the
+// samples are split over blockIdx.y as well: statistics once (pdm_stats_kernel, two passes), one
+// partial histogram per slice of the samples, pdm_finish_kernel adds them in slice order.
+//
 // Bin membership must be bit-identical to numpy's: phi = (t/period) % 1 with an IEEE division
 // and Python modulo, compared against the doubles k/m0.  The fast path uses t * (1/period) and
 // accepts its bin only when phi is provably farther from every edge than the worst-case error of
@@ -21,11 +25,15 @@
 // division and explicit edge comparisons.
 #include "pdc_internal.h"
 
+#include <cstdlib>
+
 using namespace pdc;
 
 namespace {
 
 constexpr int kChunk = 128;
+
+constexpr int kStatParts = 512;  // partial sums of the sample statistics (split mode)
 
 struct PdmArgs {
     const double *t, *x, *periods;
@@ -33,6 +41,17 @@ struct PdmArgs {
     int nb, nc;
     double sigma;
     double *theta;
+    // split mode (few trial periods, many samples): workgroup (g, z) bins the samples
+    // [z * z_len, (z + 1) * z_len) of period group g and leaves its histograms in `psum`/`pcnt`
+    // ([z][bin][p_pad]) and `pq` ([z][2][p_pad] = sum x'^2 of the overflow bin / of NaN phases);
+    // pdm_finish_kernel adds them up in z order.  `stat` = [3][kStatParts] partial sum x,
+    // max |t|, sum (x - mean)^2 from pdm_stats_kernel.
+    double *psum = nullptr;
+    unsigned *pcnt = nullptr;
+    double *pq = nullptr;
+    double *stat = nullptr;
+    int64_t z_len = 0, p_pad = 0;
+    int n_z = 1, n_stat = 0;
 };
 
 template <int BLOCK>
@@ -49,12 +68,85 @@ __device__ __forceinline__ double block_reduce(double v, double *red, bool take_
     return r;
 }
 
+// Fixed-order fold of `count` partial values by a whole workgroup (identical in every workgroup).
+template <int BLOCK>
+__device__ __forceinline__ double fold_parts(const double *p, int count, double *red, bool take_max) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < count; i += BLOCK) v = take_max ? (p[i] > v ? p[i] : v) : v + p[i];
+    return block_reduce<BLOCK>(v, red, take_max);
+}
+
+// Sample statistics for the split mode, grid-wide: pass 0 leaves partial sum x and max |t|, pass 1
+// (after re-reducing pass 0's partials to the mean) partial sum (x - mean)^2.
+__global__ __launch_bounds__(256) void pdm_stats_kernel(PdmArgs a, int pass) {
+    __shared__ double red[4];
+    double mean = 0.0;
+    if (pass == 1) mean = fold_parts<256>(a.stat, a.n_stat, red, false) / (double)a.n;
+    double acc = 0.0, tmax = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+        if (pass == 0) {
+            acc += a.x[i];
+            const double at = __builtin_fabs(a.t[i]);
+            tmax = at > tmax ? at : tmax;
+        } else {
+            const double d = a.x[i] - mean;
+            acc += d * d;
+        }
+    }
+    acc = block_reduce<256>(acc, red, false);
+    if (pass == 0) tmax = block_reduce<256>(tmax, red, true);
+    if (threadIdx.x == 0) {
+        if (pass == 0) {
+            a.stat[blockIdx.x] = acc;
+            a.stat[kStatParts + blockIdx.x] = tmax;
+        } else {
+            a.stat[2 * kStatParts + blockIdx.x] = acc;
+        }
+    }
+}
+
+// theta from one period's fine-bin histogram (phase.py:137-148); sum_at / cnt_at read bin b.
+template <typename SumAt, typename CntAt>
+__device__ __forceinline__ double theta_from_bins(SumAt sum_at, CntAt cnt_at, int m0, int nc, double q_total,
+                                                  double q_nan, double q_over, double sigma) {
+    double num = (double)nc * (q_total - q_nan) - q_over;
+    long long n_sum = 0;
+    int good = 0;
+    for (int k = 0; k < m0; ++k) {
+        double s = 0.0;
+        long long c = 0;
+        for (int j = 0; j < nc; ++j) {
+            int b = k + j;
+            if (b >= m0) {
+                if (b == m0) {  // [1.0, (m0+1)/m0): only phi == 1.0 can live here
+                    s += sum_at(m0);
+                    c += cnt_at(m0);
+                }
+                b -= m0;
+            }
+            s += sum_at(b);
+            c += cnt_at(b);
+        }
+        if (c > 1) {
+            num -= s * s / (double)c;
+            n_sum += c;
+            ++good;
+        } else if (c == 1) {
+            num -= s * s;  // a singleton contributes x^2 - x^2 = 0 and is not a "good" bin
+        }
+    }
+    // no cover with two or more members: the reference divides an empty sum by zero -> NaN
+    // (phase.py:147); here `num` would only hold the rounding residue of the singletons
+    return good == 0 ? __builtin_nan("") : (num / (double)(n_sum - good)) / sigma;
+}
+
 // SPLIT waves of a workgroup share one group of 64 trial periods (lane = period) and split every
 // staged chunk of samples between them, so that a grid of ~1e5 periods still puts several waves on
 // every SIMD (the loop is a chain of LDS read -> ALU -> LDS atomic: it needs wave-level parallelism
 // to hide latency).  Each thread keeps its own private histogram; the SPLIT partial histograms of
 // a period are summed in a fixed order at the end.
-template <int BLOCK, int SPLIT>
+// ZS: split mode (the samples are split over blockIdx.y as well, see PdmArgs).
+template <int BLOCK, int SPLIT, bool ZS = false>
 __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int m0 = a.nb * a.nc;
@@ -75,20 +167,28 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     }
 
     // mean of x, total sum of squares about it, and max |t| (identical in every workgroup)
-    double acc = 0.0, tmax = 0.0;
-    for (int64_t i = tid; i < a.n; i += BLOCK) {
-        acc += a.x[i];
-        const double at = __builtin_fabs(a.t[i]);
-        tmax = at > tmax ? at : tmax;
+    double mean, tmax, q_total;
+    if (ZS) {
+        mean = fold_parts<BLOCK>(a.stat, a.n_stat, red, false) / (double)a.n;
+        tmax = fold_parts<BLOCK>(a.stat + kStatParts, a.n_stat, red, true);
+        q_total = fold_parts<BLOCK>(a.stat + 2 * kStatParts, a.n_stat, red, false);
+    } else {
+        double acc = 0.0;
+        tmax = 0.0;
+        for (int64_t i = tid; i < a.n; i += BLOCK) {
+            acc += a.x[i];
+            const double at = __builtin_fabs(a.t[i]);
+            tmax = at > tmax ? at : tmax;
+        }
+        mean = block_reduce<BLOCK>(acc, red, false) / (double)a.n;
+        tmax = block_reduce<BLOCK>(tmax, red, true);
+        acc = 0.0;
+        for (int64_t i = tid; i < a.n; i += BLOCK) {
+            const double d = a.x[i] - mean;
+            acc += d * d;
+        }
+        q_total = block_reduce<BLOCK>(acc, red, false);
     }
-    const double mean = block_reduce<BLOCK>(acc, red, false) / (double)a.n;
-    tmax = block_reduce<BLOCK>(tmax, red, true);
-    acc = 0.0;
-    for (int64_t i = tid; i < a.n; i += BLOCK) {
-        const double d = a.x[i] - mean;
-        acc += d * d;
-    }
-    const double q_total = block_reduce<BLOCK>(acc, red, false);
 
     constexpr int PERIODS = BLOCK / SPLIT;       // trial periods per workgroup
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), part = wave % SPLIT;  // scalar
@@ -105,14 +205,17 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     double q_over = 0.0;           // sum x'^2 of samples in the overflow bin
     double q_nan = 0.0;            // sum x'^2 of samples whose phase is NaN (they are in no cover)
 
-    for (int64_t base = 0; base < a.n; base += kChunk) {
+    // this workgroup's samples: all of them, or slice blockIdx.y of them in split mode
+    const int64_t s_begin = ZS ? (int64_t)blockIdx.y * a.z_len : 0;
+    const int64_t s_end = ZS ? (s_begin + a.z_len < a.n ? s_begin + a.z_len : a.n) : a.n;
+    for (int64_t base = s_begin; base < s_end; base += kChunk) {
         __syncthreads();
         for (int i = tid; i < kChunk; i += BLOCK) {
             const int64_t g = base + i;
-            stage[i] = g < a.n ? make_double2(a.t[g], a.x[g] - mean) : make_double2(0.0, 0.0);
+            stage[i] = g < s_end ? make_double2(a.t[g], a.x[g] - mean) : make_double2(0.0, 0.0);
         }
         __syncthreads();
-        const int cnt = (int)((a.n - base) < kChunk ? (a.n - base) : kChunk);
+        const int cnt = (int)((s_end - base) < kChunk ? (s_end - base) : kChunk);
         const int i_end = cnt < (part + 1) * (kChunk / SPLIT) ? cnt : (part + 1) * (kChunk / SPLIT);
         // two samples per trip: two independent read -> bin -> atomic chains in flight per wave.
         // Fast path: 7 VALU ops (v_fract_f64 twice); the histogram update is unconditional.
@@ -192,36 +295,50 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         }
     }
     if (part != 0 || pidx >= a.n_periods) return;
-    // covers: phase.py:137-147
-    double num = (double)a.nc * (q_total - q_nan) - q_over;
-    long long n_sum = 0;
-    int good = 0;
-    for (int k = 0; k < m0; ++k) {
-        double s = 0.0;
-        long long c = 0;
-        for (int j = 0; j < a.nc; ++j) {
-            int b = k + j;
-            if (b >= m0) {
-                if (b == m0) {  // [1.0, (m0+1)/m0): only phi == 1.0 can live here
-                    s += hsum[m0 * BLOCK + tid];
-                    c += hcnt[m0 * BLOCK + tid];
-                }
-                b -= m0;
-            }
-            s += hsum[b * BLOCK + tid];
-            c += hcnt[b * BLOCK + tid];
+    if (ZS) {  // split mode: leave the histogram of this slice of the samples for pdm_finish_kernel
+        const int64_t z = blockIdx.y;
+        for (int k = 0; k < nbins; ++k) {
+            a.psum[(z * nbins + k) * a.p_pad + pidx] = hsum[k * BLOCK + tid];
+            a.pcnt[(z * nbins + k) * a.p_pad + pidx] = hcnt[k * BLOCK + tid];
         }
-        if (c > 1) {
-            num -= s * s / (double)c;
-            n_sum += c;
-            ++good;
-        } else if (c == 1) {
-            num -= s * s;  // a singleton contributes x^2 - x^2 = 0 and is not a "good" bin
-        }
+        a.pq[(z * 2 + 0) * a.p_pad + pidx] = q_over;
+        a.pq[(z * 2 + 1) * a.p_pad + pidx] = q_nan;
+        return;
     }
-    // no cover with two or more members: the reference divides an empty sum by zero -> NaN
-    // (phase.py:147); here `num` would only hold the rounding residue of the singletons
-    a.theta[pidx] = good == 0 ? __builtin_nan("") : (num / (double)(n_sum - good)) / a.sigma;
+    a.theta[pidx] = theta_from_bins([&](int b) { return hsum[b * BLOCK + tid]; },
+                                    [&](int b) { return (long long)hcnt[b * BLOCK + tid]; }, m0, a.nc, q_total,
+                                    q_nan, q_over, a.sigma);
+}
+
+// Split mode, last step: one thread per trial period adds the slices' histograms in slice order
+// (LDS laid out like the scan kernel's, [bin][thread]) and evaluates theta.
+__global__ __launch_bounds__(64) void pdm_finish_kernel(PdmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ double red[1];
+    const int m0 = a.nb * a.nc, nbins = m0 + 1, tid = threadIdx.x;
+    double *hsum = reinterpret_cast<double *>(lds_raw);                     // [nbins][64]
+    long long *hcnt = reinterpret_cast<long long *>(hsum + (size_t)nbins * 64);  // [nbins][64]
+    const double q_total = fold_parts<64>(a.stat + 2 * kStatParts, a.n_stat, red, false);
+    const int64_t pidx = (int64_t)blockIdx.x * 64 + tid;
+    if (pidx >= a.n_periods) return;
+    double q_over = 0.0, q_nan = 0.0;
+    for (int k = 0; k < nbins; ++k) {
+        double sum = 0.0;
+        long long cnt = 0;
+        for (int64_t z = 0; z < a.n_z; ++z) {
+            sum += a.psum[(z * nbins + k) * a.p_pad + pidx];
+            cnt += a.pcnt[(z * nbins + k) * a.p_pad + pidx];
+        }
+        hsum[k * 64 + tid] = sum;
+        hcnt[k * 64 + tid] = cnt;
+    }
+    for (int64_t z = 0; z < a.n_z; ++z) {
+        q_over += a.pq[(z * 2 + 0) * a.p_pad + pidx];
+        q_nan += a.pq[(z * 2 + 1) * a.p_pad + pidx];
+    }
+    a.theta[pidx] = theta_from_bins([&](int b) { return hsum[b * 64 + tid]; },
+                                    [&](int b) { return hcnt[b * 64 + tid]; }, m0, a.nc, q_total, q_nan, q_over,
+                                    a.sigma);
 }
 
 size_t lds_bytes(int m0, int block) {
@@ -247,6 +364,50 @@ int pdc_pdm_scan_dev(int device, void *stream, const double *d_t, const double *
     PdmArgs a{d_t, d_x, d_periods, n, n_periods, nb, nc, sigma, d_theta};
     const int m0 = nb * nc;
     hipStream_t st = (hipStream_t)stream;
+    // Few trial periods and many samples (the reference's default grid has 1000 periods): lanes are
+    // periods, so the period grid alone would leave most of the chip idle.  Split the SAMPLES over
+    // blockIdx.y as well: statistics once (two short grid-wide launches), partial histograms per
+    // slice, one finishing launch that adds them in slice order.  PDC_PDM_SPLIT=0 disables it.
+    static const int env_split = [] { const char *e = getenv("PDC_PDM_SPLIT"); return e ? atoi(e) : -1; }();
+    const int64_t groups0 = (n_periods + 63) / 64;
+    const int nbins = m0 + 1;
+    if (env_split != 0 && groups0 * 4 < 1024 && n >= 32 * kChunk && lds_bytes(m0, 256) <= 150 * 1024 &&
+        (size_t)nbins * 64 * 16 <= 150 * 1024) {
+        int64_t n_z = (2048 + groups0 * 4 - 1) / (groups0 * 4);
+        const int64_t max_z = n / (8 * kChunk);
+        n_z = n_z < max_z ? n_z : max_z;
+        const int64_t z_len = ((n + n_z - 1) / n_z + kChunk - 1) / kChunk * kChunk;
+        n_z = (n + z_len - 1) / z_len;
+        if (n_z > 1) {
+            a.p_pad = groups0 * 64;
+            a.n_z = (int)n_z;
+            a.z_len = z_len;
+            a.n_stat = (int)((n + 1023) / 1024 < kStatParts ? (n + 1023) / 1024 : kStatParts);
+            const size_t stat_b = (size_t)3 * kStatParts * 8;
+            const size_t psum_b = (size_t)n_z * nbins * a.p_pad * 8;
+            const size_t pq_b = (size_t)n_z * 2 * a.p_pad * 8;
+            const size_t pcnt_b = (size_t)n_z * nbins * a.p_pad * 4;
+            char *scratch = nullptr;
+            PDC_HIP(hipMallocAsync((void **)&scratch, stat_b + psum_b + pq_b + pcnt_b, st));
+            a.stat = reinterpret_cast<double *>(scratch);
+            a.psum = reinterpret_cast<double *>(scratch + stat_b);
+            a.pq = reinterpret_cast<double *>(scratch + stat_b + psum_b);
+            a.pcnt = reinterpret_cast<unsigned *>(scratch + stat_b + psum_b + pq_b);
+            hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 0);
+            hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 1);
+            const size_t lds = lds_bytes(m0, 256);
+            PDC_HIP(hipFuncSetAttribute((const void *)pdm_scan_kernel<256, 4, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((pdm_scan_kernel<256, 4, true>), dim3((unsigned)groups0, (unsigned)n_z), dim3(256), lds, st, a);
+            const size_t lds_f = (size_t)nbins * 64 * 16;
+            PDC_HIP(hipFuncSetAttribute((const void *)pdm_finish_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+            hipLaunchKernelGGL(pdm_finish_kernel, dim3((unsigned)groups0), dim3(64), lds_f, st, a);
+            PDC_HIP(hipGetLastError());
+            PDC_HIP(hipFreeAsync(scratch, st));
+            return PDC_OK;
+        }
+    }
     if (lds_bytes(m0, 256) <= 150 * 1024) {
         const size_t lds = lds_bytes(m0, 256);
         // waves = ceil(P/64) * SPLIT; aim at >= 4 waves per SIMD (4096 on the chip)

@@ -211,11 +211,47 @@ def test_period_grid_sharded_over_device_slots():
         periods = np.linspace(0.7, 30.0, n_periods)
         one = _cabi.pdm_scan(t, x, periods, 5, 2, np.var(x, ddof=1))
         many = _cabi.pdm_scan(t, x, periods, 5, 2, np.var(x, ddof=1), devices=(0, 0, 0))
-        assert np.array_equal(one, many, equal_nan=True)
+        # (a shorter period grid may split the samples over more workgroups: same bins and counts,
+        # sums added in another order)
+        np.testing.assert_allclose(many, one, rtol=1e-12)
         one = _cabi.stringlength_scan(t, m, periods)
         many = _cabi.stringlength_scan(t, m, periods, devices=(0, 0, 0))
         assert np.array_equal(one, many)
     pdm = PDM(p_min=0.7, p_max=30.0, n_periods=300, devices=(0, 0))
-    assert np.array_equal(pdm(TSeries(t, x)).values, PDM(p_min=0.7, p_max=30.0, n_periods=300)(TSeries(t, x)).values)
+    np.testing.assert_allclose(pdm(TSeries(t, x)).values,
+                               PDM(p_min=0.7, p_max=30.0, n_periods=300)(TSeries(t, x)).values, rtol=1e-12)
     sl = StringLength(n_periods=300, devices=(0, 0))
     assert np.array_equal(sl(TSeries(t, x)).values, StringLength(n_periods=300)(TSeries(t, x)).values)
+
+
+def test_pdm_few_periods_many_samples_split_the_samples():
+    """The reference's default grid has 1000 trial periods: with lanes = periods the chip would idle,
+    so the samples are split over workgroups as well (statistics once, partial histograms, one
+    finishing launch).  Same thetas as the C oracle and as the unsplit kernel (child process with
+    PDC_PDM_SPLIT=0), for odd sizes, NaNs in the data and a grid of one period."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(31)
+    for n, n_periods, nb, nc in [(50_001, 1000, 5, 2), (9_999, 7, 10, 3), (4_100, 1, 5, 2), (20_000, 130, 4, 1)]:
+        t = np.sort(rng.uniform(0, 300.0, n)) - 20.0
+        x = np.sin(2 * np.pi * t / 6.3) + 0.3 * rng.standard_normal(n)
+        periods = np.linspace(0.9, 40.0, n_periods)
+        got = _cabi.pdm_scan(t, x, periods, nb, nc, np.var(x, ddof=1))
+        want = co.pdm_scan(t, x, periods, nb, nc)
+        np.testing.assert_allclose(got, want, rtol=1e-9)
+    x[5] = np.nan
+    got = _cabi.pdm_scan(t, x, periods, 4, 1, 1.0)
+    assert np.all(np.isnan(got))          # a NaN sample poisons every bin sum it lands in and the mean
+    code = ("import numpy as np; from periodicity_amd import _cabi; rng = np.random.default_rng(31); n = 50001;"
+            "t = np.sort(rng.uniform(0, 300.0, n)) - 20.0; x = np.sin(2 * np.pi * t / 6.3) + 0.3 * rng.standard_normal(n);"
+            "p = np.linspace(0.9, 40.0, 1000); a = _cabi.pdm_scan(t, x, p, 5, 2, np.var(x, ddof=1)); np.save('/tmp/pdm_unsplit.npy', a)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PDC_PDM_SPLIT="0"), cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rng = np.random.default_rng(31)
+    n = 50_001
+    t = np.sort(rng.uniform(0, 300.0, n)) - 20.0
+    x = np.sin(2 * np.pi * t / 6.3) + 0.3 * rng.standard_normal(n)
+    split = _cabi.pdm_scan(t, x, np.linspace(0.9, 40.0, 1000), 5, 2, np.var(x, ddof=1))
+    np.testing.assert_allclose(split, np.load("/tmp/pdm_unsplit.npy"), rtol=1e-12)
