@@ -1,23 +1,36 @@
 """Headline benchmark: fp64 generalized Lomb-Scargle, N=1e5 unevenly sampled points x 1e6 trial
 frequencies per GPU (BASELINE.json configs[1]); prints ONE JSON line on rank 0.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]                  # one process, N devices
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # one rank per GPU
 
-A step = one pass of the hot path over resident inputs: ``pdc_gls_scan_dev`` (weights prologue +
-direct-sum scan + fused epilogue) writing power[nf] in HBM; with N > 1 ranks each rank scans its
-own contiguous slab of an N-times longer grid (weak scaling, samples replicated) and the slabs are
-all-gathered with RCCL so every rank ends the step holding the whole power array; the gather of
-step i runs on RCCL's stream while the compute stream already scans step i+1 (double-buffered
-outputs, everything drained before the clock stops).
+A step = one pass of the hot path over resident inputs: the weights prologue + direct-sum scan + fused
+epilogue (``pdc_gls_scan_dev``) writing power[nf] in HBM.  With N > 1 each GPU scans its own
+contiguous slab of an N-times longer grid (weak scaling, samples replicated) and the slabs are
+all-gathered with RCCL so every GPU ends the step holding the whole power array; the gather of step
+i overlaps the scan of step i+1 (double-buffered outputs, everything drained before the clock stops).
 
-The product path is the C ABI (libperiodicity_hip.so) — torch is used only under torchrun, for
-rendezvous, the barrier and the RCCL all-gather.  ``oracle/`` is touched only by the
-``cpu_baseline`` leg and the spot check, never inside the timed region.
+Two ways to drive N GPUs, same kernels, same collective:
+  * plain ``python bench.py --gpus N``: ONE process, N devices, through the C ABI's persistent plan
+    (``pdc_gls_plan_*``: hipSetDevice + two streams per device, ncclCommInitAll, grouped
+    ncclAllGather) - no torch anywhere;
+  * under ``torch.distributed.run`` (WORLD_SIZE > 1 in the environment): one rank per GPU, torch is
+    used for rendezvous, the barrier and the RCCL all-gather only.
+
+The product path is the C ABI (libperiodicity_hip.so).  ``oracle/`` is touched only by the
+``cpu_baseline`` leg, after the clock has stopped.
+
+``roofline.frac`` is the EXECUTED fp64 vector-issue fraction: VALU wave-instructions per launch
+(rocprofv3 SQ_INSTS_VALU, from profiles/r02_pmc_summary.json, which tools/pmc_summary.py wrote for
+the kernel sources whose hash it records - a summary of other sources is refused) x 4 cycles / 1024
+SIMDs / 2.4 GHz / the HIP-event time of this run.  The 50-flop-per-pair figure of SURVEY.md 8d is
+reported beside it as ``algorithmic`` (it exceeds the direct-evaluation roofline because the kernel
+advances sin/cos by rotation recurrences instead of evaluating them per pair).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -28,16 +41,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_PAIR = 50.0          # algorithmic fp64 flop per (sample, frequency) pair
+FLOP_PER_PAIR = 50.0            # algorithmic fp64 flop per (sample, frequency) pair
 PEAK_FP64_VECTOR_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz (MI355X, spec)
-VALU_INSTR_PER_PAIR = 8.56      # gls_scan_kernel<16,0,2>: SQ_INSTS_VALU 1.338e10 per launch / 1.5625e9 wave-pairs
-FP64_ISSUE_CEILING_NS = 1.93    # tools/ubench/fp64_rate.hip: ns per wave-instr per SIMD, 2 waves/SIMD
+SIMDS, CLOCK_HZ, FP64_ISSUE_CYCLES = 1024, 2.4e9, 4
+PDM_FLOP_PER_PAIR = 40.0
+SL_MODEL_BYTES_PER_PAIR = 48.0  # HBM bucket-pass model
+L2_GATHER_PER_S = 2.7e11        # tools/ubench/gather_rate.hip (profiles/r02_ubench_gather_rate.txt)
+HBM_PEAK_TBS = 8.0
 N_SAMPLES = 100_000
 NF_PER_GPU = 1_000_000
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 
 def synth_curve(n, k=2, period=37.3):
-    """SURVEY.md §8d synthetic light curve (draw order t, dy, noise)."""
+    """SURVEY.md 8d synthetic light curve (draw order t, dy, noise)."""
     rng = np.random.default_rng(20241008 + k)
     t = np.sort(rng.uniform(0, float(n), n))
     dy = rng.uniform(0.05, 0.2, n)
@@ -53,6 +70,52 @@ def throughput_grid(t, nf):
         if freq.size == nf:
             return freq, df, fmin
     raise AssertionError((freq.size, nf))
+
+
+def source_hash():
+    """sha256 over the kernel sources; tools/pmc_summary.py stores the same value."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "periodicity_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_for(kernel_substr, measured_ms):
+    """Counters of the profiled kernel whose name contains `kernel_substr` and whose profiled duration
+    is closest to this run's; (None, reason) when the summary is absent or belongs to other sources."""
+    if not os.path.isfile(PMC_SUMMARY):
+        return None, "profiles/r02_pmc_summary.json is missing"
+    summ = json.load(open(PMC_SUMMARY))
+    if summ.get("src_sha") != source_hash():
+        return None, (f"profiles/r02_pmc_summary.json was collected for kernel sources "
+                      f"{summ.get('src_sha')}, this tree is {source_hash()}: refused as stale")
+    best = None
+    for name, k in summ.get("kernels", {}).items():
+        if kernel_substr in name and "SQ_INSTS_VALU" in k and k.get("ms"):
+            d = abs(k["ms"] - measured_ms) / measured_ms
+            if best is None or d < best[0]:
+                best = (d, name, k)
+    if best is None or best[0] > 0.25:
+        return None, f"no profiled '{kernel_substr}' launch within 25% of {measured_ms:.3f} ms"
+    return dict(best[2], name=best[1]), None
+
+
+def valu_issue_block(kernel_substr, kernel_ms):
+    k, why = pmc_for(kernel_substr, kernel_ms)
+    if k is None:
+        return None, why
+    busy_s = k["SQ_INSTS_VALU"] * FP64_ISSUE_CYCLES / SIMDS / CLOCK_HZ
+    out = {"kernel": k["name"], "valu_wave_instr_per_launch": k["SQ_INSTS_VALU"],
+           "frac": round(busy_s / (kernel_ms * 1e-3), 4),
+           "profiled_ms": k["ms"], "source": "profiles/r02_pmc_summary.json"}
+    for key in ("hbm_bytes", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_LDS_BANK_CONFLICT",
+                "SQ_LDS_IDX_ACTIVE", "TCP_TCC_READ_REQ_sum"):
+        if key in k:
+            out[key] = k[key]
+    return out, None
 
 
 def cpu_baseline(t, y, dy, freq, df, fmin):
@@ -87,24 +150,166 @@ def cpu_baseline(t, y, dy, freq, df, fmin):
     return base, p_fft
 
 
+class EventTimer:
+    """HIP events on the stream the kernels are launched on."""
+
+    def __init__(self, lib, cabi, dev, stream):
+        self.lib, self.cabi, self.dev, self.stream = lib, cabi, dev, stream
+        self.ev = [self._new(), self._new()]
+
+    def _new(self):
+        e = C.c_void_p()
+        self.cabi.check(self.lib.pdc_event_create(self.dev, C.byref(e)))
+        return e.value
+
+    def ms(self, fn, reps=3, warm=1):
+        for _ in range(warm):
+            fn()
+        out = []
+        for _ in range(reps):
+            self.cabi.check(self.lib.pdc_event_record(self.dev, self.ev[0], self.stream))
+            fn()
+            self.cabi.check(self.lib.pdc_event_record(self.dev, self.ev[1], self.stream))
+            ms = C.c_float()
+            self.cabi.check(self.lib.pdc_event_elapsed_ms(self.dev, self.ev[0], self.ev[1], C.byref(ms)))
+            out.append(ms.value)
+        return float(np.median(out))
+
+
+def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2):
+    """Kernel-level numbers of the other single-GPU configs (BASELINE.json configs[2], [4]) and the
+    PCIe-inclusive rate of the headline config, so that they appear in the driver's record."""
+    tm = EventTimer(lib, cabi, dev, stream)
+    DB = cabi.DeviceBuffer
+    out = {}
+
+    # -- C2 end to end: host buffers in, host buffer out (H2D + prologue + scan + D2H) -------------
+    t0 = time.perf_counter()
+    cabi.gls_scan(t2, y2, dy2, f0, delta, nf2, device=dev)            # first call sizes the cached workspace
+    t1 = time.perf_counter()
+    cabi.gls_scan(t2, y2, dy2, f0, delta, nf2, device=dev)
+    t2_ = time.perf_counter()
+    out["c2_end_to_end"] = {"ms": round((t2_ - t1) * 1e3, 3), "first_call_ms": round((t1 - t0) * 1e3, 3),
+                            "Gpair_per_s": round(t2.size * nf2 / (t2_ - t1) / 1e9, 1),
+                            "note": "pdc_gls_scan on host buffers: H2D of (t, y, dy) + prologue + scan + "
+                                    "D2H of power[1e6], wall clock"}
+
+    # -- C3: 4096 light curves x 2000 samples, shared 5e4-frequency grid ---------------------------
+    B, n, nf = 4096, 2000, 50_000
+    rng = np.random.default_rng(20241008 + 3)
+    tt = np.sort(rng.uniform(0, float(n), (B, n)), axis=1)
+    dd = rng.uniform(0.05, 0.2, (B, n))
+    pp = (5.0 + 0.01 * np.arange(B))[:, None]
+    yy = 1.0 + 0.5 * np.sin(2 * np.pi * tt / pp) + dd * rng.standard_normal((B, n))
+    offsets = np.arange(B + 1, dtype=np.int64) * n
+    df = 1.0 / n / 5
+    f = np.arange(0.5 * df, 0.5 * df + (nf - 1.5) * df + df, df)
+    assert f.size == nf
+    g0, gd, _ = cabi.grid_params(f)
+    bt, by, bdy, boff = DB.from_array(tt, dev), DB.from_array(yy, dev), DB.from_array(dd, dev), DB.from_array(offsets, dev)
+    bt0 = DB.from_array(tt[0], dev)
+    wb = lib.pdc_gls_work_bytes(B * n, B, nf)
+    work = DB(wb, dev)
+    power = DB(B * nf * 8, dev)
+    amax, arg = DB(B * 8, dev), DB(B * 8, dev)
+    pairs = float(B) * n * nf
+
+    def c3(shared, peaks_only):
+        def fn():
+            cabi.check(lib.pdc_gls_scan_dev(dev, stream, bt0.ptr if shared else bt.ptr, by.ptr, bdy.ptr,
+                                            boff.ptr, B * n, B, int(shared), g0, gd, 0, nf, 1, 0,
+                                            None if peaks_only else power.ptr,
+                                            amax.ptr if peaks_only else None,
+                                            arg.ptr if peaks_only else None, work.ptr, wb))
+        return fn
+    for key, shared, peaks, kern in (("c3_power", False, False, "gls_scan_kernel"),
+                                     ("c3_peaks_only", False, True, "gls_scan_kernel"),
+                                     ("c3_shared_t_peaks_only", True, True, "gls_shared_kernel")):
+        ms = tm.ms(c3(shared, peaks), reps=3)
+        blk, why = valu_issue_block(kern, ms)
+        out[key] = {"ms": round(ms, 3), "Gpair_per_s": round(pairs / ms / 1e6, 1),
+                    "valu_issue": blk if blk else None}
+        if why:
+            out[key]["valu_issue_note"] = why
+    out["c3_note"] = ("BASELINE configs[2]: 4096 curves x 2000 samples x 5e4 shared frequencies, resident; "
+                      "power = 1.64 GB of spectra written; peaks_only = per-curve amax/argmax reduced on "
+                      "the device; shared_t = the bootstrap shape (one time axis, trigonometry shared "
+                      "between curves)")
+    for b in (bt, by, bdy, boff, bt0, work, power, amax, arg):
+        b.free()
+
+    # -- C5: PDM and StringLength, N=5e4 x 1e5 trial periods ----------------------------------------
+    n, n_per = 50_000, 100_000
+    t5, y5, _ = synth_curve(n, 5, period=13.7)
+    bt5 = DB.from_array(t5, dev)
+    pairs = float(n) * n_per
+    periods = np.linspace(1.0, 100.0, n_per)
+    bx, bp, bth = DB.from_array(y5, dev), DB.from_array(periods, dev), DB(n_per * 8, dev)
+    sigma = float(np.var(y5, ddof=1))
+    ms = tm.ms(lambda: cabi.check(lib.pdc_pdm_scan_dev(dev, stream, bt5.ptr, bx.ptr, n, bp.ptr, n_per, 5, 2,
+                                                       sigma, bth.ptr)), reps=5)
+    blk, why = valu_issue_block("pdm_scan_kernel", ms)
+    ach = pairs * PDM_FLOP_PER_PAIR / ms / 1e9
+    out["c5_pdm"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1),
+                     "roofline": {"bound": "valu", "achieved": round(ach, 2), "peak": PEAK_FP64_VECTOR_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": round(ach / PEAK_FP64_VECTOR_TFLOPS, 4),
+                                  "note": "40 algorithmic fp64 flop per (sample, period) pair (SURVEY 8d)"},
+                     "valu_issue": blk}
+    if why:
+        out["c5_pdm"]["valu_issue_note"] = why
+    vmax, vmin = y5.max(), y5.min()
+    m = (y5 - vmax) / (2 * (vmax - vmin)) + 0.25
+    dfp = 0.1 / (t5[-1] - t5[0])
+    sl_periods = 1 / np.linspace(n_per * dfp, dfp, n_per)
+    bm, bsp, be = DB.from_array(m, dev), DB.from_array(sl_periods, dev), DB(n_per * 8, dev)
+    swb = lib.pdc_stringlength_work_bytes(n, n_per)
+    swork = DB(swb, dev)
+    ms = tm.ms(lambda: cabi.check(lib.pdc_stringlength_scan_dev(dev, stream, bt5.ptr, bm.ptr, n, bsp.ptr, n_per,
+                                                                be.ptr, swork.ptr, swb)), reps=5)
+    blk, why = valu_issue_block("sl_", ms)
+    floor_ms = pairs / L2_GATHER_PER_S * 1e3
+    out["c5_stringlength"] = {
+        "ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1),
+        "roofline": {"bound": "l2-gather", "achieved": round(pairs / ms / 1e6, 1), "peak": L2_GATHER_PER_S / 1e9,
+                     "unit": "G gathered records/s", "frac": round(floor_ms / ms, 4),
+                     "note": "a sort by phase gathers one 16-byte (t, m) record per (sample, period) pair "
+                             "from an L2-resident table; random accesses are served at 2.7e11/s chip-wide "
+                             "whatever their width (tools/ubench/gather_rate.hip, "
+                             "profiles/r02_ubench_gather_rate.txt)"},
+        "survey_hbm_model": {"bytes_per_pair": SL_MODEL_BYTES_PER_PAIR,
+                             "achieved_TBps": round(pairs * SL_MODEL_BYTES_PER_PAIR / ms / 1e9, 2),
+                             "frac_of_8TBps": round(pairs * SL_MODEL_BYTES_PER_PAIR / ms / 1e9 / HBM_PEAK_TBS, 3),
+                             "note": "SURVEY 8d's HBM bucket-pass model (48 B/pair); the kernel sorts in LDS "
+                                     "and moves none of these bytes through HBM, so this may exceed 1"},
+        "valu_issue": blk}
+    if why:
+        out["c5_stringlength"]["valu_issue_note"] = why
+    for b in (bt5, bx, bp, bth, bm, bsp, be, swork):
+        b.free()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C3/C5/end-to-end extra keys")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the torch.distributed path even with one rank (testing)")
+    ap.add_argument("--force-plan", action="store_true",
+                    help="take the one-process multi-device plan path even with one GPU (testing)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_mode = world > 1 or args.force_dist
-    if args.gpus != world and world > 1:
+    dist_mode = world > 1 or args.force_dist            # one rank per GPU (torchrun)
+    if dist_mode and args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
+    plan_mode = not dist_mode and (args.gpus > 1 or args.force_plan)   # one process, N devices
+    n_gpus = world if dist_mode else args.gpus
 
     torch = dist = None
     if dist_mode:
@@ -121,30 +326,35 @@ def main():
     from periodicity_amd import _cabi
     lib = _cabi.lib()
     dev = local_rank
-    if _cabi.device_count() <= dev:
-        raise SystemExit("bench.py needs a GPU per rank; no CPU fallback exists")
+    have = _cabi.device_count()
+    if have <= dev or (plan_mode and have < args.gpus):
+        raise SystemExit(f"bench.py needs {args.gpus if plan_mode else dev + 1} GPU(s), {have} visible; "
+                         "no CPU fallback exists")
 
     # ---- workload --------------------------------------------------------------------------
     n = N_SAMPLES
-    nf_total = NF_PER_GPU * world
+    nf_total = NF_PER_GPU * n_gpus
     t, y, dy = synth_curve(n)
     freq, df, fmin = throughput_grid(t, nf_total)
     f0, delta, _ = _cabi.grid_params(freq)
     slab = NF_PER_GPU
-    j_begin = rank * slab
+    j_begin = rank * slab if dist_mode else 0
+    stream = None
+    plan = None
 
-    if dist_mode:
+    if plan_mode:
+        plan = _cabi.GlsPlan(list(range(args.gpus)), n, nf_total)
+        plan.upload(t, y, dy)
+    elif dist_mode:
         tt = torch.from_numpy(np.stack([t, y, dy])).cuda()
         d_t, d_y, d_dy = (tt[i].data_ptr() for i in range(3))
         # two generations of the output buffers: the all-gather of step i (RCCL's own stream) overlaps
         # the scan of step i+1 (compute stream); a buffer is reused only after its gather was waited on
         powers = [torch.empty(nf_total, dtype=torch.float64, device="cuda") for _ in range(2)]
-        power = powers[0]
         work_bytes = lib.pdc_gls_work_bytes(n, 1, slab)
         work = torch.empty(work_bytes, dtype=torch.uint8, device="cuda")
         d_work = work.data_ptr()
         slabs = [torch.empty(slab, dtype=torch.float64, device="cuda") for _ in range(2)]
-        d_power_slab = slabs[0].data_ptr()
         pending = [None, None]
         counter = [0]
         stream = torch.cuda.current_stream().cuda_stream
@@ -164,8 +374,13 @@ def main():
         _cabi.check(lib.pdc_event_create(dev, C.byref(e)))
         return e.value
 
+    plan_kernel_ms = []
+
     def step(ev=None):
-        out_ptr = d_power_slab
+        if plan_mode:
+            plan.scan(f0, delta, nf_total)
+            return
+        out_ptr = d_power_slab if not dist_mode else None
         if dist_mode:
             g = counter[0] % 2
             if pending[g] is not None:      # stream-level wait: buffers of generation g are free again
@@ -189,7 +404,9 @@ def main():
                     h.wait()
 
     def sync():
-        if dist_mode:
+        if plan_mode:
+            plan.wait()
+        elif dist_mode:
             torch.cuda.synchronize()
         else:
             _cabi.check(lib.pdc_stream_sync(dev, stream))
@@ -201,12 +418,12 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    events = [(new_event(), new_event()) for _ in range(args.steps)]
+    events = [] if plan_mode else [(new_event(), new_event()) for _ in range(args.steps)]
     barrier()
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(events[i])
+        step(None if plan_mode else events[i])
     drain()
     sync()
     barrier()
@@ -216,29 +433,47 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    kernel_ms = []
-    for a, b in events:
-        ms = C.c_float()
-        _cabi.check(lib.pdc_event_elapsed_ms(dev, a, b, C.byref(ms)))
-        kernel_ms.append(ms.value)
-    kernel_s = float(np.mean(kernel_ms)) / 1e3
+    if plan_mode:
+        # kernel time of one slab scan on device 0, measured outside the timed region (the plan keeps
+        # one event pair; reading it per step would serialise the double buffering)
+        for _ in range(3):
+            plan.scan(f0, delta, nf_total)
+            plan.wait()
+            plan_kernel_ms.append(plan.kernel_ms())
+        kernel_s = float(np.median(plan_kernel_ms)) / 1e3
+    else:
+        kernel_ms = []
+        for a, b in events:
+            ms = C.c_float()
+            _cabi.check(lib.pdc_event_elapsed_ms(dev, a, b, C.byref(ms)))
+            kernel_ms.append(ms.value)
+        kernel_s = float(np.mean(kernel_ms)) / 1e3
 
     if rank == 0:
-        if dist_mode:
+        if plan_mode:
+            got = plan.download(0)
+            if args.gpus > 1:      # every device must hold the same gathered array
+                other = plan.download(args.gpus - 1)
+                assert np.array_equal(got, other, equal_nan=True), "all-gather left the devices with different arrays"
+        elif dist_mode:
             got = powers[(counter[0] - 1) % 2].cpu().numpy()
         else:
             got = power_buf.to_array(np.float64, nf_total)
         pairs_per_step = float(n) * float(nf_total)
         value = pairs_per_step * args.steps / elapsed / 1e9
         launch_pairs = float(n) * float(slab)
-        achieved = launch_pairs * FLOP_PER_PAIR / kernel_s / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.isfile(tpath):
-            traffic = json.load(open(tpath)).get("gls_scan_c2_bytes_per_launch")
+        algorithmic = launch_pairs * FLOP_PER_PAIR / kernel_s / 1e12
+        blk, why = valu_issue_block("gls_scan_kernel", kernel_s * 1e3)
+        algo_bytes = 24.0 * n + 8.0 * slab
+        if blk:
+            achieved = blk["valu_wave_instr_per_launch"] * 64 * 2 / kernel_s / 1e12
+            frac = round(achieved / PEAK_FP64_VECTOR_TFLOPS, 4)
+            traffic = blk.get("hbm_bytes")
+        else:
+            achieved = frac = traffic = None
         out = {
             "metric": "Lomb-Scargle Gpair/s (sample x freq), fp64, N=1e5 x 1e6 per GPU",
-            "value": round(value, 2), "unit": "Gpair/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 2), "unit": "Gpair/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
@@ -247,59 +482,61 @@ def main():
                                    "frequencies per GPU (BASELINE configs[1]); inputs resident in "
                                    "HBM, exact direct summation",
                        "n_samples": n, "n_freq_total": nf_total,
-                       "sharding": f"frequency grid in {world} contiguous slab(s)"
-                                   + (", RCCL all-gather of power" if world > 1 else "")},
-            "roofline": {"bound": "valu", "achieved": round(achieved, 3),
-                         "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP64_VECTOR_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "gls_scan_kernel (+ gls_prep_kernel, <0.1%)",
+                       "sharding": f"frequency grid in {n_gpus} contiguous slab(s)"
+                                   + (", RCCL all-gather of power" if n_gpus > 1 else ""),
+                       "launcher": "one process, N devices (pdc_gls_plan_*, ncclCommInitAll)" if plan_mode
+                                   else ("one rank per GPU (torch.distributed over RCCL)" if dist_mode
+                                         else "one process, one device")},
+            "roofline": {"bound": "valu",
+                         "achieved": None if achieved is None else round(achieved, 3),
+                         "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s", "frac": frac,
+                         "traffic": traffic,
+                         "kernel": "gls_scan_kernel (+ prologue kernels, <0.1%)",
                          "kernel_ms": round(kernel_s * 1e3, 4),
-                         "valu_issue": {
-                             "instr_per_pair": VALU_INSTR_PER_PAIR,
-                             "ns_per_wave_instr_per_simd": round(
-                                 kernel_s * 1e9 * 1024 / (launch_pairs / 64 * VALU_INSTR_PER_PAIR), 3),
-                             "ceiling_ns": FP64_ISSUE_CEILING_NS,
-                             "frac_of_ceiling": round(
-                                 FP64_ISSUE_CEILING_NS / (kernel_s * 1e9 * 1024 /
-                                                          (launch_pairs / 64 * VALU_INSTR_PER_PAIR)), 3)},
-                         "note": "fp64 vector-ALU bound (software sincos + recurrences; no fp64 "
-                                 "transcendental unit, not a contraction): achieved = 50 "
-                                 "algorithmic flop/pair (SURVEY 8d) x pairs per launch / HIP-event "
-                                 "time. The recurrence kernel EXECUTES 8.56 VALU instr/pair "
-                                 "(SQ_INSTS_VALU, profiles/r01_gls_scan_c2_pmc.csv), so frac exceeds the direct-evaluation roofline; "
-                                 "valu_issue compares its issue rate with the measured v_fma_f64 "
-                                 "ceiling at 2 waves/SIMD (profiles/r01_ubench_fp64_rate.txt)"},
+                         "valu_issue": blk,
+                         "algorithmic": {"flop_per_pair": FLOP_PER_PAIR,
+                                         "achieved_TFLOPs": round(algorithmic, 3),
+                                         "ratio_to_direct_evaluation_roofline": round(
+                                             algorithmic / PEAK_FP64_VECTOR_TFLOPS, 4),
+                                         "bytes_per_launch": algo_bytes},
+                         "note": "fp64 vector-ALU bound (software sincos + rotation recurrences; no fp64 "
+                                 "transcendental unit, not a contraction).  achieved/frac = EXECUTED "
+                                 "issue: SQ_INSTS_VALU wave-instructions per launch x 64 lanes x 2 flop "
+                                 "/ HIP-event time, i.e. wave-instr x 4 cycles / 1024 SIMDs / 2.4 GHz / "
+                                 "time; `algorithmic` prices SURVEY 8d's 50 flop/pair of a direct "
+                                 "evaluation and may exceed the roofline; traffic = HBM-side bytes per "
+                                 "launch (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes) vs "
+                                 "24 N + 8 nf algorithmic"
+                                 + ("" if blk else f"; executed-issue figures unavailable: {why}")},
             "peak_bin": int(np.nanargmax(got)),
         }
-        if world == 1 and not dist_mode:
+        if n_gpus == 1 and not dist_mode and not plan_mode:
             # informational: the reference's own algorithm on the device (Tier F), same workload
             wb = lib.pdc_gls_fft_work_bytes(n, nf_total)
             fwork = _cabi.DeviceBuffer(wb, dev)
-            ev = (new_event(), new_event())
-            fms = []
-            for _ in range(6):
-                _cabi.check(lib.pdc_event_record(dev, ev[0], stream))
-                _cabi.check(lib.pdc_gls_scan_fft_dev(dev, stream, d_t, d_y, d_dy, n, fmin, df,
-                                                     nf_total, 1, 0, d_power_slab, fwork.ptr, wb))
-                _cabi.check(lib.pdc_event_record(dev, ev[1], stream))
-                ms = C.c_float()
-                _cabi.check(lib.pdc_event_elapsed_ms(dev, ev[0], ev[1], C.byref(ms)))
-                fms.append(ms.value)
+            tm = EventTimer(lib, _cabi, dev, stream)
+            fms = tm.ms(lambda: _cabi.check(lib.pdc_gls_scan_fft_dev(
+                dev, stream, d_t, d_y, d_dy, n, fmin, df, nf_total, 1, 0, d_power_slab, fwork.ptr, wb)),
+                reps=5)
             fft_power = power_buf.to_array(np.float64, nf_total)
-            out["fft_path"] = {"ms": round(float(np.median(fms[1:])), 4),
-                               "effective_Gpair_per_s": round(pairs_per_step / np.median(fms[1:]) / 1e6, 1),
+            out["fft_path"] = {"ms": round(fms, 4),
+                               "effective_Gpair_per_s": round(pairs_per_step / fms / 1e6, 1),
                                "peak_bin": int(np.nanargmax(fft_power)),
                                "note": "pdc_gls_scan_fft_dev: the reference's extirpolation + FFT "
                                        "algorithm on the device (approximate, like upstream); not "
                                        "the headline metric, which counts exact pair evaluations"}
             fwork.free()
-        if not args.no_cpu_baseline and world == 1:
+            if not args.no_extras:
+                out["extras"] = extra_configs(lib, _cabi, dev, stream, t, y, dy, f0, delta, nf_total)
+        if not args.no_cpu_baseline and n_gpus == 1:
             base, p_fft = cpu_baseline(t, y, dy, freq, df, fmin)
             out["cpu_baseline"] = base
             out["peak_bin_matches_cpu_reference_path"] = bool(
                 int(np.nanargmax(p_fft)) == out["peak_bin"])
         print(json.dumps(out), flush=True)
 
+    if plan_mode:
+        plan.close()
     if dist_mode:
         dist.destroy_process_group()
 

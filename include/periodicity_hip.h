@@ -91,6 +91,28 @@ int pdc_gls_scan_multi(const double *t, const double *y, const double *dy, int64
                        double f0, double delta, int64_t nf, int fit_mean, int psd,
                        double *power_out, const int *devices, int n_devices);
 
+/* The same shard + all-gather as a persistent plan for callers that scan repeatedly (bench.py, a
+ * survey loop over many light curves): per-device sample/power/work buffers, two streams and the
+ * events per device and the RCCL communicators (ncclCommInitAll, one process, N devices) are created
+ * ONCE by pdc_gls_plan_create and reused by every scan; this is also what pdc_gls_scan_multi keeps
+ * cached between calls.  Replaces the per-call process fan-out of phase.py:69-70,185-186 for the
+ * spectral path.  `devices` are distinct ordinals below pdc_device_count() (else PDC_ERR_INVALID).
+ *   upload   replicate (t, y, dy|NULL) of n <= n_max samples on every device (async, compute streams)
+ *   scan     enqueue: device i scans slab i of the nf <= nf_max grid into generation g of its power
+ *            buffer, then the grouped ncclAllGather of generation g runs on the communication streams
+ *            while the next scan (generation g^1) may already compute; returns without waiting
+ *   wait     drain every stream of the plan
+ *   download wait, then copy the latest complete power[nf] from device slot `which` (every device
+ *            holds the whole array after the gather)
+ *   kernel_ms  HIP-event time of the latest slab scan on devices[0] */
+int pdc_gls_plan_create(const int *devices, int n_devices, int64_t n_max, int64_t nf_max, void **plan);
+int pdc_gls_plan_upload(void *plan, const double *t, const double *y, const double *dy, int64_t n);
+int pdc_gls_plan_scan(void *plan, double f0, double delta, int64_t nf, int fit_mean, int psd);
+int pdc_gls_plan_wait(void *plan);
+int pdc_gls_plan_download(void *plan, double *power_out, int64_t nf, int which);
+int pdc_gls_plan_kernel_ms(void *plan, float *ms);
+int pdc_gls_plan_destroy(void *plan);
+
 /* Seam-level: replaces _trig_sum(t, w, df, nf, fmin) (spectral.py:11-40) by what its docstring
  * defines (:13-15): S_j = sum_i w_i sin(2 pi f_j t_i), C_j = sum_i w_i cos(2 pi f_j t_i),
  * f_j = f0 + j*delta. */

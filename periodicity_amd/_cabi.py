@@ -44,6 +44,13 @@ PROTOTYPES = {
     "pdc_gls_scan_batch": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _L, _I, _I,
                                 _VP, _VP, _VP, _I]),
     "pdc_gls_scan_multi": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _I, _I, _VP, _VP, _I]),
+    "pdc_gls_plan_create": (_I, [_VP, _I, _L, _L, C.POINTER(_VP)]),
+    "pdc_gls_plan_upload": (_I, [_VP, _VP, _VP, _VP, _L]),
+    "pdc_gls_plan_scan": (_I, [_VP, _D, _D, _L, _I, _I]),
+    "pdc_gls_plan_wait": (_I, [_VP]),
+    "pdc_gls_plan_download": (_I, [_VP, _VP, _L, _I]),
+    "pdc_gls_plan_kernel_ms": (_I, [_VP, C.POINTER(C.c_float)]),
+    "pdc_gls_plan_destroy": (_I, [_VP]),
     "pdc_trig_sums": (_I, [_VP, _VP, _L, _D, _D, _L, _VP, _VP, _I]),
     "pdc_gls_work_bytes": (_L, [_L, _L, _L]),
     "pdc_gls_scan_dev": (_I, [_I, _VP, _VP, _VP, _VP, _VP, _L, _L, _I, _D, _D, _L, _L, _I, _I,
@@ -185,6 +192,55 @@ def gls_scan_multi(t, y, dy, f0, delta, nf, fit_mean=True, psd=False, devices=(0
                                    int(bool(fit_mean)), int(bool(psd)), _ptr(out), _ptr(devs),
                                    devs.size))
     return out
+
+
+class GlsPlan:
+    """A persistent multi-GPU GLS plan (``pdc_gls_plan_*``): buffers, streams and RCCL communicators
+    are created once; ``scan`` only enqueues (double-buffered), ``download`` waits and copies."""
+
+    def __init__(self, devices, n_max, nf_max):
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        self.devices = [int(d) for d in devs]
+        self._plan = C.c_void_p()
+        check(lib().pdc_gls_plan_create(_ptr(devs), devs.size, int(n_max), int(nf_max),
+                                        C.byref(self._plan)))
+        self.nf = 0
+
+    def upload(self, t, y, dy=None):
+        t, y = _f64(t, "t"), _f64(y, "y")
+        dy = None if dy is None else _f64(dy, "dy")
+        if y.size != t.size or (dy is not None and dy.size != t.size):
+            raise ValueError("Input arrays have incompatible lengths.")
+        check(lib().pdc_gls_plan_upload(self._plan, _ptr(t), _ptr(y), _ptr(dy), t.size))
+
+    def scan(self, f0, delta, nf, fit_mean=True, psd=False):
+        check(lib().pdc_gls_plan_scan(self._plan, float(f0), float(delta), int(nf),
+                                      int(bool(fit_mean)), int(bool(psd))))
+        self.nf = int(nf)
+
+    def wait(self):
+        check(lib().pdc_gls_plan_wait(self._plan))
+
+    def download(self, which=0):
+        out = np.empty(self.nf, dtype=np.float64)
+        check(lib().pdc_gls_plan_download(self._plan, _ptr(out), self.nf, int(which)))
+        return out
+
+    def kernel_ms(self):
+        ms = C.c_float()
+        check(lib().pdc_gls_plan_kernel_ms(self._plan, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._plan:
+            check(lib().pdc_gls_plan_destroy(self._plan))
+            self._plan = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def trig_sums(t, w, f0, delta, nf, device=None):

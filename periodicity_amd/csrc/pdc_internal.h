@@ -19,6 +19,9 @@ enum Slot { SLOT_IN0 = 0, SLOT_IN1, SLOT_IN2, SLOT_IN3, SLOT_OUT0, SLOT_OUT1, SL
             SLOT_COUNT };
 int cached(int device, Slot slot, int64_t bytes, void **dptr);
 
+// Frees the multi-GPU plan pdc_gls_scan_multi caches (multi.hip).
+void release_multi();
+
 // hipSetDevice + range check; every entry point starts here.
 int use_device(int device);
 

@@ -123,6 +123,7 @@ int pdc_device_info(int device, char *name, int name_len, int *cu_count, int64_t
 }
 
 int pdc_release(void) {
+    release_multi();
     std::lock_guard<std::mutex> lk(g_mutex);
     for (size_t d = 0; d < g_devices.size(); ++d) {
         DeviceState *st = g_devices[d];

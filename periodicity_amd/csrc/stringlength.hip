@@ -36,6 +36,8 @@
 //        larger than a whole slice is gathered straight into the global scratch.
 //   P3c  links between consecutive ranges and the closing segment, from the summaries.
 // Nothing but t[], m[] (read) and ell[p] (written) touches global memory on the common path.
+#include <cstdlib>
+
 #include "pdc_internal.h"
 
 using namespace pdc;
@@ -686,6 +688,602 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
     }
 }
 
+// =====================================================================================================
+// Fast path: N <= Fast::capacity samples (one slice, 16-bit sample indices; C5's N = 5e4 fits).
+//
+// What bounds a sort-by-phase on this chip is the gather that brings the samples into phase order:
+// a random access into an L2-resident table costs ~2.3 cycles per lane per CU whatever its width
+// (tools/ubench/gather_rate.hip: the 16 L2 channels of an XCD serve 32 CUs), ~146 cycles per
+// wave-instruction against ~24 for a coalesced one.  This kernel therefore gathers ONCE per sample and
+// period - a 16-byte (t, m) record (AoS table built by sl_prep_kernel) - where the general kernel above
+// gathers t[] and later m[]; everything else is arranged to run beside that stream:
+//   P1   exact fold of every sample, read coalesced from t[] (the quotient t/period comes from a
+//        correctly rounded reciprocal and two fma corrections, `exact_quotient`, 5 instructions, not the
+//        ~12 of an IEEE division); coarse histogram over 2048 buckets by LDS atomics; the bucket of each
+//        of a thread's <= 52 samples stays in registers (two 16-bit ids per VGPR),
+//   P2   so the permutation order[] (grouped by coarse bucket) is filled without touching t[] again;
+//   P3a  wave-autonomous ranges of <= 256 sorted positions as above, with the records of the NEXT range
+//        requested before the current one is ranked; rank = fine-bucket start + number of bucket members
+//        that sort before (LDS); the sorted neighbour's (phase, m) is taken by writing one's own at the
+//        final slot and reading slot - 1, first the phases, then m through the same 2 KB;
+//        segment length = sqrt(dm^2 + dphi^2) by rsq + two refinement steps (<= 1 ulp);
+//   P3b/P3c  deferred ranges and the links between ranges, as above.
+namespace fast {
+
+constexpr int kNB = kBuckets;
+constexpr int kFWin = 208;             // sorted positions per range window (a range = window + < one bucket)
+constexpr int kFCap = 255;             // samples a wave ranks by itself: counts and starts fit in bytes
+constexpr int kFine = 1024;            // fine buckets per range, 8-bit counters packed four to a word
+constexpr int kRanges = 320;           // >= capacity / kFWin + 2
+constexpr int kKMax = 52;              // samples per thread in P1/P2 (capacity <= kKMax * kBlock)
+constexpr int kWaveBytes = Lds<unsigned short>::wave_bytes;
+constexpr int kFixed = kWaves * kWaveBytes + 2 * (kRanges + 8) * 2 + 64;
+constexpr int kStatic = 512;           // static __shared__ below, rounded up
+constexpr int kLdsTotalDyn = kLdsTotal - kStatic;
+constexpr int kCapacity = (((kLdsTotal - kFixed - kStatic) / 2) & ~7) - 64;   // (+ 64 dummy slots)
+static_assert(kCapacity / kFWin + 2 <= kRanges, "range table too small");
+static_assert(kFine + 16 <= (kWFine + 4) * 4, "byte counters live in the general kernel's counter area");
+static_assert(kCapacity <= kKMax * kBlock, "P1 keeps one bucket id per sample in registers");
+static_assert(kCapacity < 65536, "16-bit sample indices");
+static_assert(kWaves * kWaveBytes >= (kNB + 64) * 4 && kWaves * kWaveBytes >= kDCap * 10, "aliases must fit");
+
+typedef double rec_t __attribute__((ext_vector_type(2)));   // (t, m)
+
+struct FastArgs {
+    const double *t, *m, *periods;
+    const rec_t *rec;
+    const unsigned *flags;      // [0] != 0: every t is 0 or 1e-150 <= |t| <= 1e150
+    int64_t n, n_periods;
+    double *ell;
+    unsigned long long *gkeys;  // [grid][n_pad]  deferred ranges larger than kDCap
+    unsigned *gidx;             // [grid][n_pad]
+    double *rsum;               // [grid][nr_pad][4]
+    int *rcnt;                  // [grid][nr_pad]
+    int64_t n_pad, nr_pad;
+};
+
+// RN(t / period) without the division: y = RN(1 / period); q0 = RN(t y) is within 1.5 ulp of the
+// quotient, one fma correction makes it faithful, and for a faithful q and a correctly rounded
+// reciprocal Markstein's theorem (IBM J. Res. Dev. 34, 1990; Muller et al., Handbook of
+// Floating-Point Arithmetic, "division with an FMA") says the second correction IS the correctly
+// rounded quotient.  The theorem needs no over/underflow and a divisor whose significand is not all
+// ones: `safe` (wave-uniform) says so, otherwise the IEEE division runs.
+__device__ __forceinline__ double exact_quotient(double t, double period, double y, bool safe) {
+    if (!safe) return t / period;
+    const double q0 = t * y;
+    const double r0 = __builtin_fma(-period, q0, t);
+    const double q1 = __builtin_fma(r0, y, q0);
+    const double r1 = __builtin_fma(-period, q1, t);
+    return __builtin_fma(r1, y, q1);
+}
+
+__device__ __forceinline__ bool period_is_safe(double period, bool t_safe) {
+    const double ap = __builtin_fabs(period);
+    const unsigned long long frac = (unsigned long long)__double_as_longlong(period) & 0xFFFFFFFFFFFFFull;
+    return t_safe && ap >= 1e-150 && ap <= 1e150 && frac != 0xFFFFFFFFFFFFFull;
+}
+
+// ((t - 0) / period) % 1 as numpy computes it (core.py:544); NaN when the quotient is not finite.
+__device__ __forceinline__ double fast_phase(double t, double period, double y, bool safe) {
+    const double q = exact_quotient(t, period, y, safe);
+    return q - __builtin_floor(q);
+}
+
+__device__ __forceinline__ unsigned long long phase_key(double phi) {
+    // monotone for phi in [0, 1]; every NaN gets one pattern, above all numbers, so that NaN phases
+    // keep their time order (stable sort)
+    return phi == phi ? (unsigned long long)__double_as_longlong(phi) : 0x7FF8000000000000ull;
+}
+
+__device__ __forceinline__ int coarse_of(double phi) {
+    const unsigned b = (unsigned)(phi * (double)kNB);           // exact product; v_cvt_u32 saturates
+    const unsigned c = b < (unsigned)(kNB - 1) ? b : (unsigned)(kNB - 1);
+    return phi == phi ? (int)c : kNB - 1;
+}
+
+// Wave-wide inclusive scan / maximum by DPP row shifts and row broadcasts (gfx9 encodings: row_shr:n =
+// 0x110 + n, row_bcast15 = 0x142, row_bcast31 = 0x143); no LDS permutes.  The maximum ends in lane 63.
+#define PDC_DPP(old, src, ctrl, rmask) \
+    (unsigned)__builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), (rmask), 0xf, false)
+__device__ __forceinline__ unsigned wave_scan_add(unsigned v) {
+    v += PDC_DPP(0u, v, 0x111, 0xf);
+    v += PDC_DPP(0u, v, 0x112, 0xf);
+    v += PDC_DPP(0u, v, 0x114, 0xf);
+    v += PDC_DPP(0u, v, 0x118, 0xf);
+    v += PDC_DPP(0u, v, 0x142, 0xa);
+    v += PDC_DPP(0u, v, 0x143, 0xc);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {   // valid in lane 63 -> broadcast
+    unsigned u;
+    u = PDC_DPP(0u, v, 0x111, 0xf); v = u > v ? u : v;
+    u = PDC_DPP(0u, v, 0x112, 0xf); v = u > v ? u : v;
+    u = PDC_DPP(0u, v, 0x114, 0xf); v = u > v ? u : v;
+    u = PDC_DPP(0u, v, 0x118, 0xf); v = u > v ? u : v;
+    u = PDC_DPP(0u, v, 0x142, 0xa); v = u > v ? u : v;
+    u = PDC_DPP(0u, v, 0x143, 0xc); v = u > v ? u : v;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// x of the lane below (lane 0: `first`), by DPP wave_shr:1 on both halves - no LDS permute
+__device__ __forceinline__ double lane_below(double x, double first) {
+    const long long xb = __double_as_longlong(x), fb = __double_as_longlong(first);
+    const int lo = __builtin_amdgcn_update_dpp((int)fb, (int)xb, 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(fb >> 32), (int)(xb >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ double read_lane(double x, int l) {   // l wave-uniform
+    const long long xb = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)xb, l), hi = __builtin_amdgcn_readlane((int)(xb >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// sqrt(x^2 + y^2) for |x|, |y| <= ~1e150 whose squares do not underflow to a subnormal that matters:
+// here |dm| <= 0.5 and |dphi| <= 1.  rsq seed, one coupled Goldschmidt step, one Newton step.
+__device__ __forceinline__ double short_hypot(double x, double y) {
+    const double s = __builtin_fma(x, x, y * y);
+    const double r = __builtin_amdgcn_rsq(s);
+    const double g0 = s * r, h0 = 0.5 * r;
+    const double e0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, e0, g0), h1 = __builtin_fma(h0, e0, h0);
+    const double d1 = __builtin_fma(-g1, g1, s);
+    const double g2 = __builtin_fma(d1, h1, g1);
+    return (s > 0.0 && s < __builtin_inf()) ? g2 : s;        // 0, +inf and NaN pass through
+}
+
+// Four phases at once: ONE wave-uniform branch on `safe` per group, so that the four dependent fma
+// chains sit in one basic block and overlap.
+__device__ __forceinline__ void phases4(const double (&t)[4], double period, double y, bool safe,
+                                        double (&phi)[4]) {
+    double q[4];
+    if (safe) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double q0 = t[u] * y;
+            const double r0 = __builtin_fma(-period, q0, t[u]);
+            const double q1 = __builtin_fma(r0, y, q0);
+            const double r1 = __builtin_fma(-period, q1, t[u]);
+            q[u] = __builtin_fma(r1, y, q1);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = t[u] / period;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) phi[u] = q[u] - __builtin_floor(q[u]);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char *wbuf = lds_raw;                                                  // P3a: per-wave scratch
+    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw);                         // P1/P2 alias [kNB + 64]
+    unsigned long long *bkeys = reinterpret_cast<unsigned long long *>(lds_raw);    // P3b alias [kDCap]
+    unsigned short *bidx = reinterpret_cast<unsigned short *>(bkeys + kDCap);       // P3b alias [kDCap]
+    unsigned short *bndb = reinterpret_cast<unsigned short *>(lds_raw + kWaves * kWaveBytes);
+    unsigned short *bnds = bndb + kRanges + 8;
+    unsigned *defer = reinterpret_cast<unsigned *>(bnds + kRanges + 8);             // [16]
+    unsigned short *order = reinterpret_cast<unsigned short *>(defer + 16);         // [n + 64]
+    __shared__ unsigned wave_tot[kWaves];
+    __shared__ double red[kWaves];
+    const int tid0 = threadIdx.x, lane = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int n = (int)a.n;
+    unsigned long long *gk = a.gkeys + (int64_t)blockIdx.x * a.n_pad;
+    unsigned *gi = a.gidx + (int64_t)blockIdx.x * a.n_pad;
+    double *rsum = a.rsum + (int64_t)blockIdx.x * a.nr_pad * 4;
+    int *rcnt = a.rcnt + (int64_t)blockIdx.x * a.nr_pad;
+    const bool t_safe = a.flags[0] != 0u;
+
+    unsigned long long *keys_w = reinterpret_cast<unsigned long long *>(wbuf + wave * kWaveBytes);
+    unsigned *fine_w = reinterpret_cast<unsigned *>(wbuf + wave * kWaveBytes + kRCap * 8);
+    unsigned short *idx_w = reinterpret_cast<unsigned short *>(wbuf + wave * kWaveBytes + kRCap * 8 + (kWFine + 4) * 4);
+
+    const int nranges = (n + kFWin - 1) / kFWin;
+
+    for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
+        const double period = a.periods[p];
+        const double y = 1.0 / period;
+        const bool safe = period_is_safe(period, t_safe);
+        double total = 0.0;
+
+        // ---- P1: exact phases, coarse histogram; bucket ids stay in registers --------------------
+        // (the thread id goes through an opaque copy once per period: the <= 52 per-sample addresses and
+        // bounds masks are loop-invariant, and hoisted out of the period loop they would all be spilled)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        for (int b = tid; b < kNB + 64; b += kBlock) hist[b] = 0u;
+        if (tid < 16) defer[tid] = 0u;
+        __syncthreads();
+        // Samples past the end (the last trip of a thread) go to one of 64 dummy buckets behind the
+        // histogram instead of being branched around: everything below is straight-line code.
+        unsigned pk[(KMAX + 1) / 2];
+#pragma unroll
+        for (int k = 0; k < (KMAX + 1) / 2; ++k) pk[k] = 0u;
+        // (groups of four coalesced loads, the next group requested before the current one is folded;
+        // the scheduling barrier keeps the compiler from hoisting all <= 52 loads to the top)
+        double tv[4], tn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = u * kBlock + tid;
+            tn[u] = a.t[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < KMAX; k0 += 4) {
+            if (k0 * kBlock < n) {   // workgroup-uniform
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tv[u] = tn[u];
+                if (k0 + 4 < KMAX && (k0 + 4) * kBlock < n) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = (k0 + 4 + u) * kBlock + tid;
+                        tn[u] = a.t[i < n ? i : n - 1];
+                    }
+                }
+                double phi[4];
+                phases4(tv, period, y, safe, phi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + u < KMAX) {
+                        const int i = (k0 + u) * kBlock + tid;
+                        const int b = i < n ? coarse_of(phi[u]) : kNB + lane;
+                        atomicAdd(&hist[b], 1u);
+                        pk[(k0 + u) >> 1] |= (unsigned)b << (((k0 + u) & 1) * 16);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        scan_buckets<kNB>(hist, wave_tot);   // hist[b] = first sorted position of bucket b
+
+        // ---- P2: the permutation, grouped by coarse bucket ----------------------------------------
+#pragma unroll
+        for (int k0 = 0; k0 < KMAX; k0 += 4) {
+            if (k0 * kBlock < n) {   // workgroup-uniform
+                unsigned pos[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + u < KMAX) {
+                        const unsigned b = (pk[(k0 + u) >> 1] >> (((k0 + u) & 1) * 16)) & 0xFFFFu;
+                        pos[u] = atomicAdd(&hist[b], 1u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + u < KMAX) {
+                        const int i = (k0 + u) * kBlock + tid;
+                        order[i < n ? pos[u] : (unsigned)(n + lane)] = (unsigned short)i;
+                    }
+                }
+            }
+        }
+        __syncthreads();   // hist[b] = END position of bucket b
+        // range r starts at the first bucket whose start position is >= r * kWin
+        for (int r = tid; r <= nranges; r += kBlock) {
+            int b = 0, s0 = 0;
+            if (r > 0) {
+                const unsigned x = (unsigned)r * kFWin;
+                int l = 0, h = kNB;   // smallest j with end(j) >= x, kNB if none
+                while (l < h) {
+                    const int mid = (l + h) >> 1;
+                    if (hist[mid] >= x) h = mid; else l = mid + 1;
+                }
+                b = l < kNB ? l + 1 : kNB;
+                s0 = l < kNB ? (int)hist[l] : n;
+            }
+            bndb[r] = (unsigned short)b;
+            bnds[r] = (unsigned short)s0;
+        }
+        __syncthreads();   // (the histogram is dead from here on: its LDS becomes wave scratch)
+
+        // ---- P3a: wave-autonomous ranges -------------------------------------------------------------
+        // records of range r (requested one range ahead of their use)
+        int n_cnt = 0, n_slo = 0, n_lob = 0, n_hib = 0;
+        unsigned n_idx[kRPer];
+        rec_t n_rec[kRPer];
+        auto request = [&](int r) {
+            n_lob = __builtin_amdgcn_readfirstlane((int)bndb[r]);
+            n_hib = __builtin_amdgcn_readfirstlane((int)bndb[r + 1]);
+            n_slo = __builtin_amdgcn_readfirstlane((int)bnds[r]);
+            n_cnt = __builtin_amdgcn_readfirstlane((int)bnds[r + 1]) - n_slo;
+            if (n_cnt > 0 && n_cnt <= kFCap) {
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) {
+                    const int s = lane + e * 64;
+                    n_idx[e] = (unsigned)order[n_slo + (s < n_cnt ? s : 0)];
+                }
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) n_rec[e] = a.rec[n_idx[e]];
+            }
+        };
+        unsigned *fine32 = fine_w;                                          // [kFine / 4] packed counters
+        unsigned char *fine8 = reinterpret_cast<unsigned char *>(fine_w);   // [kFine + 1] starts
+        if (wave < nranges) request(wave);
+        for (int r = wave; r < nranges; r += kWaves) {
+            const int cnt = n_cnt, lo_b = n_lob, hi_b = n_hib;
+            if (cnt <= 0 || cnt > kFCap) {
+                if (lane == 0) {
+                    if (cnt <= 0) rcnt[r] = 0;
+                    else atomicOr(&defer[r >> 5], 1u << (r & 31));
+                }
+                if (r + kWaves < nranges) request(r + kWaves);
+                continue;
+            }
+            // Lanes past the range's end ("dead", only in its last row) are not branched around: they
+            // add 0 to a counter word of their own, park in the free slot lane + 64 e >= cnt, and their
+            // segment is masked out.
+            // Monotone map of the range's phases [lo_b, hi_b) / kNB onto kFine fine buckets: one fma
+            // with a positive multiplier (any monotone map keeps the sort exact; mean occupancy ~0.2).
+            const double fsc = (double)kFine / (double)(hi_b - lo_b);
+            const double fmul = (double)kNB * fsc, fadd = -(double)lo_b * fsc;
+            reinterpret_cast<uint4 *>(fine32)[lane] = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < 4) fine32[kFine / 4 + lane] = 0u;
+            wave_sync();
+            double et[kRPer], em[kRPer], ephi[kRPer];
+            unsigned ei[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                et[e] = n_rec[e].x;
+                em[e] = n_rec[e].y;
+                ei[e] = n_idx[e];
+            }
+            phases4(et, period, y, safe, ephi);
+            unsigned long long ek[kRPer];
+            unsigned er[kRPer], esh[kRPer];
+            int ef[kRPer];
+            bool live[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                live[e] = lane + e * 64 < cnt;
+                const double phi = ephi[e];
+                ek[e] = phase_key(phi);
+                int fb = (int)__builtin_fma(phi, fmul, fadd);
+                fb = fb < 0 ? 0 : (fb > kFine - 1 ? kFine - 1 : fb);
+                fb = phi == phi ? fb : kFine - 1;
+                ef[e] = fb;
+                esh[e] = ((unsigned)fb & 3u) * 8u;
+                const unsigned old = atomicAdd(&fine32[live[e] ? fb >> 2 : lane], live[e] ? 1u << esh[e] : 0u);
+                er[e] = (old >> esh[e]) & 0xFFu;
+            }
+            // the records of the next range go out now: t[] and the indices of this one are consumed
+            if (r + kWaves < nranges) request(r + kWaves);
+            unsigned mx = 0;
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                const unsigned v = live[e] ? er[e] : 0u;
+                mx = v > mx ? v : mx;
+            }
+            const int mxu = (int)wave_max_u32(mx) + 1;   // members of the fullest fine bucket
+            if (mxu > kWInsertMax) {
+                if (lane == 0) atomicOr(&defer[r >> 5], 1u << (r & 31));
+                continue;
+            }
+            wave_sync();
+            // exclusive scan of the kFine byte counters (sixteen per lane); every start is <= cnt <= 255
+            {
+                const uint4 cv = reinterpret_cast<uint4 *>(fine32)[lane];
+                unsigned w[4] = {cv.x, cv.y, cv.z, cv.w}, x[4], tot[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x[q] = w[q] + (w[q] << 8);
+                    x[q] += x[q] << 16;            // inclusive prefix of the four bytes (no carries)
+                    tot[q] = x[q] >> 24;
+                }
+                const unsigned lane_tot = (tot[0] + tot[1]) + (tot[2] + tot[3]);
+                const unsigned incl = wave_scan_add(lane_tot);
+                unsigned base = incl - lane_tot;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x[q] = (x[q] - w[q]) + __builtin_amdgcn_perm(base, base, 0u);   // + base in every byte
+                    base += tot[q];
+                }
+                reinterpret_cast<uint4 *>(fine32)[lane] = make_uint4(x[0], x[1], x[2], x[3]);
+                if (lane == 63) fine32[kFine / 4] = incl;  // == cnt: the start behind the last bucket
+            }
+            wave_sync();
+            // park the members of every fine bucket in arrival order, then count, per sample, the OTHER
+            // members that sort before it (a wave-uniform loop over the fullest bucket's others)
+            unsigned eb0[kRPer], ec[kRPer], park[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                eb0[e] = fine8[ef[e]];
+                ec[e] = fine8[ef[e] + 1];
+            }
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                ec[e] = live[e] ? ec[e] - eb0[e] : 0u;
+                park[e] = live[e] ? eb0[e] + er[e] : (unsigned)(lane + e * 64);
+                keys_w[park[e]] = ek[e];
+                idx_w[park[e]] = (unsigned short)ei[e];
+            }
+            wave_sync();
+            unsigned before[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) before[e] = 0u;
+            for (int j = 1; j < mxu; ++j) {
+                unsigned long long ky[kRPer];
+                unsigned oth[kRPer];
+                bool tie = false;
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) {
+                    const bool in = (unsigned)j < ec[e];
+                    unsigned o = er[e] + (unsigned)j;          // the j-th other member, cyclically
+                    o = o >= ec[e] ? o - ec[e] : o;
+                    oth[e] = in ? eb0[e] + o : park[e];
+                    ky[e] = keys_w[oth[e]];
+                    before[e] += (in && ky[e] < ek[e]) ? 1u : 0u;
+                    tie = tie || (in && ky[e] == ek[e]);
+                }
+                if (__any(tie)) {  // equal phases of two different samples (rare): the index decides
+#pragma unroll
+                    for (int e = 0; e < kRPer; ++e) {
+                        const bool in = (unsigned)j < ec[e];
+                        if (in && ky[e] == ek[e] && (unsigned)idx_w[oth[e]] < ei[e]) ++before[e];
+                    }
+                }
+            }
+            wave_sync();
+            // every sample writes its phase, then its m, to its final slot; lane j reads slot j back (the
+            // 2 KB key array serves both in turn), so the segments are summed in sorted order whatever
+            // order the atomics of P2 delivered the samples in: the result does not depend on timing
+            unsigned fs[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                fs[e] = live[e] ? eb0[e] + before[e] : (unsigned)(lane + e * 64);
+                keys_w[fs[e]] = (unsigned long long)__double_as_longlong(ephi[e]);
+            }
+            wave_sync();
+            double sphi[kRPer], sm[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) sphi[e] = __longlong_as_double((long long)keys_w[lane + e * 64]);
+            wave_sync();
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) keys_w[fs[e]] = (unsigned long long)__double_as_longlong(em[e]);
+            wave_sync();
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) sm[e] = __longlong_as_double((long long)keys_w[lane + e * 64]);
+            // the predecessor of lane j's point sits in lane j - 1 (one DPP shift per half); lane 0 takes
+            // lane 63 of the previous row, carried as a wave-uniform pair
+            double carry_phi = 0.0, carry_m = 0.0, last_phi = 0.0, last_m = 0.0;
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                const int j = lane + e * 64;
+                const double phi = sphi[e], mm = sm[e];
+                const double pphi = lane_below(phi, carry_phi), pm = lane_below(mm, carry_m);
+                const double seg = short_hypot(mm - pm, phi - pphi);
+                total += (live[e] && j > 0) ? seg : 0.0;
+                carry_phi = read_lane(phi, 63);
+                carry_m = read_lane(mm, 63);
+                if (e == ((cnt - 1) >> 6)) {  // wave-uniform: the row that holds the range's last point
+                    last_phi = read_lane(phi, (cnt - 1) & 63);
+                    last_m = read_lane(mm, (cnt - 1) & 63);
+                }
+            }
+            if (lane == 0) {
+                rsum[(int64_t)r * 4 + 0] = sphi[0];
+                rsum[(int64_t)r * 4 + 1] = sm[0];
+                rsum[(int64_t)r * 4 + 2] = last_phi;
+                rsum[(int64_t)r * 4 + 3] = last_m;
+                rcnt[r] = cnt;
+            }
+            wave_sync();
+        }
+        __syncthreads();
+
+        // ---- P3b: deferred ranges, whole workgroup ---------------------------------------------------
+        for (int w32 = 0; w32 < (nranges + 31) / 32; ++w32) {
+            unsigned bits = defer[w32];
+            while (bits) {
+                const int r = w32 * 32 + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int s_lo = bnds[r], cnt = (int)bnds[r + 1] - s_lo;
+                int P = 2;
+                while (P < cnt) P <<= 1;
+                double p0, m0, p1, m1;
+                if (cnt <= kDCap) {
+                    for (int s = tid; s < P; s += kBlock) {
+                        if (s < cnt) {
+                            const unsigned short id = order[s_lo + s];
+                            bkeys[s] = phase_key(fast_phase(a.t[id], period, y, safe));
+                            bidx[s] = id;
+                        } else {
+                            bkeys[s] = ~0ull;
+                            bidx[s] = (unsigned short)~0u;
+                        }
+                    }
+                    __syncthreads();
+                    bitonic_sort<unsigned short>(bkeys, bidx, P);
+                    total += segment_sum(bkeys, bidx, cnt, a.m);
+                    p0 = __longlong_as_double((long long)bkeys[0]);
+                    m0 = a.m[bidx[0]];
+                    p1 = __longlong_as_double((long long)bkeys[cnt - 1]);
+                    m1 = a.m[bidx[cnt - 1]];
+                } else {
+                    for (int s = tid; s < P; s += kBlock) {
+                        if (s < cnt) {
+                            const unsigned id = order[s_lo + s];
+                            gk[s] = phase_key(fast_phase(a.t[id], period, y, safe));
+                            gi[s] = id;
+                        } else {
+                            gk[s] = ~0ull;
+                            gi[s] = ~0u;
+                        }
+                    }
+                    __syncthreads();
+                    bitonic_sort<unsigned>(gk, gi, P);
+                    total += segment_sum(gk, gi, cnt, a.m);
+                    p0 = __longlong_as_double((long long)gk[0]);
+                    m0 = a.m[gi[0]];
+                    p1 = __longlong_as_double((long long)gk[cnt - 1]);
+                    m1 = a.m[gi[cnt - 1]];
+                }
+                if (tid == 0) {
+                    rsum[(int64_t)r * 4 + 0] = p0;
+                    rsum[(int64_t)r * 4 + 1] = m0;
+                    rsum[(int64_t)r * 4 + 2] = p1;
+                    rsum[(int64_t)r * 4 + 3] = m1;
+                    rcnt[r] = cnt;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();  // every summary of this period (global, this workgroup's) is visible
+
+        // ---- P3c: links between consecutive non-empty ranges + the closing segment ----------------
+        for (int r = tid; r < nranges; r += kBlock) {
+            if (rcnt[r] > 0) {
+                int q = r - 1;
+                while (q >= 0 && rcnt[q] == 0) --q;
+                if (q >= 0)
+                    total += hypot(rsum[(int64_t)r * 4 + 1] - rsum[(int64_t)q * 4 + 3],
+                                   rsum[(int64_t)r * 4 + 0] - rsum[(int64_t)q * 4 + 2]);
+            }
+        }
+        if (tid == 0 && nranges > 0) {
+            int f0 = 0, l0 = nranges - 1;
+            while (f0 < nranges && rcnt[f0] == 0) ++f0;
+            while (l0 >= 0 && rcnt[l0] == 0) --l0;
+            // closing segment of np.roll(-1): first minus last, no phase wrap (phase.py:50)
+            if (f0 < nranges && l0 >= 0)
+                total += hypot(rsum[(int64_t)f0 * 4 + 1] - rsum[(int64_t)l0 * 4 + 3],
+                               rsum[(int64_t)f0 * 4 + 0] - rsum[(int64_t)l0 * 4 + 2]);
+        }
+        total = wave_sum(total);
+        if (lane == 0) red[wave] = total;
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0;
+            for (int w = 0; w < kWaves; ++w) sum += red[w];
+            a.ell[p] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+// AoS (t, m) table + the "every t is tame" flag (one workgroup; N <= 52k)
+__global__ __launch_bounds__(kBlock) void sl_prep_kernel(const double *t, const double *m, int n,
+                                                         rec_t *rec, unsigned *flags) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const double tv = t[i];
+        rec_t v;
+        v.x = tv;
+        v.y = m[i];
+        rec[i] = v;
+        const double at = __builtin_fabs(tv);
+        if (!(at == 0.0 || (at >= 1e-150 && at <= 1e150))) mine = 1;
+    }
+    if (mine) atomicOr(&bad, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) flags[0] = bad ? 0u : 1u;
+}
+
+}  // namespace fast
+
 int64_t pad_pow2(int64_t n) {
     int64_t p = 2;
     while (p < n) p <<= 1;
@@ -700,6 +1298,24 @@ int64_t range_slots(int64_t n) { return n / kWin + n / 8192 + 64; }
 // (the smaller of the two slice capacities: above it the kernel may need the per-period partition)
 bool may_need_partition(int64_t n) { return n > Lds<unsigned>::capacity; }
 
+int64_t scratch_bytes(int64_t n, int64_t n_periods, int64_t partition) {
+    return grid_for(n_periods > 0 ? n_periods : 1) * (pad_pow2(n) * 12 + range_slots(n) * 36 + partition) + 512;
+}
+
+// AoS (t, m) records + flags of the fast path, placed behind the general scratch
+int64_t fast_table_bytes(int64_t n) { return n <= fast::kCapacity ? ((n * 16 + 255) & ~(int64_t)255) + 256 : 0; }
+
+template <int KMAX>
+int launch_fast(const fast::FastArgs &a, int64_t grid, hipStream_t st) {
+    const size_t lds = (size_t)fast::kFixed + (size_t)((a.n + 64 + 7) & ~(int64_t)7) * 2;
+    static const hipError_t attr = hipFuncSetAttribute((const void *)fast::sl_fast_kernel<KMAX>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       fast::kLdsTotalDyn);
+    PDC_HIP(attr);
+    hipLaunchKernelGGL((fast::sl_fast_kernel<KMAX>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    return PDC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -707,7 +1323,7 @@ extern "C" {
 int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) {
     if (n < 0 || n_periods < 0) return -1;
     const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
-    return grid_for(n_periods > 0 ? n_periods : 1) * (pad_pow2(n) * 12 + range_slots(n) * 36 + partition) + 512;
+    return scratch_bytes(n, n_periods, partition) + fast_table_bytes(n);
 }
 
 int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
@@ -738,7 +1354,32 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
     a.gorder = reinterpret_cast<unsigned *>(a.rcnt + grid * a.nr_pad);
     a.ghist = a.gorder + (may_need_partition(n) ? grid * a.n_pad : 0);
     hipStream_t st = (hipStream_t)stream;
-    if (n < 65536) {
+    static const bool general_only = [] { const char *e = getenv("PDC_SL_GENERAL"); return e && e[0] == '1'; }();
+    if (n >= 1 && n <= fast::kCapacity && !general_only) {
+        fast::FastArgs f;
+        f.t = d_t;
+        f.m = d_m;
+        f.periods = d_periods;
+        f.n = n;
+        f.n_periods = n_periods;
+        f.ell = d_ell;
+        f.gkeys = a.gkeys;
+        f.gidx = a.gidx;
+        f.rsum = a.rsum;
+        f.rcnt = a.rcnt;
+        f.n_pad = a.n_pad;
+        f.nr_pad = a.nr_pad;
+        char *table = static_cast<char *>(work) + scratch_bytes(n, n_periods, 0);
+        f.rec = reinterpret_cast<const fast::rec_t *>(table);
+        f.flags = reinterpret_cast<const unsigned *>(table + ((n * 16 + 255) & ~(int64_t)255));
+        hipLaunchKernelGGL(fast::sl_prep_kernel, dim3(1), dim3(kBlock), 0, st, d_t, d_m, (int)n,
+                           reinterpret_cast<fast::rec_t *>(table), const_cast<unsigned *>(f.flags));
+        const int k = (int)((n + kBlock - 1) / kBlock);
+        if (k <= 8) PDC_TRY(launch_fast<8>(f, grid, st));
+        else if (k <= 20) PDC_TRY(launch_fast<20>(f, grid, st));
+        else if (k <= 36) PDC_TRY(launch_fast<36>(f, grid, st));
+        else PDC_TRY(launch_fast<fast::kKMax>(f, grid, st));
+    } else if (n < 65536) {
         using L = Lds<unsigned short>;
         const int64_t slice = n < L::capacity ? n : L::capacity;
         const size_t lds = (size_t)L::fixed + (size_t)((slice + 7) & ~(int64_t)7) * 2;

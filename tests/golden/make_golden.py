@@ -71,9 +71,28 @@ def save(name, **arrays):
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def model_golden(GLS):
+    # G9 - GLS.model (spectral.py:169-204): the weighted sinusoid fit at the peak frequency and at an
+    # off-peak one, with heteroscedastic errors and with err=None (all-ones errors)
+    t, y, dy = synthetic_curve(400, 20241008 + 9, period=17.0)
+    tf = np.linspace(t[0] - 3.0, t[-1] + 3.0, 257)
+    out = dict(t=t, y=y, dy=dy, tf=tf)
+    for tag, err in (("err", dy), ("noerr", None)):
+        g = GLS()
+        ls = g(TSeries(t, y), err=err)
+        f_peak = float(ls.frequency[np.nanargmax(ls.values)])
+        out["f0_" + tag] = np.array([f_peak, 0.0371])
+        out["yf_" + tag] = np.stack([np.asarray(g.model(tf, f).values) for f in out["f0_" + tag]])
+        out["tf_sorted_" + tag] = np.asarray(g.model(tf, f_peak).time)
+    save("g9_model", **out)
+
+
 def main():
     spectral, phase = refstub.load()
     GLS = spectral.GLS
+    model_golden(GLS)
+    if "--only-g9" in sys.argv:
+        return
 
     # G1 — tests/test_spectral.py:7-24 (default grid; values default to ones)
     time = np.arange(0, 2.5 + 0.1, 0.1)

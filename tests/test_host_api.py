@@ -162,3 +162,18 @@ def test_no_silent_cpu_fallback():
         phase.PDM(n_periods=8)(TSeries(t, y))
     with pytest.raises(RuntimeError):
         phase.StringLength(n_periods=8)(TSeries(t, y))
+
+
+# ---- GLS.model against the reference's own output (golden G9, spectral.py:169-204) -----------------
+def test_gls_model_matches_reference_golden(golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "g9_model.npz"))
+    for tag, err in (("err", g["dy"]), ("noerr", None)):
+        gls = spectral.GLS()
+        gls.signal = TSeries(g["t"], g["y"])                      # what __call__ leaves behind
+        gls.err = np.ones_like(g["y"]) if err is None else err    # (spectral.py:99-101)
+        for f0, want in zip(g["f0_" + tag], g["yf_" + tag]):
+            fit = gls.model(g["tf"], float(f0))
+            assert isinstance(fit, TSeries)
+            np.testing.assert_array_equal(fit.time, g["tf_sorted_" + tag])
+            np.testing.assert_allclose(fit.values, want, rtol=1e-10, atol=1e-12)

@@ -44,6 +44,9 @@ def exact_power_and_sensitivity(t, y, err, freq, fit_mean, psd, eps=1e-12, trial
         with np.errstate(invalid="ignore"):
             wobble = np.fmax(wobble, np.abs(other - want))
     wobble[singular] = np.inf
+    # the slack is for ill-conditioned bins only: where both rotated variances are comfortably away
+    # from zero the plain 1e-6 gate applies and nothing below it is hidden
+    wobble[np.minimum(np.abs(CC), np.abs(SS)) > 1e-3] = 0.0
     return want, wobble
 
 

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): one rocprofv3 pass per counter set over the bench command,
+# plus a plain --kernel-trace --stats pass; then tools/pmc_summary.py merges them.
+#   tools/collect_pmc.sh gpurun_out/r02_pmc [bench args...]
+# Counter sets are kept apart because of the per-block slot limits (SQ 8, TCC 4: FETCH_SIZE takes 3,
+# WRITE_SIZE 2) - see /opt/skills/guides/MI355X_MICROARCH.md.
+set -u
+out=$1; shift
+args=${*:---steps 3 --warmup 1 --no-cpu-baseline}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p "$out"
+pass() {
+    name=$1; shift
+    rocprofv3 --pmc "$@" --kernel-trace -d "$out/$name" -o run --output-format csv -- python3 bench.py $args > "$out/$name.log" 2>&1
+    tail -1 "$out/$name.log" | cut -c1-200
+}
+pass valu  SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+pass lds   SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass l2    TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
+rocprofv3 --kernel-trace --stats -d "$out/stats" -o run --output-format csv -- python3 bench.py $args > "$out/stats.log" 2>&1
+python3 tools/pmc_summary.py "$out" --out "$out/pmc_summary.json" --command "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py $args"
