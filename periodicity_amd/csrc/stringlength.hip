@@ -711,7 +711,7 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
 namespace fast {
 
 constexpr int kNB = kBuckets;
-constexpr int kFWin = 208;             // sorted positions per range window (a range = window + < one bucket)
+constexpr int kFWin = 216;             // sorted positions per range window (a range = window + < one bucket)
 constexpr int kFCap = 255;             // samples a wave ranks by itself: counts and starts fit in bytes
 constexpr int kFine = 1024;            // fine buckets per range, 8-bit counters packed four to a word
 constexpr int kRanges = 320;           // >= capacity / kFWin + 2
@@ -1015,7 +1015,9 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             // segment is masked out.
             // Monotone map of the range's phases [lo_b, hi_b) / kNB onto kFine fine buckets: one fma
             // with a positive multiplier (any monotone map keeps the sort exact; mean occupancy ~0.2).
-            const double fsc = (double)kFine / (double)(hi_b - lo_b);
+            // (the scale only has to be positive and keep the map inside [0, kFine): a float reciprocal
+            // is plenty; indices are clamped anyway)
+            const double fsc = (double)((float)(kFine - 1) * __builtin_amdgcn_rcpf((float)(hi_b - lo_b)));
             const double fmul = (double)kNB * fsc, fadd = -(double)lo_b * fsc;
             reinterpret_cast<uint4 *>(fine32)[lane] = make_uint4(0u, 0u, 0u, 0u);
             if (lane < 4) fine32[kFine / 4 + lane] = 0u;
@@ -1029,23 +1031,24 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 ei[e] = n_idx[e];
             }
             phases4(et, period, y, safe, ephi);
-            unsigned long long ek[kRPer];
-            unsigned er[kRPer], esh[kRPer];
+            unsigned er[kRPer];
             int ef[kRPer];
             bool live[kRPer];
 #pragma unroll
             for (int e = 0; e < kRPer; ++e) {
                 live[e] = lane + e * 64 < cnt;
                 const double phi = ephi[e];
-                ek[e] = phase_key(phi);
                 int fb = (int)__builtin_fma(phi, fmul, fadd);
                 fb = fb < 0 ? 0 : (fb > kFine - 1 ? kFine - 1 : fb);
                 fb = phi == phi ? fb : kFine - 1;
+                // one bit pattern for every NaN phase: the sort key is the pattern itself
+                ephi[e] = __longlong_as_double((long long)phase_key(phi));
                 ef[e] = fb;
-                esh[e] = ((unsigned)fb & 3u) * 8u;
-                const unsigned old = atomicAdd(&fine32[live[e] ? fb >> 2 : lane], live[e] ? 1u << esh[e] : 0u);
-                er[e] = (old >> esh[e]) & 0xFFu;
+                const unsigned esh = ((unsigned)fb & 3u) * 8u;
+                const unsigned old = atomicAdd(&fine32[live[e] ? fb >> 2 : lane], live[e] ? 1u << esh : 0u);
+                er[e] = (old >> esh) & 0xFFu;
             }
+#define EK(e) ((unsigned long long)__double_as_longlong(ephi[e]))
             // the records of the next range go out now: t[] and the indices of this one are consumed
             if (r + kWaves < nranges) request(r + kWaves);
             unsigned mx = 0;
@@ -1094,7 +1097,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             for (int e = 0; e < kRPer; ++e) {
                 ec[e] = live[e] ? ec[e] - eb0[e] : 0u;
                 park[e] = live[e] ? eb0[e] + er[e] : (unsigned)(lane + e * 64);
-                keys_w[park[e]] = ek[e];
+                keys_w[park[e]] = EK(e);
                 idx_w[park[e]] = (unsigned short)ei[e];
             }
             wave_sync();
@@ -1112,18 +1115,19 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                     o = o >= ec[e] ? o - ec[e] : o;
                     oth[e] = in ? eb0[e] + o : park[e];
                     ky[e] = keys_w[oth[e]];
-                    before[e] += (in && ky[e] < ek[e]) ? 1u : 0u;
-                    tie = tie || (in && ky[e] == ek[e]);
+                    before[e] += (in && ky[e] < EK(e)) ? 1u : 0u;
+                    tie = tie || (in && ky[e] == EK(e));
                 }
                 if (__any(tie)) {  // equal phases of two different samples (rare): the index decides
 #pragma unroll
                     for (int e = 0; e < kRPer; ++e) {
                         const bool in = (unsigned)j < ec[e];
-                        if (in && ky[e] == ek[e] && (unsigned)idx_w[oth[e]] < ei[e]) ++before[e];
+                        if (in && ky[e] == EK(e) && (unsigned)idx_w[oth[e]] < ei[e]) ++before[e];
                     }
                 }
             }
             wave_sync();
+#undef EK
             // every sample writes its phase, then its m, to its final slot; lane j reads slot j back (the
             // 2 KB key array serves both in turn), so the segments are summed in sorted order whatever
             // order the atomics of P2 delivered the samples in: the result does not depend on timing
