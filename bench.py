@@ -72,26 +72,39 @@ def throughput_grid(t, nf):
     raise AssertionError((freq.size, nf))
 
 
-def source_hash():
-    """sha256 over the kernel sources; tools/pmc_summary.py stores the same value."""
-    h = hashlib.sha256()
+# which sources a profiled kernel was built from: a PMC summary entry is refused once any of them changed
+KERNEL_SOURCES = {
+    "gls_": ("gls.hip", "gls_epilogue.h", "pdc_internal.h"),
+    "pdm_": ("pdm.hip", "pdc_internal.h"),
+    "sl_": ("stringlength.hip", "pdc_internal.h"),
+    "fft_": ("glsfft.hip", "pdc_internal.h"),
+    "glsfft_": ("glsfft.hip", "gls_epilogue.h", "pdc_internal.h"),
+    "peak": ("peaks.hip", "pdc_internal.h"),
+}
+
+
+def source_hashes():
+    """sha256 (first 16 hex digits) of every kernel source; tools/pmc_summary.py stores the same."""
     src = os.path.join(ROOT, "periodicity_amd", "csrc")
-    for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(src, name), "rb").read())
-    return h.hexdigest()[:16]
+    return {name: hashlib.sha256(open(os.path.join(src, name), "rb").read()).hexdigest()[:16]
+            for name in sorted(os.listdir(src)) if name.endswith((".hip", ".h"))}
+
+
+def sources_of(kernel_name):
+    for prefix, files in KERNEL_SOURCES.items():
+        if prefix in kernel_name:
+            return files
+    return tuple(source_hashes())
 
 
 def pmc_for(kernel_substr, measured_ms):
     """Counters of the profiled kernel whose name contains `kernel_substr` and whose profiled duration
-    is closest to this run's; (None, reason) when the summary is absent or belongs to other sources."""
+    is closest to this run's; (None, reason) when the summary is absent or was collected for other
+    sources of that kernel."""
     if not os.path.isfile(PMC_SUMMARY):
         return None, "profiles/r02_pmc_summary.json is missing"
     summ = json.load(open(PMC_SUMMARY))
-    if summ.get("src_sha") != source_hash():
-        return None, (f"profiles/r02_pmc_summary.json was collected for kernel sources "
-                      f"{summ.get('src_sha')}, this tree is {source_hash()}: refused as stale")
+    now, then = source_hashes(), summ.get("src_sha", {})
     best = None
     for name, k in summ.get("kernels", {}).items():
         if kernel_substr in name and "SQ_INSTS_VALU" in k and k.get("ms"):
@@ -100,6 +113,10 @@ def pmc_for(kernel_substr, measured_ms):
                 best = (d, name, k)
     if best is None or best[0] > 0.25:
         return None, f"no profiled '{kernel_substr}' launch within 25% of {measured_ms:.3f} ms"
+    changed = [f for f in sources_of(best[1]) if now.get(f) != then.get(f)]
+    if changed:
+        return None, (f"profiles/r02_pmc_summary.json was collected before {', '.join(changed)} changed: "
+                      "refused as stale")
     return dict(best[2], name=best[1]), None
 
 

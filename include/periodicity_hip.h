@@ -173,6 +173,29 @@ int pdc_gls_batch_highest_peak(const double *t, const double *y, const double *d
                                double f0, double delta, int64_t nf, int fit_mean, int psd,
                                int64_t *idx_out, double *val_out, int device);
 
+/* The k <= 8 highest (by_prominence == 0: FSeries.psort_by_peak, core.py:944-946) or most prominent
+ * (psort_by_prominence :948-950, period_at_highest_prominence :957-961) find_peaks() maxima of each
+ * spectrum, found and ranked on the device: count[b] = number of maxima scipy.signal.find_peaks(x,
+ * prominence=0.0) reports; idx/height/prominence are [n_curves][k], ranked descending, padded with
+ * -1 / NaN; prominences follow scipy.signal.peak_prominences (wlen=None).  half_lo / half_hi
+ * ([n_curves][k], -1 when absent; may be NULL) are the two sign changes of x - (x[idx] - key/2), key =
+ * the ranking quantity, that FSeries.periods_at_half_max (core.py:963-978) looks up for
+ * peak_order = rank + 1: half_hi = the last one inside x[:idx], half_lo = the first one of x[idx:]
+ * as an absolute bin (np.where(np.diff(np.signbit(..))), core.py:362); the method returns
+ * (period[half_lo], period[half_hi]).  Equal keys rank the lower bin first.
+ * pdc_gls_batch_peaks runs the batched periodogram first; the spectra never leave HBM. */
+int pdc_peaks_topk(const double *power, int64_t n_curves, int64_t nf, int k, int by_prominence,
+                   int64_t *count_out, int64_t *idx_out, double *height_out, double *prominence_out,
+                   int64_t *half_lo_out, int64_t *half_hi_out, int device);
+int pdc_peaks_topk_dev(int device, void *stream, const double *d_power, int64_t n_curves, int64_t nf,
+                       int k, int by_prominence, int64_t *d_count, int64_t *d_idx, double *d_height,
+                       double *d_prominence, int64_t *d_half_lo, int64_t *d_half_hi);
+int pdc_gls_batch_peaks(const double *t, const double *y, const double *dy, const int64_t *offsets,
+                        int64_t n_curves, int shared_t, double f0, double delta, int64_t nf,
+                        int fit_mean, int psd, int k, int by_prominence,
+                        int64_t *count_out, int64_t *idx_out, double *height_out,
+                        double *prominence_out, int64_t *half_lo_out, int64_t *half_hi_out, int device);
+
 /* ---- Phase Dispersion Minimization -----------------------------------------------------------
  * Replaces pool.map(PDM._pdm, periods) (phase.py:128-149, 185-187): theta_out[p] for every trial
  * period, bins phi in [k/m0, (k+nc)/m0) U [0, (k+nc-m0)/m0), m0 = nb*nc, phi = (t/period) % 1

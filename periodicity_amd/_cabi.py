@@ -63,6 +63,10 @@ PROTOTYPES = {
     "pdc_highest_peak": (_I, [_VP, _L, _L, _VP, _VP, _I]),
     "pdc_highest_peak_dev": (_I, [_I, _VP, _VP, _L, _L, _VP, _VP]),
     "pdc_gls_batch_highest_peak": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _I, _I, _VP, _VP, _I]),
+    "pdc_peaks_topk": (_I, [_VP, _L, _L, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _I]),
+    "pdc_peaks_topk_dev": (_I, [_I, _VP, _VP, _L, _L, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "pdc_gls_batch_peaks": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _I, _I, _I, _I,
+                                 _VP, _VP, _VP, _VP, _VP, _VP, _I]),
     "pdc_pdm_scan": (_I, [_VP, _VP, _L, _VP, _L, _I, _I, _D, _VP, _I]),
     "pdc_pdm_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _I, _I, _D, _VP]),
     "pdc_stringlength_scan": (_I, [_VP, _VP, _L, _VP, _L, _VP, _I]),
@@ -328,6 +332,47 @@ def gls_batch_highest_peak(t, y, dy, offsets, f0, delta, nf, fit_mean=True, psd=
                                            int(shared_t), f0, delta, nf, int(bool(fit_mean)),
                                            int(bool(psd)), _ptr(idx), _ptr(val), dev))
     return idx, val
+
+
+def _topk_outputs(nb, k):
+    return {"count": np.empty(nb, dtype=np.int64), "indices": np.empty((nb, k), dtype=np.int64),
+            "heights": np.empty((nb, k)), "prominences": np.empty((nb, k)),
+            "half_lo": np.empty((nb, k), dtype=np.int64), "half_hi": np.empty((nb, k), dtype=np.int64)}
+
+
+def peaks_topk(power, k=1, by_prominence=False, device=None):
+    """The ``k`` (<= 8) highest, or most prominent, ``find_peaks`` maxima of each row of ``power`` with
+    prominences and half-maximum crossings (``pdc_peaks_topk``); a dict of arrays shaped ``[rows, k]``
+    (``count``: ``[rows]``), ranked descending, padded with -1 / NaN."""
+    power = np.ascontiguousarray(power, dtype=np.float64)
+    rows = power.reshape(1, -1) if power.ndim == 1 else power
+    out = _topk_outputs(rows.shape[0], int(k))
+    dev = default_device() if device is None else device
+    check(lib().pdc_peaks_topk(_ptr(rows), rows.shape[0], rows.shape[1], int(k), int(bool(by_prominence)),
+                               _ptr(out["count"]), _ptr(out["indices"]), _ptr(out["heights"]),
+                               _ptr(out["prominences"]), _ptr(out["half_lo"]), _ptr(out["half_hi"]), dev))
+    return out
+
+
+def gls_batch_peaks(t, y, dy, offsets, f0, delta, nf, k=1, by_prominence=False, fit_mean=True,
+                    psd=False, shared_t=False, device=None):
+    """Batched periodograms reduced on the device to their ``k`` best peaks (see :func:`peaks_topk`)."""
+    t, y = _f64(t, "t"), _f64(y, "y")
+    dy = None if dy is None else _f64(dy, "dy")
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    nb = offsets.size - 1
+    if nb < 1 or offsets[-1] != y.size or (dy is not None and dy.size != y.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    if (shared_t and t.size != offsets[1]) or (not shared_t and t.size != y.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    out = _topk_outputs(nb, int(k))
+    dev = default_device() if device is None else device
+    check(lib().pdc_gls_batch_peaks(_ptr(t), _ptr(y), _ptr(dy), _ptr(offsets), nb, int(shared_t), f0,
+                                    delta, nf, int(bool(fit_mean)), int(bool(psd)), int(k),
+                                    int(bool(by_prominence)), _ptr(out["count"]), _ptr(out["indices"]),
+                                    _ptr(out["heights"]), _ptr(out["prominences"]), _ptr(out["half_lo"]),
+                                    _ptr(out["half_hi"]), dev))
+    return out
 
 
 def pdm_scan(t, x, periods, nb, nc, sigma, device=None, devices=None):

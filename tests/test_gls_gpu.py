@@ -356,6 +356,27 @@ def test_full_size_c3_batch_peaks_only():
         # (a lone curve picks another tile shape than the 4096-curve batch: equal to rounding)
         assert argmax[b] == np.argmax(single) and abs(amax[b] / single.max() - 1) < 1e-12
         assert abs(val[b] / single[idx[b]] - 1) < 1e-12
+    # the same batch reduced to its 4 highest / most prominent find_peaks() maxima with prominences and
+    # half-maximum crossings (core.py:283-317, 944-978): 1.64 GB of spectra stay in HBM
+    from scipy.signal import find_peaks
+    top = _cabi.gls_batch_peaks(t.ravel(), y.ravel(), dy.ravel(), offsets, f0, delta, nf, k=4)
+    pro = _cabi.gls_batch_peaks(t.ravel(), y.ravel(), dy.ravel(), offsets, f0, delta, nf, k=4,
+                                by_prominence=True)
+    assert np.array_equal(top["indices"][:, 0], idx)
+    assert np.all(top["count"] > 100) and np.all(pro["prominences"][:, 0] >= pro["prominences"][:, 1])
+    for b in rng.integers(0, B, 3):
+        single = _cabi.gls_scan(t[b], y[b], dy[b], f0, delta, nf)
+        pk, res = find_peaks(single, prominence=0.0)
+        order = np.lexsort((pk, -single[pk]))[:4]
+        # (batch and single-curve spectra agree to rounding, so ranks of near-equal peaks may swap:
+        # compare the winner exactly and the rest as sets of bins)
+        assert top["indices"][b, 0] == pk[order][0]
+        assert abs(top["count"][b] - pk.size) <= 2
+        order_p = np.lexsort((pk, -res["prominences"]))[:4]
+        assert pro["indices"][b, 0] == pk[order_p][0]
+        assert abs(pro["prominences"][b, 0] / res["prominences"][order_p][0] - 1) < 1e-9
+        lo, hi = top["half_lo"][b, 0], top["half_hi"][b, 0]
+        assert 0 <= hi < idx[b] <= lo < nf and lo - hi < 40       # the half-maximum width of the main peak
 
 
 def test_full_size_c4_on_one_gpu_both_paths():

@@ -62,3 +62,104 @@ def test_batched_periodograms_reduced_on_device():
         assert fs.period_at_highest_peak == 1 / freq[idx[b]]        # the reference's consumer
         assert val[b] == power[b, idx[b]]
         assert abs(1 / freq[idx[b]] - (7.0 + 3 * b)) < 0.5
+
+
+# ---- top-k, prominences, half-maximum crossings (core.py:283-317, 944-978) --------------------------
+def scipy_ranked(x, k, by_prominence):
+    """(count, idx[k], height[k], prom[k]) as the host FSeries methods would rank them; equal keys:
+    lower bin first (the device's rule; numpy's argsort leaves it open)."""
+    idx, res = find_peaks(x, prominence=0.0)
+    prom = res["prominences"]
+    key = prom if by_prominence else x[idx]
+    order = np.lexsort((idx, -key))[:k]
+    pad = k - order.size
+    return (idx.size, np.concatenate([idx[order], -np.ones(pad, dtype=np.int64)]),
+            np.concatenate([x[idx][order], np.full(pad, np.nan)]),
+            np.concatenate([prom[order], np.full(pad, np.nan)]))
+
+
+def host_half_max(x, idmax, key):
+    """The two lookups of FSeries.periods_at_half_max (core.py:972-975) as absolute bins, -1 if none."""
+    half = x[idmax] - key / 2
+    left = np.where(np.diff(np.signbit(x[:idmax] - half)))[0]
+    right = np.where(np.diff(np.signbit(x[idmax:] - half)))[0]
+    return (int(idmax + right[0]) if right.size else -1), (int(left[-1]) if left.size else -1)
+
+
+def check_topk(x, k, by_prominence):
+    got = _cabi.peaks_topk(x, k=k, by_prominence=by_prominence)
+    count, idx, height, prom = scipy_ranked(x, k, by_prominence)
+    assert got["count"][0] == count
+    np.testing.assert_array_equal(got["indices"][0], idx)
+    np.testing.assert_array_equal(got["heights"][0], height)
+    np.testing.assert_array_equal(got["prominences"][0], prom)     # same subtraction: bit-exact
+    for r in range(k):
+        if idx[r] < 0:
+            assert got["half_lo"][0, r] == -1 and got["half_hi"][0, r] == -1
+            continue
+        lo, hi = host_half_max(x, idx[r], prom[r] if by_prominence else height[r])
+        assert (got["half_lo"][0, r], got["half_hi"][0, r]) == (lo, hi), (r, idx[r])
+
+
+def test_topk_prominences_and_half_max_follow_scipy():
+    rng = np.random.default_rng(3)
+    smooth = np.convolve(rng.standard_normal(6000), np.ones(25) / 25, mode="same")   # periodogram-like
+    rows = [rng.standard_normal(4000), smooth, rng.standard_normal(3000).round(1),     # ties, flat tops
+            np.abs(np.sin(np.arange(2000) * 0.05)) * np.linspace(1, 2, 2000),
+            np.arange(50.0), np.zeros(30), np.array([0.0, 1.0, 0.0]), np.array([1.0, 2.0]),
+            np.array([0.0, 2.0, 2.0, 3.0, 3.0, 1.0, 3.0, 3.0, 0.0]),
+            np.array([3.0, 1.0, 2.0, 1.0, 5.0, 0.0, 4.0, 0.5, 4.0, 0.0])]
+    nanrow = np.convolve(rng.standard_normal(900), np.ones(9) / 9, mode="same")
+    nanrow[[40, 41, 500]] = np.nan
+    rows.append(nanrow)
+    for x in rows:
+        for k in (1, 3, 8):
+            for by_prominence in (False, True):
+                check_topk(np.asarray(x, dtype=float), k, by_prominence)
+
+
+def test_topk_long_rows_hop_blocks_and_match_fseries():
+    """Rows longer than 64 x 4096 bins use coarser blocks; the consumers' own answers come out."""
+    rng = np.random.default_rng(11)
+    n = 300_000
+    x = np.convolve(rng.standard_normal(n), np.ones(101) / 101, mode="same") + 0.3 * np.sin(np.arange(n) / 4000.0)
+    freq = np.linspace(0.001, 3.0, n)
+    fs = FSeries(freq, x)
+    top = _cabi.peaks_topk(x, k=4, by_prominence=False)
+    assert 1 / freq[top["indices"][0, 0]] == fs.period_at_highest_peak
+    np.testing.assert_array_equal(1 / freq[top["indices"][0]], fs.psort_by_peak()[:4])
+    lower, upper = fs.periods_at_half_max(peak_order=2)
+    assert (1 / freq[top["half_lo"][0, 1]], 1 / freq[top["half_hi"][0, 1]]) == (lower, upper)
+    pro = _cabi.peaks_topk(x, k=4, by_prominence=True)
+    assert 1 / freq[pro["indices"][0, 0]] == fs.period_at_highest_prominence
+    np.testing.assert_array_equal(1 / freq[pro["indices"][0]], fs.psort_by_prominence()[:4])
+    lower, upper = fs.periods_at_half_max(peak_order=1, use_prominence=True)
+    assert (1 / freq[pro["half_lo"][0, 0]], 1 / freq[pro["half_hi"][0, 0]]) == (lower, upper)
+    check_topk(x, 8, True)
+
+
+def test_gls_batch_peaks_keeps_spectra_on_device():
+    rng = np.random.default_rng(6)
+    lens = [400, 257, 900]
+    ts, ys, dys = [], [], []
+    for i, n in enumerate(lens):
+        t = np.sort(rng.uniform(0, n, n))
+        dy = rng.uniform(0.05, 0.2, n)
+        ts.append(t)
+        dys.append(dy)
+        ys.append(np.sin(2 * np.pi * t / (9.0 + 4 * i)) + 0.5 * np.sin(2 * np.pi * t / 3.1) + dy * rng.standard_normal(n))
+    offsets = np.concatenate([[0], np.cumsum(lens)])
+    freq = np.arange(0.003, 0.6, 0.0003)
+    f0, delta, nf = _cabi.grid_params(freq)
+    t, y, dy = map(np.concatenate, (ts, ys, dys))
+    power, _, _ = _cabi.gls_scan_batch(t, y, dy, offsets, f0, delta, nf)
+    for by_prominence in (False, True):
+        got = _cabi.gls_batch_peaks(t, y, dy, offsets, f0, delta, nf, k=4, by_prominence=by_prominence)
+        for b in range(len(lens)):
+            count, idx, height, prom = scipy_ranked(power[b], 4, by_prominence)
+            assert got["count"][b] == count
+            np.testing.assert_array_equal(got["indices"][b], idx)
+            np.testing.assert_array_equal(got["prominences"][b], prom)
+        assert abs(1 / freq[got["indices"][0, 0]] - 9.0) < 0.5
+    with pytest.raises(ValueError):
+        _cabi.peaks_topk(power[0], k=9)

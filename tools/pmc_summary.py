@@ -8,8 +8,8 @@ once; FETCH_SIZE and WRITE_SIZE need a pass each).  Per kernel (name + grid size
 template run on two workloads stays apart) the mean over dispatches of every counter, the mean
 dispatch duration, and - when both FETCH_SIZE and WRITE_SIZE were collected - the HBM-side bytes per
 launch with the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE counts 64 B
-per 128-B request: doubled; both are in KB).  The sha256 of the kernel sources is stored so that
-bench.py can refuse a summary collected for other sources.
+per 128-B request: doubled; both are in KB).  The sha256 of every kernel source file is stored so that
+bench.py can refuse the entries of a kernel whose sources changed since.
 
 Without --out: prints the per-kernel means (the round-1 behaviour), optionally filtered by a
 kernel-name substring given as second positional argument.
@@ -70,14 +70,14 @@ def main():
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             e["hbm_bytes"] = int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
         kernels[k] = e
-    out = {"src_sha": bench.source_hash(), "generated_by": "tools/pmc_summary.py",
+    out = {"src_sha": bench.source_hashes(), "generated_by": "tools/pmc_summary.py",
            "command": args.command,
            "note": "means per dispatch; ms = mean dispatch duration under the profiler (PMC passes run "
                    "a few % slower than un-profiled); FETCH_SIZE/WRITE_SIZE in KB; hbm_bytes = "
                    "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE tallies 64 B per 128-B request)",
            "kernels": kernels}
     json.dump(out, open(args.out, "w"), indent=1, sort_keys=True)
-    print(f"wrote {args.out}: {len(kernels)} kernels, sources {out['src_sha']}")
+    print(f"wrote {args.out}: {len(kernels)} kernels")
 
 
 if __name__ == "__main__":
