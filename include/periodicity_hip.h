@@ -207,6 +207,25 @@ int pdc_pdm_scan_dev(int device, void *stream, const double *d_t, const double *
                      const double *d_periods, int64_t n_periods, int nb, int nc, double sigma,
                      double *d_theta);
 
+/* The two period searches phase.py:11-15 lists as TODO, on the PDM binning kernel (same phase bins
+ * [k/r, (k+1)/r) against the doubles k/r as phase.py:137, same exact phases, one thread per trial
+ * period; only the epilogue differs).  The reference has no implementation: parity is pinned to the
+ * published formulas, restated in oracle/scan_oracle.py.
+ *   Analysis of Variance (Schwarzenberg-Czerny 1989, MNRAS 241, 153, eq. 1-3) over n_bins phase bins:
+ *     theta_out[p] = [sum_i n_i (xbar_i - xbar)^2 / (r - 1)] / [sum_i sum_j (x_ij - xbar_i)^2 / (n - r)]
+ *   Conditional entropy (Graham et al. 2013, MNRAS 434, 2629, eq. 1) over n_phase x n_mag cells:
+ *     entropy_out[p] = sum_ij p(m_j, phi_i) ln(p(phi_i) / p(m_j, phi_i));  mag_bin[i] is the magnitude
+ *     bin (0 .. n_mag-1, stored as a double) of sample i, (n_phase + 1) * n_mag <= 191. */
+int pdc_aov_scan(const double *t, const double *x, int64_t n, const double *periods, int64_t n_periods,
+                 int n_bins, double *theta_out, int device);
+int pdc_aov_scan_dev(int device, void *stream, const double *d_t, const double *d_x, int64_t n,
+                     const double *d_periods, int64_t n_periods, int n_bins, double *d_theta);
+int pdc_cond_entropy_scan(const double *t, const double *mag_bin, int64_t n, const double *periods,
+                          int64_t n_periods, int n_phase, int n_mag, double *entropy_out, int device);
+int pdc_cond_entropy_scan_dev(int device, void *stream, const double *d_t, const double *d_mag_bin,
+                              int64_t n, const double *d_periods, int64_t n_periods, int n_phase,
+                              int n_mag, double *d_entropy);
+
 /* The period grid cut into contiguous slabs over `n_devices` GPUs of this node (one process, one
  * stream per slab; a device may be listed more than once).  Replaces the multiprocessing.Pool
  * fan-out of phase.py:182-186; trial periods are independent, so there is no exchange step. */

@@ -261,6 +261,69 @@ def pdm(time, values, nb=5, nc=2, p_min=None, p_max=None, n_periods=1000, oversa
     return freq[order], thetas[order]
 
 
+# The two scans below are listed as TODO in the reference (``phase.py:11-15``) and have no upstream
+# implementation: PARITY UNPINNED by the reference.  They restate the published formulas; the phase
+# bins are the PDM fine bins of ``phase.py:137`` ([k/r, (k+1)/r) against the doubles k/r, phi from the
+# same ``(t / period) % 1``), phi == 1.0 joins the last bin, NaN phases belong to no bin.
+def _phase_bins(t, period, r):
+    phi = (t / period) % 1
+    edges = np.arange(r + 1) / r
+    k = np.searchsorted(edges, phi, side="right") - 1
+    k = np.where(np.isnan(phi), -1, np.minimum(k, r - 1))
+    return k
+
+
+def aov_theta(t, x, period, n_bins=10):
+    """Analysis-of-Variance statistic, Schwarzenberg-Czerny 1989 (MNRAS 241, 153), eq. 1-3:
+    ``s1^2 / s2^2`` with ``s1^2 = sum n_i (xbar_i - xbar)^2 / (r - 1)`` and
+    ``s2^2 = sum_i sum_j (x_ij - xbar_i)^2 / (n - r)`` over ``r`` phase bins."""
+    k = _phase_bins(t, period, n_bins)
+    ok = k >= 0
+    n = int(ok.sum())
+    if n <= n_bins or n_bins < 2:
+        return np.nan
+    xbar = x[ok].mean()
+    between = within = 0.0
+    for i in range(n_bins):
+        xi = x[k == i]
+        if xi.size:
+            between += xi.size * (xi.mean() - xbar) ** 2
+            within += np.sum((xi - xi.mean()) ** 2)
+    return (between / (n_bins - 1)) / (within / (n - n_bins))
+
+
+def aov_scan(t, x, periods, n_bins=10):
+    return np.array([aov_theta(t, x, p, n_bins) for p in periods])
+
+
+def magnitude_bins(values, n_mag=5):
+    """Graham et al. 2013: magnitudes normalised to the unit interval, ``n_mag`` equal bins (the
+    maximum joins the last one); the bin index of every sample as float64 (the C ABI's input)."""
+    v = np.asarray(values, dtype=float)
+    lo, hi = np.nanmin(v), np.nanmax(v)
+    unit = (v - lo) / (hi - lo)
+    return np.minimum(np.floor(unit * n_mag), n_mag - 1).astype(float)
+
+
+def cond_entropy(t, mag_bin, period, n_phase=10, n_mag=5):
+    """Conditional entropy, Graham et al. 2013 (MNRAS 434, 2629), eq. 1:
+    ``H_c = sum_ij p(m_j, phi_i) ln(p(phi_i) / p(m_j, phi_i))`` over the occupied cells."""
+    k = _phase_bins(t, period, n_phase)
+    ok = k >= 0
+    n = int(ok.sum())
+    if n == 0:
+        return np.nan
+    cells = np.zeros((n_phase, n_mag))
+    np.add.at(cells, (k[ok], mag_bin[ok].astype(int)), 1)
+    rows = cells.sum(axis=1, keepdims=True) * np.ones_like(cells)
+    live = cells > 0
+    return float(np.sum(cells[live] / n * np.log(rows[live] / cells[live])))
+
+
+def cond_entropy_scan(t, mag_bin, periods, n_phase=10, n_mag=5):
+    return np.array([cond_entropy(t, mag_bin, p, n_phase, n_mag) for p in periods])
+
+
 def stringlength_one(t, m, period):
     """Dworetsky string length for one trial period: ``StringLength._stringlength``
     (``phase.py:45-51``) through ``TSeries.fold`` (``core.py:543-544``) and the stable

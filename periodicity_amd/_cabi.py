@@ -69,6 +69,10 @@ PROTOTYPES = {
                                  _VP, _VP, _VP, _VP, _VP, _VP, _I]),
     "pdc_pdm_scan": (_I, [_VP, _VP, _L, _VP, _L, _I, _I, _D, _VP, _I]),
     "pdc_pdm_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _I, _I, _D, _VP]),
+    "pdc_aov_scan": (_I, [_VP, _VP, _L, _VP, _L, _I, _VP, _I]),
+    "pdc_aov_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _I, _VP]),
+    "pdc_cond_entropy_scan": (_I, [_VP, _VP, _L, _VP, _L, _I, _I, _VP, _I]),
+    "pdc_cond_entropy_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _I, _I, _VP]),
     "pdc_stringlength_scan": (_I, [_VP, _VP, _L, _VP, _L, _VP, _I]),
     "pdc_stringlength_work_bytes": (_L, [_L, _L]),
     "pdc_stringlength_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _VP, _VP, _L]),
@@ -392,6 +396,33 @@ def pdm_scan(t, x, periods, nb, nc, sigma, device=None, devices=None):
     dev = default_device() if device is None else device
     check(lib().pdc_pdm_scan(_ptr(t), _ptr(x), t.size, _ptr(periods), periods.size, int(nb),
                              int(nc), float(sigma), _ptr(out), dev))
+    return out
+
+
+def aov_scan(t, x, periods, n_bins, device=None):
+    """Analysis-of-Variance statistic at every trial period (``pdc_aov_scan``)."""
+    t, x, periods = _f64(t, "t"), _f64(x, "x"), _f64(periods, "periods")
+    if x.size != t.size:
+        raise ValueError("Input arrays have incompatible lengths.")
+    out = np.empty(periods.size, dtype=np.float64)
+    dev = default_device() if device is None else device
+    check(lib().pdc_aov_scan(_ptr(t), _ptr(x), t.size, _ptr(periods), periods.size, int(n_bins),
+                             _ptr(out), dev))
+    return out
+
+
+def cond_entropy_scan(t, mag_bin, periods, n_phase, n_mag, device=None):
+    """Conditional entropy at every trial period (``pdc_cond_entropy_scan``); ``mag_bin`` holds the
+    magnitude bin (0 .. n_mag-1) of every sample."""
+    t, mag_bin, periods = _f64(t, "t"), _f64(mag_bin, "mag_bin"), _f64(periods, "periods")
+    if mag_bin.size != t.size:
+        raise ValueError("Input arrays have incompatible lengths.")
+    if mag_bin.size and not (np.all(mag_bin >= 0) and np.all(mag_bin < n_mag)):
+        raise ValueError("magnitude bins must lie in 0 .. n_mag-1")
+    out = np.empty(periods.size, dtype=np.float64)
+    dev = default_device() if device is None else device
+    check(lib().pdc_cond_entropy_scan(_ptr(t), _ptr(mag_bin), t.size, _ptr(periods), periods.size,
+                                      int(n_phase), int(n_mag), _ptr(out), dev))
     return out
 
 

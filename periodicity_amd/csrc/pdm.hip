@@ -52,6 +52,11 @@ struct PdmArgs {
     double *stat = nullptr;
     int64_t z_len = 0, p_pad = 0;
     int n_z = 1, n_stat = 0;
+    // which statistic the epilogue evaluates from the same histograms: 0 = PDM theta (phase.py:128-149);
+    // the scans the reference lists as TODO at phase.py:11-15: 1 = Analysis of Variance
+    // (Schwarzenberg-Czerny 1989; nb phase bins), 2 = conditional entropy (Graham et al. 2013; nb
+    // phase bins x nc magnitude bins, x = magnitude bin of every sample)
+    int kind = 0;
 };
 
 template <int BLOCK>
@@ -140,17 +145,65 @@ __device__ __forceinline__ double theta_from_bins(SumAt sum_at, CntAt cnt_at, in
     return good == 0 ? __builtin_nan("") : (num / (double)(n_sum - good)) / sigma;
 }
 
+// Analysis of Variance (Schwarzenberg-Czerny 1989, MNRAS 241, 153, eq. 1-3) from the same histogram:
+// r = m0 phase bins [k/r, (k+1)/r) (phi == 1.0 joins the last one), n valid samples,
+//     s1^2 = sum_i n_i (xbar_i - xbar)^2 / (r - 1),   s2^2 = sum_i sum_j (x_ij - xbar_i)^2 / (n - r),
+// Theta_AoV = s1^2 / s2^2.  With S_i = sum of the (mean-shifted) samples of bin i and Q their total
+// square: between = sum S_i^2 / n_i - (sum S_i)^2 / n,  within = Q - sum S_i^2 / n_i.
+template <typename SumAt, typename CntAt>
+__device__ __forceinline__ double aov_from_bins(SumAt sum_at, CntAt cnt_at, int m0, double q_valid) {
+    double per_bin = 0.0, s_all = 0.0;
+    long long n = 0;
+    for (int k = 0; k < m0; ++k) {
+        double s = sum_at(k);
+        long long c = cnt_at(k);
+        if (k == m0 - 1) {
+            s += sum_at(m0);
+            c += cnt_at(m0);
+        }
+        if (c > 0) per_bin += s * s / (double)c;
+        s_all += s;
+        n += c;
+    }
+    if (n <= m0 || m0 < 2) return __builtin_nan("");
+    const double between = per_bin - s_all * s_all / (double)n;
+    const double within = q_valid - per_bin;
+    return ((double)(n - m0) * between) / ((double)(m0 - 1) * within);
+}
+
+// Conditional entropy (Graham et al. 2013, MNRAS 434, 2629, eq. 1): H_c = sum_ij p(m_j, phi_i)
+// ln(p(phi_i) / p(m_j, phi_i)) over the occupied cells of an m0 x mag (phase x magnitude) partition;
+// cnt_at(i * mag + j) reads cell (i, j), row m0 (phi == 1.0) joins row m0 - 1.
+template <typename CntAt>
+__device__ __forceinline__ double ce_from_bins(CntAt cnt_at, int m0, int mag) {
+    long long n = 0;
+    for (int c = 0; c < (m0 + 1) * mag; ++c) n += cnt_at(c);
+    if (n == 0) return __builtin_nan("");
+    double h = 0.0;
+    for (int i = 0; i < m0; ++i) {
+        long long row = 0;
+        for (int j = 0; j < mag; ++j) row += cnt_at(i * mag + j) + (i == m0 - 1 ? cnt_at(m0 * mag + j) : 0);
+        for (int j = 0; j < mag; ++j) {
+            const long long c = cnt_at(i * mag + j) + (i == m0 - 1 ? cnt_at(m0 * mag + j) : 0);
+            if (c > 0) h += ((double)c / (double)n) * log((double)row / (double)c);
+        }
+    }
+    return h;
+}
+
 // SPLIT waves of a workgroup share one group of 64 trial periods (lane = period) and split every
 // staged chunk of samples between them, so that a grid of ~1e5 periods still puts several waves on
 // every SIMD (the loop is a chain of LDS read -> ALU -> LDS atomic: it needs wave-level parallelism
 // to hide latency).  Each thread keeps its own private histogram; the SPLIT partial histograms of
 // a period are summed in a fixed order at the end.
 // ZS: split mode (the samples are split over blockIdx.y as well, see PdmArgs).
-template <int BLOCK, int SPLIT, bool ZS = false>
+// CE: conditional-entropy cells (phase bin x magnitude bin, counts only) instead of phase bins.
+template <int BLOCK, int SPLIT, bool ZS = false, bool CE = false>
 __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int m0 = a.nb * a.nc;
-    const int nbins = m0 + 1;  // + overflow bin for phi == 1.0
+    const int mag = CE ? a.nc : 1;                 // magnitude bins per phase bin
+    const int m0 = CE ? a.nb : a.nb * a.nc;        // phase bins
+    const int nbins = (m0 + 1) * mag;              // + overflow row for phi == 1.0
     double2 *stage = reinterpret_cast<double2 *>(lds_raw);                  // [kChunk] (t, x')
     // the staging area doubles as the q_over/q_nan exchange ([2][BLOCK] doubles) at the end
     constexpr int kStage = kChunk > BLOCK ? kChunk : BLOCK;
@@ -212,7 +265,7 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         __syncthreads();
         for (int i = tid; i < kChunk; i += BLOCK) {
             const int64_t g = base + i;
-            stage[i] = g < s_end ? make_double2(a.t[g], a.x[g] - mean) : make_double2(0.0, 0.0);
+            stage[i] = g < s_end ? make_double2(a.t[g], CE ? a.x[g] : a.x[g] - mean) : make_double2(0.0, 0.0);
         }
         __syncthreads();
         const int cnt = (int)((s_end - base) < kChunk ? (s_end - base) : kChunk);
@@ -243,8 +296,12 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
             if (k == m0) q_over += tx.y * tx.y;
         };
         auto add = [&](const int k, const double val, const unsigned inc) {
-            atomicAdd(&hsum[k * BLOCK + tid], val);
-            atomicAdd(&hcnt[k * BLOCK + tid], inc);
+            if (CE) {   // val = the sample's magnitude bin; a NaN phase (inc == 0) counts nowhere
+                atomicAdd(&hcnt[(k * mag + (int)val) * BLOCK + tid], inc);
+            } else {
+                atomicAdd(&hsum[k * BLOCK + tid], val);
+                atomicAdd(&hcnt[k * BLOCK + tid], inc);
+            }
         };
         auto update = [&](const double2 tx) {
             int k;
@@ -305,9 +362,11 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         a.pq[(z * 2 + 1) * a.p_pad + pidx] = q_nan;
         return;
     }
-    a.theta[pidx] = theta_from_bins([&](int b) { return hsum[b * BLOCK + tid]; },
-                                    [&](int b) { return (long long)hcnt[b * BLOCK + tid]; }, m0, a.nc, q_total,
-                                    q_nan, q_over, a.sigma);
+    auto sum_at = [&](int b) { return hsum[b * BLOCK + tid]; };
+    auto cnt_at = [&](int b) { return (long long)hcnt[b * BLOCK + tid]; };
+    if (CE) a.theta[pidx] = ce_from_bins(cnt_at, m0, mag);
+    else if (a.kind == 1) a.theta[pidx] = aov_from_bins(sum_at, cnt_at, m0, q_total - q_nan);
+    else a.theta[pidx] = theta_from_bins(sum_at, cnt_at, m0, a.nc, q_total, q_nan, q_over, a.sigma);
 }
 
 // Split mode, last step: one thread per trial period adds the slices' histograms in slice order
@@ -336,9 +395,10 @@ __global__ __launch_bounds__(64) void pdm_finish_kernel(PdmArgs a) {
         q_over += a.pq[(z * 2 + 0) * a.p_pad + pidx];
         q_nan += a.pq[(z * 2 + 1) * a.p_pad + pidx];
     }
-    a.theta[pidx] = theta_from_bins([&](int b) { return hsum[b * 64 + tid]; },
-                                    [&](int b) { return hcnt[b * 64 + tid]; }, m0, a.nc, q_total, q_nan, q_over,
-                                    a.sigma);
+    auto sum_at = [&](int b) { return hsum[b * 64 + tid]; };
+    auto cnt_at = [&](int b) { return hcnt[b * 64 + tid]; };
+    if (a.kind == 1) a.theta[pidx] = aov_from_bins(sum_at, cnt_at, m0, q_total - q_nan);
+    else a.theta[pidx] = theta_from_bins(sum_at, cnt_at, m0, a.nc, q_total, q_nan, q_over, a.sigma);
 }
 
 size_t lds_bytes(int m0, int block) {
@@ -346,32 +406,48 @@ size_t lds_bytes(int m0, int block) {
     return stage + (size_t)(m0 + 1) * block * 12 + (size_t)(m0 + 2) * 8 + 64;
 }
 
-}  // namespace
+// stream-ordered scratch that is released on every exit path
+struct AsyncScratch {
+    char *p = nullptr;
+    hipStream_t st;
+    explicit AsyncScratch(hipStream_t s) : st(s) {}
+    ~AsyncScratch() {
+        if (p) (void)hipFreeAsync(p, st);
+    }
+};
 
-extern "C" {
+// dynamic-LDS limit of a kernel, raised once per process (not on every call)
+template <typename Kernel>
+int allow_lds(Kernel kernel) {
+    static const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    150 * 1024);
+    PDC_HIP(e);
+    return PDC_OK;
+}
 
-int pdc_pdm_scan_dev(int device, void *stream, const double *d_t, const double *d_x, int64_t n,
-                     const double *d_periods, int64_t n_periods, int nb, int nc, double sigma,
-                     double *d_theta) {
-    PDC_REQUIRE(d_t && d_x && (d_periods || n_periods == 0) && (d_theta || n_periods == 0),
-                "pdm: NULL argument");
-    PDC_REQUIRE(n >= 0 && n_periods >= 0, "pdm: negative size");
-    PDC_REQUIRE(nb >= 1 && nc >= 1 && nc <= nb * nc, "pdm: nb and nc must be positive");
-    PDC_REQUIRE((int64_t)nb * nc <= 190, "pdm: nb*nc = %lld exceeds the 190 bins that fit in LDS",
-                (long long)nb * nc);
+// kind 0: PDM theta; 1: AoV over nb phase bins; 2: conditional entropy over nb x nc cells
+int phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, const double *d_x, int64_t n,
+                   const double *d_periods, int64_t n_periods, int nb, int nc, double sigma, double *d_out) {
+    PDC_REQUIRE(d_t && d_x && (d_periods || n_periods == 0) && (d_out || n_periods == 0),
+                "phase scan: NULL argument");
+    PDC_REQUIRE(n >= 0 && n_periods >= 0, "phase scan: negative size");
+    PDC_REQUIRE(nb >= 1 && nc >= 1, "phase scan: bin counts must be positive");
+    if (kind == 1) nc = 1;
+    const int m0 = kind == 2 ? nb : nb * nc;                    // phase bins
+    const int last = kind == 2 ? (nb + 1) * nc - 1 : m0;        // highest histogram bin
+    PDC_REQUIRE(last <= 190, "phase scan: %d histogram bins exceed the 191 that fit in LDS", last + 1);
     if (n_periods == 0) return PDC_OK;
     PDC_TRY(use_device(device));
-    PdmArgs a{d_t, d_x, d_periods, n, n_periods, nb, nc, sigma, d_theta};
-    const int m0 = nb * nc;
-    hipStream_t st = (hipStream_t)stream;
+    PdmArgs a{d_t, d_x, d_periods, n, n_periods, nb, nc, sigma, d_out};
+    a.kind = kind;
     // Few trial periods and many samples (the reference's default grid has 1000 periods): lanes are
     // periods, so the period grid alone would leave most of the chip idle.  Split the SAMPLES over
     // blockIdx.y as well: statistics once (two short grid-wide launches), partial histograms per
     // slice, one finishing launch that adds them in slice order.  PDC_PDM_SPLIT=0 disables it.
     static const int env_split = [] { const char *e = getenv("PDC_PDM_SPLIT"); return e ? atoi(e) : -1; }();
     const int64_t groups0 = (n_periods + 63) / 64;
-    const int nbins = m0 + 1;
-    if (env_split != 0 && groups0 * 4 < 1024 && n >= 32 * kChunk && lds_bytes(m0, 256) <= 150 * 1024 &&
+    const int nbins = last + 1;
+    if (kind != 2 && env_split != 0 && groups0 * 4 < 1024 && n >= 32 * kChunk && lds_bytes(last, 256) <= 150 * 1024 &&
         (size_t)nbins * 64 * 16 <= 150 * 1024) {
         int64_t n_z = (2048 + groups0 * 4 - 1) / (groups0 * 4);
         const int64_t max_z = n / (8 * kChunk);
@@ -387,40 +463,39 @@ int pdc_pdm_scan_dev(int device, void *stream, const double *d_t, const double *
             const size_t psum_b = (size_t)n_z * nbins * a.p_pad * 8;
             const size_t pq_b = (size_t)n_z * 2 * a.p_pad * 8;
             const size_t pcnt_b = (size_t)n_z * nbins * a.p_pad * 4;
-            char *scratch = nullptr;
-            PDC_HIP(hipMallocAsync((void **)&scratch, stat_b + psum_b + pq_b + pcnt_b, st));
-            a.stat = reinterpret_cast<double *>(scratch);
-            a.psum = reinterpret_cast<double *>(scratch + stat_b);
-            a.pq = reinterpret_cast<double *>(scratch + stat_b + psum_b);
-            a.pcnt = reinterpret_cast<unsigned *>(scratch + stat_b + psum_b + pq_b);
+            PDC_TRY(allow_lds(pdm_scan_kernel<256, 4, true>));
+            PDC_TRY(allow_lds(pdm_finish_kernel));
+            AsyncScratch scratch(st);
+            PDC_HIP(hipMallocAsync((void **)&scratch.p, stat_b + psum_b + pq_b + pcnt_b, st));
+            a.stat = reinterpret_cast<double *>(scratch.p);
+            a.psum = reinterpret_cast<double *>(scratch.p + stat_b);
+            a.pq = reinterpret_cast<double *>(scratch.p + stat_b + psum_b);
+            a.pcnt = reinterpret_cast<unsigned *>(scratch.p + stat_b + psum_b + pq_b);
             hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 0);
             hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 1);
-            const size_t lds = lds_bytes(m0, 256);
-            PDC_HIP(hipFuncSetAttribute((const void *)pdm_scan_kernel<256, 4, true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((pdm_scan_kernel<256, 4, true>), dim3((unsigned)groups0, (unsigned)n_z), dim3(256), lds, st, a);
-            const size_t lds_f = (size_t)nbins * 64 * 16;
-            PDC_HIP(hipFuncSetAttribute((const void *)pdm_finish_kernel,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-            hipLaunchKernelGGL(pdm_finish_kernel, dim3((unsigned)groups0), dim3(64), lds_f, st, a);
+            hipLaunchKernelGGL((pdm_scan_kernel<256, 4, true>), dim3((unsigned)groups0, (unsigned)n_z), dim3(256),
+                               lds_bytes(last, 256), st, a);
+            hipLaunchKernelGGL(pdm_finish_kernel, dim3((unsigned)groups0), dim3(64), (size_t)nbins * 64 * 16, st, a);
             PDC_HIP(hipGetLastError());
-            PDC_HIP(hipFreeAsync(scratch, st));
-            return PDC_OK;
+            return PDC_OK;   // (the scratch goes back to the pool in stream order)
         }
     }
-    if (lds_bytes(m0, 256) <= 150 * 1024) {
-        const size_t lds = lds_bytes(m0, 256);
+    if (lds_bytes(last, 256) <= 150 * 1024) {
+        const size_t lds = lds_bytes(last, 256);
         // waves = ceil(P/64) * SPLIT; aim at >= 4 waves per SIMD (4096 on the chip)
         const int64_t groups = (n_periods + 63) / 64;
         const int split = groups >= 4096 ? 1 : (groups >= 2048 ? 2 : 4);
         auto launch = [&](auto kernel, int periods_per_block) -> int {
-            PDC_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
+            PDC_TRY(allow_lds(kernel));
             hipLaunchKernelGGL(kernel, dim3((unsigned)((n_periods + periods_per_block - 1) / periods_per_block)),
                                dim3(256), lds, st, a);
             return PDC_OK;
         };
-        if (split == 4) {
+        if (kind == 2) {
+            if (split == 4) PDC_TRY(launch(pdm_scan_kernel<256, 4, false, true>, 64));
+            else if (split == 2) PDC_TRY(launch(pdm_scan_kernel<256, 2, false, true>, 128));
+            else PDC_TRY(launch(pdm_scan_kernel<256, 1, false, true>, 256));
+        } else if (split == 4) {
             PDC_TRY(launch(pdm_scan_kernel<256, 4>, 64));
         } else if (split == 2) {
             PDC_TRY(launch(pdm_scan_kernel<256, 2>, 128));
@@ -428,21 +503,50 @@ int pdc_pdm_scan_dev(int device, void *stream, const double *d_t, const double *
             PDC_TRY(launch(pdm_scan_kernel<256, 1>, 256));
         }
     } else {
-        const size_t lds = lds_bytes(m0, 64);
-        PDC_HIP(hipFuncSetAttribute((const void *)pdm_scan_kernel<64, 1>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((pdm_scan_kernel<64, 1>), dim3((unsigned)((n_periods + 63) / 64)), dim3(64), lds,
-                           st, a);
+        const size_t lds = lds_bytes(last, 64);
+        if (kind == 2) {
+            PDC_TRY(allow_lds(pdm_scan_kernel<64, 1, false, true>));
+            hipLaunchKernelGGL((pdm_scan_kernel<64, 1, false, true>), dim3((unsigned)((n_periods + 63) / 64)), dim3(64),
+                               lds, st, a);
+        } else {
+            PDC_TRY(allow_lds(pdm_scan_kernel<64, 1>));
+            hipLaunchKernelGGL((pdm_scan_kernel<64, 1>), dim3((unsigned)((n_periods + 63) / 64)), dim3(64), lds, st, a);
+        }
     }
     PDC_HIP(hipGetLastError());
     return PDC_OK;
 }
 
-int pdc_pdm_scan(const double *t, const double *x, int64_t n, const double *periods,
-                 int64_t n_periods, int nb, int nc, double sigma, double *theta_out, int device) {
-    PDC_REQUIRE(t && x && (periods || n_periods == 0) && (theta_out || n_periods == 0),
-                "pdm: NULL argument");
-    PDC_REQUIRE(n >= 0 && n_periods >= 0, "pdm: negative size");
+}  // namespace
+
+extern "C" {
+
+int pdc_pdm_scan_dev(int device, void *stream, const double *d_t, const double *d_x, int64_t n,
+                     const double *d_periods, int64_t n_periods, int nb, int nc, double sigma,
+                     double *d_theta) {
+    return phase_stat_dev(0, device, (hipStream_t)stream, d_t, d_x, n, d_periods, n_periods, nb, nc, sigma,
+                          d_theta);
+}
+
+int pdc_aov_scan_dev(int device, void *stream, const double *d_t, const double *d_x, int64_t n,
+                     const double *d_periods, int64_t n_periods, int n_bins, double *d_theta) {
+    return phase_stat_dev(1, device, (hipStream_t)stream, d_t, d_x, n, d_periods, n_periods, n_bins, 1, 1.0,
+                          d_theta);
+}
+
+int pdc_cond_entropy_scan_dev(int device, void *stream, const double *d_t, const double *d_mag_bin, int64_t n,
+                              const double *d_periods, int64_t n_periods, int n_phase, int n_mag,
+                              double *d_entropy) {
+    return phase_stat_dev(2, device, (hipStream_t)stream, d_t, d_mag_bin, n, d_periods, n_periods, n_phase,
+                          n_mag, 1.0, d_entropy);
+}
+
+namespace {
+
+int phase_stat_host(int kind, const double *t, const double *x, int64_t n, const double *periods,
+                    int64_t n_periods, int nb, int nc, double sigma, double *out, int device) {
+    PDC_REQUIRE(t && x && (periods || n_periods == 0) && (out || n_periods == 0), "phase scan: NULL argument");
+    PDC_REQUIRE(n >= 0 && n_periods >= 0, "phase scan: negative size");
     PDC_TRY(use_device(device));
     DeviceLock lock(device);
     void *d_t, *d_x, *d_p, *d_th;
@@ -454,11 +558,28 @@ int pdc_pdm_scan(const double *t, const double *x, int64_t n, const double *peri
     PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_x, x, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_p, periods, n_periods * 8, hipMemcpyHostToDevice, st));
-    PDC_TRY(pdc_pdm_scan_dev(device, st, (double *)d_t, (double *)d_x, n, (double *)d_p, n_periods, nb,
-                             nc, sigma, (double *)d_th));
-    PDC_HIP(hipMemcpyAsync(theta_out, d_th, n_periods * 8, hipMemcpyDeviceToHost, st));
+    PDC_TRY(phase_stat_dev(kind, device, st, (double *)d_t, (double *)d_x, n, (double *)d_p, n_periods, nb, nc,
+                           sigma, (double *)d_th));
+    PDC_HIP(hipMemcpyAsync(out, d_th, n_periods * 8, hipMemcpyDeviceToHost, st));
     PDC_HIP(hipStreamSynchronize(st));
     return PDC_OK;
+}
+
+}  // namespace
+
+int pdc_aov_scan(const double *t, const double *x, int64_t n, const double *periods, int64_t n_periods,
+                 int n_bins, double *theta_out, int device) {
+    return phase_stat_host(1, t, x, n, periods, n_periods, n_bins, 1, 1.0, theta_out, device);
+}
+
+int pdc_cond_entropy_scan(const double *t, const double *mag_bin, int64_t n, const double *periods,
+                          int64_t n_periods, int n_phase, int n_mag, double *entropy_out, int device) {
+    return phase_stat_host(2, t, mag_bin, n, periods, n_periods, n_phase, n_mag, 1.0, entropy_out, device);
+}
+
+int pdc_pdm_scan(const double *t, const double *x, int64_t n, const double *periods,
+                 int64_t n_periods, int nb, int nc, double sigma, double *theta_out, int device) {
+    return phase_stat_host(0, t, x, n, periods, n_periods, nb, nc, sigma, theta_out, device);
 }
 
 }  // extern "C"

@@ -21,7 +21,7 @@ from .core import FSeries, TSeries
 
 MAX_CORES = cpu_count()
 
-__all__ = ["StringLength", "PDM"]
+__all__ = ["StringLength", "PDM", "AOV", "ConditionalEntropy"]
 
 
 # ---- host-side grid / scaling rules (O(N) or O(n_periods) numpy, as upstream) -----------------------
@@ -175,4 +175,80 @@ class PDM(object):
         if self.do_subharmonic:
             thetas = _average_with_double_period(thetas, self.periods, signal.size, shortest, longest)
         self.periodogram = FSeries(1 / self.periods, thetas)
+        return self.periodogram
+
+
+class AOV(object):
+    """Analysis of Variance period search (Schwarzenberg-Czerny 1989) - one of the scans the
+    reference lists as TODO (``phase.py:11``), shaped like :class:`PDM` and computed by the same
+    binning kernel (``csrc/pdm.hip``): the statistic is large where the folded curve is coherent.
+
+    Parameters
+    ----------
+    n_bins: int, optional
+        Number of phase bins r (the default is 10).
+    p_min, p_max, n_periods, oversample, cores:
+        The trial-period grid, exactly as for :class:`PDM` (``phase.py:167-180``).
+    device: int, keyword-only
+        GPU ordinal.
+    """
+
+    def __init__(self, n_bins=10, p_min=None, p_max=None, n_periods=1000, oversample=1, cores=None,
+                 *, device=None):
+        self.n_bins = n_bins
+        self.p_min, self.p_max = p_min, p_max
+        self.n_periods = n_periods
+        self.oversample = oversample
+        self.cores = cores
+        self.device = device
+
+    def __call__(self, signal):
+        signal = _coerce(signal)
+        self.signal = signal
+        self.t = np.asarray(signal.time, dtype=float)
+        self.x = np.asarray(signal.values, dtype=float)
+        self.periods, _, _ = _pdm_periods(signal, self.p_min, self.p_max, self.n_periods,
+                                          self.oversample)
+        theta = _cabi.aov_scan(self.t, self.x, self.periods, self.n_bins, device=self.device)
+        self.periodogram = FSeries(1 / self.periods, theta)
+        return self.periodogram
+
+
+class ConditionalEntropy(object):
+    """Conditional-entropy period search (Graham et al. 2013) - TODO upstream (``phase.py:15``),
+    shaped like :class:`PDM`: the entropy of the magnitudes given the phase, over an
+    ``n_phase x n_mag`` partition of the folded, unit-normalised light curve; minimal at the period.
+
+    Parameters
+    ----------
+    n_phase, n_mag: int, optional
+        Phase and magnitude bins (defaults 10 and 5).
+    p_min, p_max, n_periods, oversample, cores:
+        The trial-period grid, exactly as for :class:`PDM`.
+    device: int, keyword-only
+        GPU ordinal.
+    """
+
+    def __init__(self, n_phase=10, n_mag=5, p_min=None, p_max=None, n_periods=1000, oversample=1,
+                 cores=None, *, device=None):
+        self.n_phase, self.n_mag = n_phase, n_mag
+        self.p_min, self.p_max = p_min, p_max
+        self.n_periods = n_periods
+        self.oversample = oversample
+        self.cores = cores
+        self.device = device
+
+    def __call__(self, signal):
+        signal = _coerce(signal)
+        self.signal = signal
+        self.t = np.asarray(signal.time, dtype=float)
+        values = np.asarray(signal.values, dtype=float)
+        low, high = np.nanmin(values), np.nanmax(values)
+        unit = (values - low) / (high - low)
+        self.mag_bin = np.minimum(np.floor(unit * self.n_mag), self.n_mag - 1).astype(float)
+        self.periods, _, _ = _pdm_periods(signal, self.p_min, self.p_max, self.n_periods,
+                                          self.oversample)
+        entropy = _cabi.cond_entropy_scan(self.t, self.mag_bin, self.periods, self.n_phase, self.n_mag,
+                                          device=self.device)
+        self.periodogram = FSeries(1 / self.periods, entropy)
         return self.periodogram

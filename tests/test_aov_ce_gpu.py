@@ -1,0 +1,82 @@
+"""Analysis of Variance and conditional entropy (the TODO scans of the reference's phase.py:11-15) on
+the PDM binning kernel, against oracle/scan_oracle.py's restatement of the published formulas
+(parity unpinned by the reference: it has no implementation of either)."""
+import numpy as np
+import pytest
+
+from oracle import scan_oracle as so
+from periodicity_amd import _cabi, phase
+from periodicity_amd.core import TSeries
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def curve(n, seed, period=13.7, t_shift=0.0):
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(0, float(n), n)) + t_shift
+    dy = rng.uniform(0.05, 0.2, n)
+    return t, 1.0 + 0.5 * np.sin(2 * np.pi * t / period) + dy * rng.standard_normal(n)
+
+
+@pytest.mark.parametrize("n,n_periods,n_bins", [(2000, 200, 10), (777, 65, 5), (5000, 3000, 16), (40, 10, 8)])
+def test_aov_matches_published_formula(n, n_periods, n_bins):
+    t, x = curve(n, 100 + n)
+    periods = np.linspace(1.0, 60.0, n_periods)
+    got = _cabi.aov_scan(t, x, periods, n_bins)
+    want = so.aov_scan(t, x, periods, n_bins)
+    np.testing.assert_allclose(got, want, rtol=RTOL)
+    assert np.argmax(got) == np.argmax(want)
+
+
+def test_aov_split_mode_negative_times_and_edges():
+    t, x = curve(40_000, 5, t_shift=-12345.5)                   # few periods x many samples: split mode
+    periods = np.linspace(3.0, 40.0, 90)
+    np.testing.assert_allclose(_cabi.aov_scan(t, x, periods, 10), so.aov_scan(t, x, periods, 10), rtol=RTOL)
+    te = np.arange(300.0)                                        # evenly sampled, commensurate periods: phases
+    xe = np.sin(2 * np.pi * te / 12.5) + 0.1 * np.cos(te)        # sit on bin edges and in few bins
+    pe = np.array([1.0, 2.0, 2.5, 4.0, 5.0, 12.5, 25.0, 50.0])
+    np.testing.assert_allclose(_cabi.aov_scan(te, xe, pe, 5), so.aov_scan(te, xe, pe, 5), rtol=RTOL)
+    assert _cabi.aov_scan(t, x, np.empty(0), 10).size == 0
+    assert np.all(np.isnan(_cabi.aov_scan(t[:6], x[:6], [3.0, 7.0], 10)))   # n <= r: undefined
+    with pytest.raises(ValueError):
+        _cabi.aov_scan(t, x[:-1], [1.0], 10)
+    with pytest.raises(ValueError):
+        _cabi.aov_scan(t, x, [1.0], 500)
+
+
+@pytest.mark.parametrize("n,n_periods,n_phase,n_mag", [(2000, 200, 10, 5), (513, 70, 4, 3), (5000, 2100, 12, 8)])
+def test_conditional_entropy_matches_published_formula(n, n_periods, n_phase, n_mag):
+    t, x = curve(n, 300 + n)
+    mag = so.magnitude_bins(x, n_mag)
+    periods = np.linspace(1.0, 60.0, n_periods)
+    got = _cabi.cond_entropy_scan(t, mag, periods, n_phase, n_mag)
+    want = so.cond_entropy_scan(t, mag, periods, n_phase, n_mag)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-13)
+    assert np.argmin(got) == np.argmin(want)
+    with pytest.raises(ValueError):
+        _cabi.cond_entropy_scan(t, mag + n_mag, periods, n_phase, n_mag)
+
+
+def test_classes_find_the_period():
+    t, x = curve(3000, 9, period=13.7)
+    sig = TSeries(t, x)
+    aov = phase.AOV(n_bins=10, p_min=2.0, p_max=40.0, n_periods=4000)(sig)
+    ce = phase.ConditionalEntropy(p_min=2.0, p_max=40.0, n_periods=4000)(sig)
+    assert abs(aov.period[np.nanargmax(aov.values)] - 13.7) < 0.1
+    assert abs(ce.period[np.nanargmin(ce.values)] - 13.7) < 0.1
+    assert np.all(np.diff(aov.frequency) > 0) and aov.size == 4000     # FSeries order, as PDM's output
+
+
+def test_full_size_c5_aov_and_entropy():
+    """BASELINE configs[4] shape (N=5e4 x 1e5 trial periods) through both new scans; spot-checked."""
+    n, n_per = 50_000, 100_000
+    t, x = curve(n, 20241012)
+    periods = np.linspace(1.0, 100.0, n_per)
+    pick = np.random.default_rng(0).integers(0, n_per, 25)
+    aov = _cabi.aov_scan(t, x, periods, 10)
+    np.testing.assert_allclose(aov[pick], so.aov_scan(t, x, periods[pick], 10), rtol=RTOL)
+    mag = so.magnitude_bins(x, 5)
+    ce = _cabi.cond_entropy_scan(t, mag, periods, 10, 5)
+    np.testing.assert_allclose(ce[pick], so.cond_entropy_scan(t, mag, periods[pick], 10, 5), rtol=RTOL)
+    assert abs(periods[np.argmax(aov)] - 13.7) < 0.05 and abs(periods[np.argmin(ce)] - 13.7) < 0.05

@@ -97,6 +97,10 @@ def oracle_backend(monkeypatch):
                         lambda t, x, p, nb, nc, sigma, device=None, devices=None: so.pdm_scan(t, x, np.asarray(p), nb, nc))
     monkeypatch.setattr(_cabi, "stringlength_scan",
                         lambda t, m, p, device=None, devices=None: so.stringlength_scan(t, m, np.asarray(p)))
+    monkeypatch.setattr(_cabi, "aov_scan",
+                        lambda t, x, p, n_bins, device=None: so.aov_scan(t, x, np.asarray(p), n_bins))
+    monkeypatch.setattr(_cabi, "cond_entropy_scan",
+                        lambda t, mb, p, n_phase, n_mag, device=None: so.cond_entropy_scan(t, mb, np.asarray(p), n_phase, n_mag))
 
 
 def curve(n=400, seed=2):
@@ -177,3 +181,21 @@ def test_gls_model_matches_reference_golden(golden_dir):
             assert isinstance(fit, TSeries)
             np.testing.assert_array_equal(fit.time, g["tf_sorted_" + tag])
             np.testing.assert_allclose(fit.values, want, rtol=1e-10, atol=1e-12)
+
+
+def test_aov_and_entropy_host_rules(oracle_backend):
+    """The two TODO scans of phase.py:11-15 behind PDM-shaped classes: grid, ordering, attributes."""
+    t, y, _ = curve(600, 4)
+    sig = TSeries(t, y)
+    aov = phase.AOV(n_bins=8, p_min=5.0, p_max=40.0, n_periods=300)
+    res = aov(sig)
+    assert np.array_equal(aov.periods, np.linspace(5.0, 40.0, 300)) and res.size == 300
+    assert np.all(np.diff(res.frequency) > 0)                                   # FSeries sorts ascending
+    assert abs(res.period[np.argmax(res.values)] - 17.0) < 0.5
+    ce = phase.ConditionalEntropy(n_phase=8, n_mag=4, p_min=5.0, p_max=40.0, n_periods=300)
+    res = ce(sig)
+    assert set(np.unique(ce.mag_bin)) <= {0.0, 1.0, 2.0, 3.0}
+    assert np.array_equal(ce.mag_bin, so.magnitude_bins(y, 4))
+    assert abs(res.period[np.argmin(res.values)] - 17.0) < 0.5
+    # an all-in-one-bin fold has zero conditional entropy only if the magnitudes are constant there
+    assert so.cond_entropy(t, np.zeros_like(t), 7.0, 8, 4) == 0.0
