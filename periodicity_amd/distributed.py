@@ -8,9 +8,11 @@ all-gather of the result array (RCCL over xGMI when the process group's backend 
 ``/root/reference/src/periodicity/phase.py:69-70,185-186`` — has the same shape with pickling
 instead of a collective.
 
-torch is imported lazily and only here: it provides rendezvous and the collective, not compute.
-The single-process alternative (one process driving N devices with RCCL directly) is
-``pdc_gls_scan_multi`` in ``csrc/multi.hip``.
+torch is OPTIONAL plumbing: it is imported lazily, only inside the functions of this module, and
+provides rendezvous and the collective, never compute; ``spectral.py`` / ``phase.py`` / ``_cabi.py`` do
+not import it (``tests/test_host_api.py`` imports the package with torch blocked).  The torch-free
+alternative - one process driving N devices with RCCL directly - is the persistent plan
+``pdc_gls_plan_*`` / ``pdc_gls_scan_multi`` in ``csrc/multi.hip`` (``_cabi.GlsPlan``, ``GLS(devices=...)``).
 """
 import numpy as np
 
@@ -68,17 +70,43 @@ def sharded_scan(compute_slab, n_grid, group=None):
 
 def sharded_gls(t, y, dy, f0, delta, nf, fit_mean=True, psd=False, device=None, group=None):
     """Generalized Lomb-Scargle power on ``f0 + j*delta``, j < nf, with the grid sharded over the
-    ranks of ``group`` (one GPU per rank, ``cuda:LOCAL_RANK`` unless ``device`` is given)."""
+    ranks of ``group`` (one GPU per rank, ``cuda:LOCAL_RANK`` unless ``device`` is given).
+
+    With an ``nccl`` (RCCL) group the slab never leaves the GPU before the exchange: the samples go
+    up once, ``pdc_gls_scan_dev`` writes the slab into a device tensor on torch's current stream, the
+    all-gather runs on device tensors, and only the gathered array comes back.  With ``gloo`` (CPU
+    groups of the tests, or a host-side exchange) the slab is computed through the host entry point."""
     import torch
+    import torch.distributed as dist
 
     from . import _cabi
+    on_host = dist.get_backend(group) == "gloo"
     if device is None:
-        device = torch.cuda.current_device()
+        device = _cabi.default_device() if on_host else torch.cuda.current_device()
+    if on_host:
+        def compute(begin, count):
+            part = _cabi.gls_scan(t, y, dy, f0, delta, count, fit_mean, psd, j_begin=begin, device=device)
+            return torch.from_numpy(part)
+        return sharded_scan(compute, nf, group).numpy()
+
+    where = f"cuda:{device}"
+    d_t, d_y = (torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(where) for a in (t, y))
+    d_dy = None if dy is None else torch.as_tensor(np.ascontiguousarray(dy, dtype=np.float64)).to(where)
+    if d_y.numel() != d_t.numel() or (d_dy is not None and d_dy.numel() != d_t.numel()):
+        raise ValueError("Input arrays have incompatible lengths.")
 
     def compute(begin, count):
-        part = _cabi.gls_scan(t, y, dy, f0, delta, count, fit_mean, psd, j_begin=begin,
-                              device=device)
-        return _place(part, device, group)
+        slab = torch.empty(count, dtype=torch.float64, device=where)
+        if count:
+            lib = _cabi.lib()
+            wb = lib.pdc_gls_work_bytes(d_t.numel(), 1, count)
+            work = torch.empty(wb, dtype=torch.uint8, device=where)
+            _cabi.check(lib.pdc_gls_scan_dev(
+                device, torch.cuda.current_stream(device).cuda_stream, d_t.data_ptr(), d_y.data_ptr(),
+                None if d_dy is None else d_dy.data_ptr(), None, d_t.numel(), 1, 0, f0, delta, begin,
+                count, int(bool(fit_mean)), int(bool(psd)), slab.data_ptr(), None, None,
+                work.data_ptr(), wb))
+        return slab
 
     return sharded_scan(compute, nf, group).cpu().numpy()
 

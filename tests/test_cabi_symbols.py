@@ -45,3 +45,32 @@ def test_runtime_entry_points_without_a_gpu(built):
         import numpy as np
         with pytest.raises((RuntimeError, ValueError)):
             _cabi.gls_scan(np.arange(4.0), np.ones(4), None, 0.1, 0.1, 4)
+
+
+def test_integration_md_binding_snippet_runs_against_the_built_library(built, monkeypatch):
+    """The ctypes stub INTEGRATION.md tells a maintainer of the reference to add must keep loading:
+    every symbol it names exists, its argtypes marshal, and without a GPU the calls fail loudly with
+    the library's own error (never a crash, never a CPU answer)."""
+    import numpy as np
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    snippet = next(b for b in blocks if "C.CDLL" in b)
+    monkeypatch.setenv("PERIODICITY_HIP_LIB", _cabi.library_path())
+    ns = {}
+    exec(compile(snippet, "INTEGRATION.md:_hip.py", "exec"), ns)
+    for name in re.findall(r"_lib\.(pdc_[a-z0-9_]+)", snippet):
+        assert name in _cabi.PROTOTYPES, name
+        if name != "pdc_last_error":        # same argument list as the package's own binding
+            assert len(getattr(ns["_lib"], name).argtypes) == len(_cabi.PROTOTYPES[name][1]), name
+    t = np.arange(8.0)
+    calls = [lambda: ns["gls_power"](t, np.ones(8), None, 0.1 + 0.1 * np.arange(4), True, False),
+             lambda: ns["trig_sum"](t, np.ones(8), 0.1, 4, 0.05),
+             lambda: ns["pdm_thetas"](t, np.cos(t), [2.0, 3.0], 5, 2, 0.5),
+             lambda: ns["string_lengths"](t, np.cos(t) / 4, [2.0, 3.0])]
+    if _cabi.device_count() == 0:
+        for call in calls:
+            with pytest.raises(RuntimeError):
+                call()
+    else:
+        for call in calls:
+            assert np.all(np.isfinite(call()))

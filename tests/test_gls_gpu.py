@@ -242,6 +242,49 @@ def test_rccl_all_gather_path_on_one_device():
     assert "all-gather equal: True" in out.stdout, out.stdout[-400:] + out.stderr[-400:]
 
 
+def test_persistent_plan_repeated_scans_and_validation():
+    """pdc_gls_plan_*: buffers, streams and communicators created once; scans only enqueue, outputs are
+    double-buffered; every scan of a sequence comes back bit-identical to the one-shot call."""
+    t, y, dy = synth(3000, 77)
+    grids = [np.arange(0.002, 0.9, 0.00031), np.arange(0.001, 0.5, 0.0007), np.arange(0.002, 0.9, 0.00031)]
+    plan = _cabi.GlsPlan([0], n_max=4000, nf_max=max(g.size for g in grids))
+    plan.upload(t, y, dy)
+    for g in grids:                      # back-to-back enqueues, one wait at the end of each check
+        f0, delta, nf = _cabi.grid_params(g)
+        plan.scan(f0, delta, nf)
+        plan.scan(f0, delta, nf)         # second generation while the first may still be in flight
+        got = plan.download()
+        assert np.array_equal(got, _cabi.gls_scan(t, y, dy, f0, delta, nf))
+        assert plan.kernel_ms() > 0
+    plan.upload(t[:1000], y[:1000], None)            # new light curve, same plan
+    f0, delta, nf = _cabi.grid_params(grids[1])
+    plan.scan(f0, delta, nf, fit_mean=False, psd=True)
+    assert np.array_equal(plan.download(), _cabi.gls_scan(t[:1000], y[:1000], None, f0, delta, nf, False, True))
+    with pytest.raises(ValueError):
+        plan.upload(np.arange(5000.0), np.ones(5000))            # more samples than the plan holds
+    with pytest.raises(ValueError):
+        plan.scan(0.1, 0.1, 10 * max(g.size for g in grids))      # more frequencies than the plan holds
+    plan.close()
+    n_dev = _cabi.device_count()
+    with pytest.raises(ValueError):
+        _cabi.GlsPlan([n_dev], 10, 10)                           # not one of the visible devices
+    with pytest.raises(ValueError):
+        _cabi.GlsPlan([0, 0], 10, 10)                            # listed twice
+    with pytest.raises(ValueError):
+        _cabi.gls_scan_multi(t, y, dy, 0.1, 0.1, 8, devices=(n_dev + 3,))
+
+
+def test_sharded_gls_gathers_the_device_slab_over_rccl():
+    """periodicity_amd.distributed.sharded_gls under a one-rank nccl (RCCL) group: the slab is
+    written by pdc_gls_scan_dev into a device tensor and all-gathered there."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_single_device_check.py"), "torch"],
+                         cwd=root, capture_output=True, text=True, timeout=600)
+    assert "sharded_gls equal: True" in out.stdout, out.stdout[-400:] + out.stderr[-600:]
+
+
 def test_large_time_offset_is_harmless():
     # Kepler-style barycentric dates: f*t spans ~1e7 cycles, the phase must not lose bits
     t, y, dy = synth(2000, 33)

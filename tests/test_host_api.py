@@ -199,3 +199,19 @@ def test_aov_and_entropy_host_rules(oracle_backend):
     assert abs(res.period[np.argmin(res.values)] - 17.0) < 0.5
     # an all-in-one-bin fold has zero conditional entropy only if the magnitudes are constant there
     assert so.cond_entropy(t, np.zeros_like(t), 7.0, 8, 4) == 0.0
+
+
+def test_package_imports_and_runs_host_logic_without_torch():
+    """torch is optional plumbing of periodicity_amd.distributed only: the callables, the containers
+    and the ctypes binding import with torch made unimportable."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.modules['torch'] = None\n"
+            "import periodicity_amd\n"
+            "from periodicity_amd import _cabi, core, phase, spectral, distributed\n"
+            "assert 'torch' not in [m for m in sys.modules if sys.modules[m] is not None]\n"
+            "print(distributed.slab_bounds(10, 3, 2), spectral.LombScargle.__name__, phase.AOV.__name__)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         cwd=__import__("os").path.dirname(__import__("os").path.dirname(__file__)))
+    assert out.returncode == 0, out.stderr
+    assert "(8, 10, 4) GLS AOV" in out.stdout

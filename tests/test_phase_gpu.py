@@ -35,10 +35,12 @@ def test_pdm_seam_and_call_golden(golden_dir, nb, nc):
     periods = g[f"periods_{nb}_{nc}"]
     theta = _cabi.pdm_scan(g["t"], g["y"], periods, nb, nc, float(g["sigma"]))
     np.testing.assert_allclose(theta, g[f"theta_seam_{nb}_{nc}"], rtol=RTOL)
+    assert np.argmin(theta) == np.argmin(g[f"theta_seam_{nb}_{nc}"])      # the best period: same index
     pdm = PDM(nb=nb, nc=nc, p_min=1.0, p_max=60.0, n_periods=200, cores=1)
     res = pdm(TSeries(g["t"], g["y"]))
     assert np.array_equal(res.frequency, g[f"frequency_{nb}_{nc}"])
     np.testing.assert_allclose(res.values, g[f"theta_call_{nb}_{nc}"], rtol=RTOL)
+    assert np.argmin(res.values) == np.argmin(g[f"theta_call_{nb}_{nc}"])
     assert np.array_equal(pdm.periods, periods) and pdm.sigma == float(g["sigma"])
     assert pdm.periodogram is res and pdm.signal.size == g["t"].size
     np.testing.assert_allclose(pdm._pdm(periods[17]), g[f"theta_seam_{nb}_{nc}"][17], rtol=RTOL)
@@ -100,9 +102,11 @@ def test_stringlength_seam_golden(golden_dir):
     g = load(golden_dir, "g8_stringlength")
     ell = _cabi.stringlength_scan(g["t"], g["m"], g["periods"])
     np.testing.assert_allclose(ell, g["ell"], rtol=RTOL)
+    assert np.argmin(ell) == np.argmin(g["ell"]) and np.argmax(ell) == np.argmax(g["ell"])
     # evenly sampled: many bit-identical phases, the stable (time) order of ties matters
     ell = _cabi.stringlength_scan(g["t_even"], g["m_even"], g["periods_even"])
     np.testing.assert_allclose(ell, g["ell_even"], rtol=RTOL)
+    assert np.argmin(ell) == np.argmin(g["ell_even"])
 
 
 def test_stringlength_call_matches_restated_reference(golden_dir):
@@ -197,6 +201,16 @@ def test_phase_scans_full_size_c5():
     np.testing.assert_allclose(ell[pick], co.stringlength_scan(t, m, sl_periods[pick]), rtol=RTOL)
     # the closed polygon is at least twice the phase span plus twice the value span
     assert ell.min() >= 2 * (m.max() - m.min())
+    # "peak-period index bit-exact": the oracle over a window around each device optimum plus a random
+    # third of a percent of the grid picks the SAME grid index as the device did over the whole grid
+    for values, scan, grid in ((theta, lambda p: co.pdm_scan(t, y, p, 5, 2), periods),
+                               (ell, lambda p: co.stringlength_scan(t, m, p), sl_periods)):
+        best = int(np.argmin(values))
+        near = np.arange(max(0, best - 150), min(n_per, best + 151))
+        cand = np.unique(np.concatenate([near, rng.integers(0, n_per, 300), np.argsort(values)[:50]]))
+        want = scan(grid[cand])
+        assert cand[np.argmin(want)] == best
+        np.testing.assert_allclose(values[cand], want, rtol=RTOL)
 
 
 def test_period_grid_sharded_over_device_slots():

@@ -1,10 +1,42 @@
-import os, sys
+"""Child-process checks of the collectives on ONE device (run by tests/test_gls_gpu.py).
+
+    PDC_FORCE_RCCL=1 python tools/rccl_single_device_check.py         # pdc_gls_scan_multi + plan, RCCL forced
+    python tools/rccl_single_device_check.py torch                    # distributed.sharded_gls, 1-rank nccl group
+"""
+import os
+import sys
+
 sys.path.insert(0, os.getcwd())
 import numpy as np
+
 from periodicity_amd import _cabi
+
 rng = np.random.default_rng(0)
-t = np.sort(rng.uniform(0, 500, 500)); dy = rng.uniform(.05,.2,500); y = np.sin(t/3) + dy*rng.standard_normal(500)
+t = np.sort(rng.uniform(0, 500, 500))
+dy = rng.uniform(.05, .2, 500)
+y = np.sin(t / 3) + dy * rng.standard_normal(500)
 f0, delta, nf = 0.001, 0.0007, 3001
 a = _cabi.gls_scan(t, y, dy, f0, delta, nf)
-b = _cabi.gls_scan_multi(t, y, dy, f0, delta, nf, devices=(0,))
-print("forced RCCL single-device all-gather equal:", np.array_equal(a, b))
+if len(sys.argv) > 1 and sys.argv[1] == "torch":
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    import torch
+    import torch.distributed as dist
+
+    from periodicity_amd.distributed import sharded_gls
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+    b = sharded_gls(t, y, dy, f0, delta, nf)
+    print("sharded_gls equal:", np.array_equal(a, b))
+    dist.destroy_process_group()
+else:
+    b = _cabi.gls_scan_multi(t, y, dy, f0, delta, nf, devices=(0,))
+    c = _cabi.gls_scan_multi(t, y, dy, f0, delta, nf, devices=(0,))      # second call: the cached plan
+    plan = _cabi.GlsPlan([0], 600, 4000)
+    plan.upload(t, y, dy)
+    for _ in range(3):
+        plan.scan(f0, delta, nf)
+    d = plan.download()
+    plan.close()
+    print("forced RCCL single-device all-gather equal:",
+          np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, d))
