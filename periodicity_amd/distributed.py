@@ -13,6 +13,8 @@ provides rendezvous and the collective, never compute; ``spectral.py`` / ``phase
 not import it (``tests/test_host_api.py`` imports the package with torch blocked).  The torch-free
 alternative - one process driving N devices with RCCL directly - is the persistent plan
 ``pdc_gls_plan_*`` / ``pdc_gls_scan_multi`` in ``csrc/multi.hip`` (``_cabi.GlsPlan``, ``GLS(devices=...)``).
+A process that uses both must initialise torch's GPU context (``torch.cuda.set_device``) BEFORE the
+first scan call: the torch wheel carries its own HIP runtime, and the one loaded first serves both.
 """
 import numpy as np
 

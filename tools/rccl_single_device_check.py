@@ -11,21 +11,23 @@ import numpy as np
 
 from periodicity_amd import _cabi
 
+TORCH = len(sys.argv) > 1 and sys.argv[1] == "torch"
+if TORCH:   # torch brings its own HIP runtime: it has to initialise before the library's first call
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+
 rng = np.random.default_rng(0)
 t = np.sort(rng.uniform(0, 500, 500))
 dy = rng.uniform(.05, .2, 500)
 y = np.sin(t / 3) + dy * rng.standard_normal(500)
 f0, delta, nf = 0.001, 0.0007, 3001
 a = _cabi.gls_scan(t, y, dy, f0, delta, nf)
-if len(sys.argv) > 1 and sys.argv[1] == "torch":
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
-    import torch
-    import torch.distributed as dist
-
+if TORCH:
     from periodicity_amd.distributed import sharded_gls
-    torch.cuda.set_device(0)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
     b = sharded_gls(t, y, dy, f0, delta, nf)
     print("sharded_gls equal:", np.array_equal(a, b))
     dist.destroy_process_group()
