@@ -977,6 +977,11 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         }
         __syncthreads();   // (the histogram is dead from here on: its LDS becomes wave scratch)
 
+#ifdef PDC_SL_ONLY_P12   // timing experiment: histogram + scatter + range table only
+        if (tid == 0) a.ell[p] = (double)bnds[nranges];
+        __syncthreads();
+        continue;
+#endif
         // ---- P3a: wave-autonomous ranges -------------------------------------------------------------
         // records of range r (requested one range ahead of their use)
         int n_cnt = 0, n_slo = 0, n_lob = 0, n_hib = 0;

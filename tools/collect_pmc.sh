@@ -20,4 +20,6 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass l2    TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
 rocprofv3 --kernel-trace --stats -d "$out/stats" -o run --output-format csv -- python3 bench.py $args > "$out/stats.log" 2>&1
+# the headline workload alone, so that the average duration of gls_scan_kernel is the C2 launch's
+rocprofv3 --kernel-trace --stats -d "$out/stats_c2" -o run --output-format csv -- python3 bench.py $args --no-extras > "$out/stats_c2.log" 2>&1
 python3 tools/pmc_summary.py "$out" --out "$out/pmc_summary.json" --command "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py $args"
