@@ -37,6 +37,7 @@
 //   P3c  links between consecutive ranges and the closing segment, from the summaries.
 // Nothing but t[], m[] (read) and ell[p] (written) touches global memory on the common path.
 #include <cstdlib>
+#include <type_traits>
 
 #include "pdc_internal.h"
 
@@ -1004,8 +1005,12 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         };
         unsigned *fine32 = fine_w;                                          // [kFine / 4] packed counters
         unsigned char *fine8 = reinterpret_cast<unsigned char *>(fine_w);   // [kFine + 1] starts
-        if (wave < nranges) request(wave);
-        for (int r = wave; r < nranges; r += kWaves) {
+        // One range, ranked and summed by this wave.  ROWS3: the first three rows of 64 are known to be
+        // full (cnt > 192, the usual case with 216-position windows), so only the last row carries the
+        // dead-lane selects; the generic instance serves short ranges (the last one of a period,
+        // sparse phases).
+        auto process = [&](const int r, auto rows3_tag) {
+            constexpr bool ROWS3 = decltype(rows3_tag)::value;
             const int cnt = n_cnt, lo_b = n_lob, hi_b = n_hib;
             if (cnt <= 0 || cnt > kFCap) {
                 if (lane == 0) {
@@ -1013,7 +1018,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                     else atomicOr(&defer[r >> 5], 1u << (r & 31));
                 }
                 if (r + kWaves < nranges) request(r + kWaves);
-                continue;
+                return;
             }
             // Lanes past the range's end ("dead", only in its last row) are not branched around: they
             // add 0 to a counter word of their own, park in the free slot lane + 64 e >= cnt, and their
@@ -1041,7 +1046,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             bool live[kRPer];
 #pragma unroll
             for (int e = 0; e < kRPer; ++e) {
-                live[e] = lane + e * 64 < cnt;
+                live[e] = (ROWS3 && e < 3) ? true : lane + e * 64 < cnt;
                 const double phi = ephi[e];
                 int fb = (int)__builtin_fma(phi, fmul, fadd);
                 fb = fb < 0 ? 0 : (fb > kFine - 1 ? kFine - 1 : fb);
@@ -1065,7 +1070,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             const int mxu = (int)wave_max_u32(mx) + 1;   // members of the fullest fine bucket
             if (mxu > kWInsertMax) {
                 if (lane == 0) atomicOr(&defer[r >> 5], 1u << (r & 31));
-                continue;
+                return;
             }
             wave_sync();
             // exclusive scan of the kFine byte counters (sixteen per lane); every start is <= cnt <= 255
@@ -1177,6 +1182,11 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 rcnt[r] = cnt;
             }
             wave_sync();
+        };
+        if (wave < nranges) request(wave);
+        for (int r = wave; r < nranges; r += kWaves) {
+            if (n_cnt > 192) process(r, std::true_type{});
+            else process(r, std::false_type{});
         }
         __syncthreads();
 

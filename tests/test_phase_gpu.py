@@ -238,7 +238,7 @@ def test_period_grid_sharded_over_device_slots():
     assert np.array_equal(sl(TSeries(t, x)).values, StringLength(n_periods=300)(TSeries(t, x)).values)
 
 
-def test_pdm_few_periods_many_samples_split_the_samples():
+def test_pdm_few_periods_many_samples_split_the_samples(tmp_path):
     """The reference's default grid has 1000 trial periods: with lanes = periods the chip would idle,
     so the samples are split over workgroups as well (statistics once, partial histograms, one
     finishing launch).  Same thetas as the C oracle and as the unsplit kernel (child process with
@@ -258,7 +258,7 @@ def test_pdm_few_periods_many_samples_split_the_samples():
     assert np.all(np.isnan(got))          # a NaN sample poisons every bin sum it lands in and the mean
     code = ("import numpy as np; from periodicity_amd import _cabi; rng = np.random.default_rng(31); n = 50001;"
             "t = np.sort(rng.uniform(0, 300.0, n)) - 20.0; x = np.sin(2 * np.pi * t / 6.3) + 0.3 * rng.standard_normal(n);"
-            "p = np.linspace(0.9, 40.0, 1000); a = _cabi.pdm_scan(t, x, p, 5, 2, np.var(x, ddof=1)); np.save('/tmp/pdm_unsplit.npy', a)")
+            "p = np.linspace(0.9, 40.0, 1000); a = _cabi.pdm_scan(t, x, p, 5, 2, np.var(x, ddof=1)); np.save(r'%s', a)" % str(tmp_path / 'pdm_unsplit.npy'))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PDC_PDM_SPLIT="0"), cwd=root,
                          capture_output=True, text=True, timeout=300)
@@ -268,4 +268,4 @@ def test_pdm_few_periods_many_samples_split_the_samples():
     t = np.sort(rng.uniform(0, 300.0, n)) - 20.0
     x = np.sin(2 * np.pi * t / 6.3) + 0.3 * rng.standard_normal(n)
     split = _cabi.pdm_scan(t, x, np.linspace(0.9, 40.0, 1000), 5, 2, np.var(x, ddof=1))
-    np.testing.assert_allclose(split, np.load("/tmp/pdm_unsplit.npy"), rtol=1e-12)
+    np.testing.assert_allclose(split, np.load(str(tmp_path / "pdm_unsplit.npy")), rtol=1e-12)
