@@ -262,3 +262,18 @@ def test_scans_are_bitwise_reproducible_run_to_run():
         assert np.array_equal(_cabi.gls_scan(t, y, dy, f0, delta, nf), ref[0])
         assert np.array_equal(_cabi.pdm_scan(t, y, periods, 5, 2, np.var(y, ddof=1)), ref[1])
         assert np.array_equal(_cabi.stringlength_scan(t, m, periods), ref[2])
+
+
+def test_stringlength_fuzz_around_the_fast_path(seed=5):
+    """tools/fuzz_sl.py's generator (sizes around the fast kernel's capacity, tied / clustered / offset /
+    non-finite time stamps, extreme and special periods: all-ones significands, 1e±200, negative),
+    60 cases: parity with the oracle and bitwise repeatability."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_sl
+    rng = np.random.default_rng(seed)
+    with np.errstate(all="ignore"):
+        for case in range(60):
+            ok, info = fuzz_sl.one_case(rng)
+            assert ok, (case, info["n"], info["kind"], info["periods"], info["got"], info["want"])
