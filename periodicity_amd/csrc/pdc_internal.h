@@ -22,6 +22,13 @@ int cached(int device, Slot slot, int64_t bytes, void **dptr);
 // Frees the multi-GPU plan pdc_gls_scan_multi caches (multi.hip).
 void release_multi();
 
+// Grow-only device scratch cached per (device, stream) for the `_dev` entry points that need a
+// workspace the ABI does not pass in: work enqueued on one stream is ordered, so reuse is safe, and two
+// streams never share a buffer.  (Stream-ordered pool memory - hipMallocAsync - is NOT used: on ROCm 7.2 a
+// block handed out again by the pool gave kernels of the next call stale partial results unless the block
+// was memset first)  Released by pdc_release().
+int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr);
+
 // hipSetDevice + range check; every entry point starts here.
 int use_device(int device);
 

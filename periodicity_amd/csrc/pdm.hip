@@ -406,16 +406,6 @@ size_t lds_bytes(int m0, int block) {
     return stage + (size_t)(m0 + 1) * block * 12 + (size_t)(m0 + 2) * 8 + 64;
 }
 
-// stream-ordered scratch that is released on every exit path
-struct AsyncScratch {
-    char *p = nullptr;
-    hipStream_t st;
-    explicit AsyncScratch(hipStream_t s) : st(s) {}
-    ~AsyncScratch() {
-        if (p) (void)hipFreeAsync(p, st);
-    }
-};
-
 // dynamic-LDS limit of a kernel, raised once per process (not on every call)
 template <typename Kernel>
 int allow_lds(Kernel kernel) {
@@ -465,19 +455,24 @@ int phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, cons
             const size_t pcnt_b = (size_t)n_z * nbins * a.p_pad * 4;
             PDC_TRY(allow_lds(pdm_scan_kernel<256, 4, true>));
             PDC_TRY(allow_lds(pdm_finish_kernel));
-            AsyncScratch scratch(st);
-            PDC_HIP(hipMallocAsync((void **)&scratch.p, stat_b + psum_b + pq_b + pcnt_b, st));
-            a.stat = reinterpret_cast<double *>(scratch.p);
-            a.psum = reinterpret_cast<double *>(scratch.p + stat_b);
-            a.pq = reinterpret_cast<double *>(scratch.p + stat_b + psum_b);
-            a.pcnt = reinterpret_cast<unsigned *>(scratch.p + stat_b + psum_b + pq_b);
+            void *spv = nullptr;   // cached per (device, stream): see pdc_internal.h on why not hipMallocAsync
+            PDC_TRY(stream_scratch(device, st, (int64_t)(stat_b + psum_b + pq_b + pcnt_b), &spv));
+            char *const sp = static_cast<char *>(spv);
+            // PDC_PDM_POISON=1 fills the scratch with a NaN pattern first (debugging aid: every word the kernels
+            // read must have been written by them)
+            static const bool poison = [] { const char *e = getenv("PDC_PDM_POISON"); return e && e[0] == '1'; }();
+            if (poison) PDC_HIP(hipMemsetAsync(sp, 0x7f, stat_b + psum_b + pq_b + pcnt_b, st));
+            a.stat = reinterpret_cast<double *>(sp);
+            a.psum = reinterpret_cast<double *>(sp + stat_b);
+            a.pq = reinterpret_cast<double *>(sp + stat_b + psum_b);
+            a.pcnt = reinterpret_cast<unsigned *>(sp + stat_b + psum_b + pq_b);
             hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 0);
             hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 1);
             hipLaunchKernelGGL((pdm_scan_kernel<256, 4, true>), dim3((unsigned)groups0, (unsigned)n_z), dim3(256),
                                lds_bytes(last, 256), st, a);
             hipLaunchKernelGGL(pdm_finish_kernel, dim3((unsigned)groups0), dim3(64), (size_t)nbins * 64 * 16, st, a);
             PDC_HIP(hipGetLastError());
-            return PDC_OK;   // (the scratch goes back to the pool in stream order)
+            return PDC_OK;
         }
     }
     if (lds_bytes(last, 256) <= 150 * 1024) {

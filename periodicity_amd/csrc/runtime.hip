@@ -80,6 +80,50 @@ int cached(int device, Slot slot, int64_t bytes, void **dptr) {
     return PDC_OK;
 }
 
+struct StreamScratch {
+    int device;
+    hipStream_t stream;
+    void *buf;
+    int64_t cap;
+};
+static std::mutex g_scratch_mutex;
+static std::vector<StreamScratch> g_scratch;
+
+int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
+    std::lock_guard<std::mutex> lk(g_scratch_mutex);
+    if (bytes < 256) bytes = 256;
+    StreamScratch *e = nullptr;
+    for (StreamScratch &s : g_scratch)
+        if (s.device == device && s.stream == stream) e = &s;
+    if (!e) {
+        g_scratch.push_back({device, stream, nullptr, 0});
+        e = &g_scratch.back();
+    }
+    if (e->cap < bytes) {
+        if (e->buf) PDC_HIP(hipFree(e->buf));   // (synchronises the device: no kernel still uses it)
+        e->buf = nullptr;
+        e->cap = 0;
+        const int64_t want = bytes + bytes / 4;
+        PDC_HIP(hipMalloc(&e->buf, (size_t)want));
+        e->cap = want;
+    }
+    *dptr = e->buf;
+    return PDC_OK;
+}
+
+static int release_stream_scratch() {
+    std::lock_guard<std::mutex> lk(g_scratch_mutex);
+    for (StreamScratch &s : g_scratch) {
+        if (!s.buf) continue;
+        PDC_HIP(hipSetDevice(s.device));
+        PDC_HIP(hipFree(s.buf));
+        s.buf = nullptr;
+        s.cap = 0;
+    }
+    g_scratch.clear();
+    return PDC_OK;
+}
+
 DeviceLock::DeviceLock(int d) : device(d) {
     if (d >= 0 && d < (int)g_devices.size()) g_devices[d]->call_mutex.lock();
 }
@@ -124,6 +168,7 @@ int pdc_device_info(int device, char *name, int name_len, int *cu_count, int64_t
 
 int pdc_release(void) {
     release_multi();
+    PDC_TRY(release_stream_scratch());
     std::lock_guard<std::mutex> lk(g_mutex);
     for (size_t d = 0; d < g_devices.size(); ++d) {
         DeviceState *st = g_devices[d];

@@ -740,6 +740,7 @@ struct FastArgs {
     unsigned *gidx;             // [grid][n_pad]
     double *rsum;               // [grid][nr_pad][4]
     int *rcnt;                  // [grid][nr_pad]
+    double *rlen;               // [grid][nr_pad]  string length inside each range
     int64_t n_pad, nr_pad;
 };
 
@@ -874,6 +875,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
     unsigned *gi = a.gidx + (int64_t)blockIdx.x * a.n_pad;
     double *rsum = a.rsum + (int64_t)blockIdx.x * a.nr_pad * 4;
     int *rcnt = a.rcnt + (int64_t)blockIdx.x * a.nr_pad;
+    double *rlen = a.rlen + (int64_t)blockIdx.x * a.nr_pad;
     const bool t_safe = a.flags[0] != 0u;
 
     unsigned long long *keys_w = reinterpret_cast<unsigned long long *>(wbuf + wave * kWaveBytes);
@@ -894,7 +896,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         for (int b = tid; b < kNB + 64; b += kBlock) hist[b] = 0u;
-        if (tid < 16) defer[tid] = 0u;
+        if (tid < 16) defer[tid] = tid == 15 ? (unsigned)kWaves : 0u;   // [15]: next range to hand out (P3a)
         __syncthreads();
         // Samples past the end (the last trip of a thread) go to one of 64 dummy buckets behind the
         // histogram instead of being branched around: everything below is straight-line code.
@@ -1009,15 +1011,21 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         // full (cnt > 192, the usual case with 216-position windows), so only the last row carries the
         // dead-lane selects; the generic instance serves short ranges (the last one of a period,
         // sparse phases).
+        int r_next = nranges;
         auto process = [&](const int r, auto rows3_tag) {
             constexpr bool ROWS3 = decltype(rows3_tag)::value;
             const int cnt = n_cnt, lo_b = n_lob, hi_b = n_hib;
+            // the range after this one is handed out dynamically (waves that draw short or deferred ranges
+            // take more of them); the ticket is drawn now and used when the request goes out
+            unsigned ticket = 0u;
+            if (lane == 0) ticket = atomicAdd(&defer[15], 1u);
             if (cnt <= 0 || cnt > kFCap) {
                 if (lane == 0) {
                     if (cnt <= 0) rcnt[r] = 0;
                     else atomicOr(&defer[r >> 5], 1u << (r & 31));
                 }
-                if (r + kWaves < nranges) request(r + kWaves);
+                r_next = __builtin_amdgcn_readfirstlane((int)ticket);
+                if (r_next < nranges) request(r_next);
                 return;
             }
             // Lanes past the range's end ("dead", only in its last row) are not branched around: they
@@ -1060,7 +1068,8 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             }
 #define EK(e) ((unsigned long long)__double_as_longlong(ephi[e]))
             // the records of the next range go out now: t[] and the indices of this one are consumed
-            if (r + kWaves < nranges) request(r + kWaves);
+            r_next = __builtin_amdgcn_readfirstlane((int)ticket);
+            if (r_next < nranges) request(r_next);
             unsigned mx = 0;
 #pragma unroll
             for (int e = 0; e < kRPer; ++e) {
@@ -1159,14 +1168,14 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             for (int e = 0; e < kRPer; ++e) sm[e] = __longlong_as_double((long long)keys_w[lane + e * 64]);
             // the predecessor of lane j's point sits in lane j - 1 (one DPP shift per half); lane 0 takes
             // lane 63 of the previous row, carried as a wave-uniform pair
-            double carry_phi = 0.0, carry_m = 0.0, last_phi = 0.0, last_m = 0.0;
+            double carry_phi = 0.0, carry_m = 0.0, last_phi = 0.0, last_m = 0.0, inside = 0.0;
 #pragma unroll
             for (int e = 0; e < kRPer; ++e) {
                 const int j = lane + e * 64;
                 const double phi = sphi[e], mm = sm[e];
                 const double pphi = lane_below(phi, carry_phi), pm = lane_below(mm, carry_m);
                 const double seg = short_hypot(mm - pm, phi - pphi);
-                total += (live[e] && j > 0) ? seg : 0.0;
+                inside += (live[e] && j > 0) ? seg : 0.0;
                 carry_phi = read_lane(phi, 63);
                 carry_m = read_lane(mm, 63);
                 if (e == ((cnt - 1) >> 6)) {  // wave-uniform: the row that holds the range's last point
@@ -1174,17 +1183,22 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                     last_m = read_lane(mm, (cnt - 1) & 63);
                 }
             }
+            // the range's own length, lanes added in a fixed order: ranges are handed out dynamically, so
+            // the per-range sums (added up in range order in P3c), not per-lane running sums, keep the
+            // result independent of timing
+            inside = wave_sum(inside);
             if (lane == 0) {
                 rsum[(int64_t)r * 4 + 0] = sphi[0];
                 rsum[(int64_t)r * 4 + 1] = sm[0];
                 rsum[(int64_t)r * 4 + 2] = last_phi;
                 rsum[(int64_t)r * 4 + 3] = last_m;
                 rcnt[r] = cnt;
+                rlen[r] = inside;
             }
             wave_sync();
         };
         if (wave < nranges) request(wave);
-        for (int r = wave; r < nranges; r += kWaves) {
+        for (int r = wave; r < nranges; r = r_next) {
             if (n_cnt > 192) process(r, std::true_type{});
             else process(r, std::false_type{});
         }
@@ -1243,6 +1257,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                     rsum[(int64_t)r * 4 + 2] = p1;
                     rsum[(int64_t)r * 4 + 3] = m1;
                     rcnt[r] = cnt;
+                    rlen[r] = 0.0;   // (its segments were added to `total` by the whole workgroup, in a fixed order)
                 }
                 __syncthreads();
             }
@@ -1252,6 +1267,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         // ---- P3c: links between consecutive non-empty ranges + the closing segment ----------------
         for (int r = tid; r < nranges; r += kBlock) {
             if (rcnt[r] > 0) {
+                total += rlen[r];
                 int q = r - 1;
                 while (q >= 0 && rcnt[q] == 0) --q;
                 if (q >= 0)
@@ -1312,13 +1328,13 @@ int64_t pad_pow2(int64_t n) {
 int64_t grid_for(int64_t n_periods) { return n_periods < kMaxGrid ? n_periods : kMaxGrid; }
 
 // ranges: one per window of every slice, plus one per slice / oversized bucket
-int64_t range_slots(int64_t n) { return n / kWin + n / 8192 + 64; }
+int64_t range_slots(int64_t n) { return (n / kWin + n / 8192 + 64 + 3) & ~(int64_t)3; }   // (multiple of 4: keeps every array 16-byte aligned)
 
 // (the smaller of the two slice capacities: above it the kernel may need the per-period partition)
 bool may_need_partition(int64_t n) { return n > Lds<unsigned>::capacity; }
 
 int64_t scratch_bytes(int64_t n, int64_t n_periods, int64_t partition) {
-    return grid_for(n_periods > 0 ? n_periods : 1) * (pad_pow2(n) * 12 + range_slots(n) * 36 + partition) + 512;
+    return grid_for(n_periods > 0 ? n_periods : 1) * (pad_pow2(n) * 12 + range_slots(n) * 44 + partition) + 512;
 }
 
 // AoS (t, m) records + flags of the fast path, placed behind the general scratch
@@ -1386,6 +1402,7 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
         f.gidx = a.gidx;
         f.rsum = a.rsum;
         f.rcnt = a.rcnt;
+        f.rlen = reinterpret_cast<double *>(static_cast<char *>(work) + grid * (a.n_pad * 12 + a.nr_pad * 36));
         f.n_pad = a.n_pad;
         f.nr_pad = a.nr_pad;
         char *table = static_cast<char *>(work) + scratch_bytes(n, n_periods, 0);

@@ -269,3 +269,25 @@ def test_pdm_few_periods_many_samples_split_the_samples(tmp_path):
     x = np.sin(2 * np.pi * t / 6.3) + 0.3 * rng.standard_normal(n)
     split = _cabi.pdm_scan(t, x, np.linspace(0.9, 40.0, 1000), 5, 2, np.var(x, ddof=1))
     np.testing.assert_allclose(split, np.load(str(tmp_path / "pdm_unsplit.npy")), rtol=1e-12)
+
+
+def test_pdm_split_mode_is_stable_over_repeated_calls_and_reallocations():
+    """Regression: the split mode's partial histograms used to live in stream-ordered pool memory
+    (hipMallocAsync); a block handed out again by the pool gave the next call stale partials - the
+    second of two back-to-back calls after a large reallocation came back wrong by O(1).  The scratch
+    is now cached per (device, stream)."""
+    rng = np.random.default_rng(1)
+    n, n_per = 200_000, 2048
+    t = np.sort(rng.uniform(0, float(n), n))
+    y = np.sin(2 * np.pi * t / 13.7) + 0.1 * rng.standard_normal(n)
+    m = so.stringlength_scale(y)
+    periods = np.linspace(1.0, 100.0, n_per)
+    sigma = np.var(y, ddof=1)
+    first = _cabi.pdm_scan(t, y, periods, 5, 2, sigma)
+    _cabi.stringlength_scan(t, m, periods[:64])                 # grows the cached workspace (hipFree + hipMalloc)
+    for _ in range(3):
+        assert np.array_equal(_cabi.pdm_scan(t, y, periods, 5, 2, sigma), first)
+    pick = np.array([0, n_per // 3, n_per - 1])
+    np.testing.assert_allclose(first[pick], co.pdm_scan(t, y, periods[pick], 5, 2), rtol=RTOL)
+    aov = _cabi.aov_scan(t, y, periods, 10)
+    assert np.array_equal(_cabi.aov_scan(t, y, periods, 10), aov)
