@@ -807,6 +807,23 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {   // valid in lan
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Wave-wide sum of doubles in a FIXED order (the scan pattern above on both halves of the double; the
+// total ends in lane 63 and is broadcast): no LDS permutes on the critical path of a range.
+#define PDC_DPP_F64(v, ctrl, rmask)                                                                          \
+    __longlong_as_double(((long long)PDC_DPP(0u, (unsigned)(__double_as_longlong(v) >> 32), ctrl, rmask) << 32) | \
+                         (long long)PDC_DPP(0u, (unsigned)__double_as_longlong(v), ctrl, rmask))
+__device__ __forceinline__ double wave_sum_fixed(double v) {
+    v += PDC_DPP_F64(v, 0x111, 0xf);
+    v += PDC_DPP_F64(v, 0x112, 0xf);
+    v += PDC_DPP_F64(v, 0x114, 0xf);
+    v += PDC_DPP_F64(v, 0x118, 0xf);
+    v += PDC_DPP_F64(v, 0x142, 0xa);
+    v += PDC_DPP_F64(v, 0x143, 0xc);
+    const long long b = __double_as_longlong(v);
+    return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(b >> 32), 63) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane((int)b, 63));
+}
+
 // x of the lane below (lane 0: `first`), by DPP wave_shr:1 on both halves - no LDS permute
 __device__ __forceinline__ double lane_below(double x, double first) {
     const long long xb = __double_as_longlong(x), fb = __double_as_longlong(first);
@@ -1186,7 +1203,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             // the range's own length, lanes added in a fixed order: ranges are handed out dynamically, so
             // the per-range sums (added up in range order in P3c), not per-lane running sums, keep the
             // result independent of timing
-            inside = wave_sum(inside);
+            inside = wave_sum_fixed(inside);
             if (lane == 0) {
                 rsum[(int64_t)r * 4 + 0] = sphi[0];
                 rsum[(int64_t)r * 4 + 1] = sm[0];
