@@ -127,7 +127,10 @@ def valu_issue_block(kernel_substr, kernel_ms):
     busy_s = k["SQ_INSTS_VALU"] * FP64_ISSUE_CYCLES / SIMDS / CLOCK_HZ
     out = {"kernel": k["name"], "valu_wave_instr_per_launch": k["SQ_INSTS_VALU"],
            "frac": round(busy_s / (kernel_ms * 1e-3), 4),
-           "profiled_ms": k["ms"], "source": "profiles/r02_pmc_summary.json"}
+           "profiled_ms": k["ms"], "source": "profiles/r02_pmc_summary.json",
+           "note": "frac prices every VALU wave-instruction at the fp64 rate (4 cycles per wave64): exact for "
+                   "the fp64-fma streams of the GLS kernels, an upper bound where the mix holds 32-bit "
+                   "instructions (PDM, StringLength)"}
     for key in ("hbm_bytes", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_LDS_BANK_CONFLICT",
                 "SQ_LDS_IDX_ACTIVE", "TCP_TCC_READ_REQ_sum"):
         if key in k:
