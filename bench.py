@@ -251,6 +251,20 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2):
                     "valu_issue": blk if blk else None}
         if why:
             out[key]["valu_issue_note"] = why
+    # ranked peaks with prominences + half-maximum crossings of the 4096 resident spectra (f3)
+    k = 4
+    pk = DB(B * (1 + 5 * k) * 8, dev)
+    p_cnt = pk.ptr
+    p_idx, p_lo, p_hi = p_cnt + B * 8, p_cnt + B * 8 * (1 + k), p_cnt + B * 8 * (1 + 2 * k)
+    p_h, p_p = p_cnt + B * 8 * (1 + 3 * k), p_cnt + B * 8 * (1 + 4 * k)
+    ms = tm.ms(lambda: cabi.check(lib.pdc_peaks_topk_dev(dev, stream, power.ptr, B, nf, k, 1, p_cnt, p_idx, p_h, p_p,
+                                                         p_lo, p_hi)), reps=3)
+    out["c3_peaks_topk"] = {"ms": round(ms, 3), "k": k, "by": "prominence",
+                            "GBps_over_spectra": round(B * nf * 8 / ms / 1e6, 1),
+                            "note": "pdc_peaks_topk_dev on the 1.64 GB of spectra left in HBM by c3_power: "
+                                    "find_peaks maxima, scipy prominences, 4 most prominent + half-maximum "
+                                    "crossings per curve; 0.8 MB come back instead of 1.64 GB"}
+    pk.free()
     out["c3_note"] = ("BASELINE configs[2]: 4096 curves x 2000 samples x 5e4 shared frequencies, resident; "
                       "power = 1.64 GB of spectra written; peaks_only = per-curve amax/argmax reduced on "
                       "the device; shared_t = the bootstrap shape (one time axis, trigonometry shared "
@@ -304,7 +318,32 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2):
         "valu_issue": blk}
     if why:
         out["c5_stringlength"]["valu_issue_note"] = why
-    for b in (bt5, bx, bp, bth, bm, bsp, be, swork):
+    ms = tm.ms(lambda: cabi.check(lib.pdc_aov_scan_dev(dev, stream, bt5.ptr, bx.ptr, n, bp.ptr, n_per, 10, bth.ptr)),
+               reps=3)
+    out["c5_aov"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), "n_bins": 10}
+    lo5, hi5 = y5.min(), y5.max()
+    mag = np.minimum(np.floor((y5 - lo5) / (hi5 - lo5) * 5), 4).astype(np.float64)
+    bmag = DB.from_array(mag, dev)
+    ms = tm.ms(lambda: cabi.check(lib.pdc_cond_entropy_scan_dev(dev, stream, bt5.ptr, bmag.ptr, n, bp.ptr, n_per,
+                                                                10, 5, bth.ptr)), reps=3)
+    out["c5_cond_entropy"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), "cells": "10 x 5"}
+    for b in (bt5, bx, bp, bth, bm, bsp, be, swork, bmag):
+        b.free()
+
+    # -- C4's per-GPU share: N=1e6 samples x the 1.25e6-frequency slab one of 8 GPUs scans ------------
+    n4, nf4 = 1_000_000, 1_250_000
+    t4, y4, dy4 = synth_curve(n4, 4)
+    df4 = 1.0 / (t4[-1] - t4[0]) / 5
+    b4 = [DB.from_array(a_, dev) for a_ in (t4, y4, dy4)]
+    wb4 = lib.pdc_gls_work_bytes(n4, 1, nf4)
+    w4, p4 = DB(wb4, dev), DB(nf4 * 8, dev)
+    ms = tm.ms(lambda: cabi.check(lib.pdc_gls_scan_dev(dev, stream, b4[0].ptr, b4[1].ptr, b4[2].ptr, None, n4, 1, 0,
+                                                       0.5 * df4, df4, 3 * nf4, nf4, 1, 0, p4.ptr, None, None,
+                                                       w4.ptr, wb4)), reps=2, warm=1)
+    out["c4_slab_of_8"] = {"ms": round(ms, 2), "Gpair_per_s": round(float(n4) * nf4 / ms / 1e6, 1),
+                           "note": "BASELINE configs[3] (N=1e6 x nf=1e7 over 8 GPUs): the slab j in [3.75e6, 5e6) "
+                                   "one GPU scans, resident; the 8-GPU run adds one 10 MB-per-rank all-gather"}
+    for b in b4 + [w4, p4]:
         b.free()
     return out
 

@@ -9,6 +9,8 @@
 // flat top while x[j] == x[i]; it is a peak only if the sample after the flat top is lower, and
 // the reported index is the midpoint (left + right) // 2 of the flat top.  The first and last
 // sample are never peaks; comparisons with NaN are false, so NaN is never part of one.
+#include <type_traits>
+
 #include "pdc_internal.h"
 
 using namespace pdc;
@@ -83,7 +85,7 @@ struct PeakArgs {
     const double *power;
     int64_t nf;
     int k, by_prominence, blk_shift;
-    int64_t nblk;
+    int64_t nblk, tile;
     long long *count, *idx, *half_lo, *half_hi;
     double *height, *prom;
 };
@@ -102,6 +104,9 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *bmin = reinterpret_cast<double *>(lds_raw);   // [nblk]
     double *bmax = bmin + a.nblk;                         // [nblk]
+    double *tile = bmax + a.nblk + 1;                     // [-1 .. a.tile]: the part of the spectrum being scanned + halo
+    int *plist = reinterpret_cast<int *>(tile + a.tile + 1);  // [a.tile / 2 + 2] peaks of the tile (bin - t0)
+    __shared__ int s_npk;
     __shared__ double red_k[kPkBlock / 64];
     __shared__ long long red_i[kPkBlock / 64];
     __shared__ int red_t[kPkBlock / 64];
@@ -140,15 +145,22 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
     }
     __syncthreads();
 
-    // lowest sample met walking from `from` in direction dir (+1 / -1) while x[i] <= h (scipy's loop)
-    auto walk = [&](int64_t from, int dir, double h) -> double {
+    // The spectrum is scanned tile by tile through LDS (tiles are whole blocks): a dependent chain of
+    // global loads costs an L2 round trip per step once 32 waves of walkers thrash the 32 KB L1, an LDS
+    // read ~20x less, and nearly every step of nearly every walk stays inside the tile of its peak.
+    int64_t t0 = 0, t1 = 0;
+
+    // lowest sample met walking from `from` (a bin of the current tile) in direction dir (+1 / -1) while
+    // x[i] <= h (scipy's loop).  Blocks never straddle tiles, so every stepping loop reads either LDS
+    // or global memory, never a per-lane mix.
+    auto walk = [&](int64_t from, int dir, double h, auto start_in_tile) -> double {
         double low = h;
         int64_t i = from;
-        // inside the starting block
+        // inside the starting block (in the tile, except for a flat top that ran past the tile's end)
         const int64_t b0 = from >> sh;
         const int64_t edge = dir > 0 ? (((b0 + 1) << sh) < nf ? ((b0 + 1) << sh) : nf) : (b0 << sh) - 1;
         while (i != edge) {
-            const double v = x[i];
+            const double v = decltype(start_in_tile)::value ? tile[i - t0] : x[i];
             if (!(v <= h)) return low;
             low = v < low ? v : low;
             i += dir;
@@ -161,7 +173,15 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
         }
         if (b < 0 || b >= a.nblk) return low;   // reached the border of the signal
         i = dir > 0 ? b << sh : (((b + 1) << sh) < nf ? ((b + 1) << sh) : nf) - 1;
-        for (;;) {                               // this block holds a sample > h (or a NaN): the walk ends in it
+        if (i >= t0 && i < t1) {
+            for (;;) {                           // this block holds a sample > h (or a NaN): the walk ends in it
+                const double v = tile[i - t0];
+                if (!(v <= h)) return low;
+                low = v < low ? v : low;
+                i += dir;
+            }
+        }
+        for (;;) {                               // ... the same in a block of another tile
             const double v = x[i];
             if (!(v <= h)) return low;
             low = v < low ? v : low;
@@ -179,15 +199,39 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
         best_h[q] = best_p[q] = 0.0;
     }
     long long mine = 0;
-    for (int64_t i = 1 + tid; i < nf - 1; i += kPkBlock) {   // ascending per thread
-        const double v = x[i];
-        if (!(x[i - 1] < v)) continue;
-        int64_t ahead = i + 1;
-        while (ahead < nf - 1 && x[ahead] == v) ++ahead;
-        if (!(x[ahead] < v)) continue;
-        const int64_t mid = (i + ahead - 1) / 2;
-        ++mine;
-        const double lo = walk(mid, -1, v), hi = walk(mid, +1, v);
+    for (t0 = 0; t0 < nf; t0 += a.tile) {
+    t1 = t0 + a.tile < nf ? t0 + a.tile : nf;
+    __syncthreads();   // everyone is done with the previous tile
+    for (int64_t i = t0 - 1 + tid; i <= t1; i += kPkBlock) tile[i - t0] = (i >= 0 && i < nf) ? x[i] : 0.0;
+    __syncthreads();
+    if (tid == 0) s_npk = 0;
+    __syncthreads();
+    // (1) the tile's maxima, compacted into a list: with lanes = bins only every eighth lane would hold a
+    // peak and every 64-bin window would cost the longest walk among its few peaks
+    for (int64_t i = (t0 > 0 ? t0 : 1) + tid; i < t1 && i < nf - 1; i += kPkBlock) {
+        const double v = tile[i - t0];
+        if (!(tile[i - 1 - t0] < v)) continue;
+        int64_t ahead = i + 1;   // (a flat top may run past the tile and its halo: global reads from there on)
+        while (ahead < nf - 1 && (ahead <= t1 ? tile[ahead - t0] : x[ahead]) == v) ++ahead;
+        if (!((ahead <= t1 ? tile[ahead - t0] : x[ahead]) < v)) continue;
+        plist[atomicAdd(&s_npk, 1)] = (int)((i + ahead - 1) / 2 - t0);
+    }
+    __syncthreads();
+    const int npk = s_npk;
+    mine += tid == 0 ? npk : 0;
+    // (2) lanes = consecutive entries of the list: prominence walks, per-thread top K
+    for (int pi = tid; pi < npk; pi += kPkBlock) {
+        const int64_t mid = t0 + plist[pi];
+        const bool inside = mid < t1;
+        const double v = inside ? tile[mid - t0] : x[mid];
+        double lo, hi;
+        if (inside) {
+            lo = walk(mid, -1, v, std::true_type{});
+            hi = walk(mid, +1, v, std::true_type{});
+        } else {
+            lo = walk(mid, -1, v, std::false_type{});
+            hi = walk(mid, +1, v, std::false_type{});
+        }
         const double prom = v - (lo > hi ? lo : hi);
         const double ckey = a.by_prominence ? prom : v;
         // insertion into the sorted list (descending key, then bin): slot = number of entries that stay
@@ -212,6 +256,7 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
                 best_p[q] = prom;
             }
         }
+    }
     }
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
     if (lane == 0) s_count[wave] = mine;
@@ -384,7 +429,17 @@ int launch_topk(hipStream_t st, PeakArgs a, int64_t n_curves) {
     while (((a.nf + ((int64_t)1 << sh) - 1) >> sh) > kPkMaxBlocks) ++sh;
     a.blk_shift = sh;
     a.nblk = (a.nf + ((int64_t)1 << sh) - 1) >> sh;
-    const size_t lds = (size_t)(a.nblk > 0 ? a.nblk : 1) * 16;
+    // tile of the spectrum staged in LDS: whole blocks, ~2048 bins (16 KB + halo: five workgroups per CU
+    // at 5e4 bins), or the whole row
+    const int64_t blk = (int64_t)1 << sh;
+    a.tile = blk > 2048 ? blk : 2048;
+    if (a.tile > a.nf) a.tile = ((a.nf > 0 ? a.nf : 1) + blk - 1) / blk * blk;
+    const size_t lds = (size_t)(a.nblk > 0 ? a.nblk : 1) * 16 + (size_t)(a.tile + 2) * 8 + (size_t)(a.tile / 2 + 4) * 4 + 16;
+    static const hipError_t attr[3] = {
+        hipFuncSetAttribute((const void *)peaks_topk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
+        hipFuncSetAttribute((const void *)peaks_topk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
+        hipFuncSetAttribute((const void *)peaks_topk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)};
+    for (hipError_t e : attr) PDC_HIP(e);
     const dim3 grid((unsigned)n_curves), block(kPkBlock);
     if (a.k <= 1) hipLaunchKernelGGL((peaks_topk_kernel<1>), grid, block, lds, st, a);
     else if (a.k <= 4) hipLaunchKernelGGL((peaks_topk_kernel<4>), grid, block, lds, st, a);
