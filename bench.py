@@ -196,7 +196,7 @@ class EventTimer:
         return float(np.median(out))
 
 
-def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2):
+def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=True):
     """Kernel-level numbers of the other single-GPU configs (BASELINE.json configs[2], [4]) and the
     PCIe-inclusive rate of the headline config, so that they appear in the driver's record."""
     tm = EventTimer(lib, cabi, dev, stream)
@@ -318,6 +318,31 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2):
         "valu_issue": blk}
     if why:
         out["c5_stringlength"]["valu_issue_note"] = why
+    if with_cpu:
+        # the reference's per-period work on the host (never inside a timed GPU region): numpy restatement
+        # of PDM._pdm / _stringlength on ONE core as upstream's Pool worker runs it, and the plain-C
+        # restatement under OpenMP on all cores, on a bounded subsample of the grid, scaled linearly
+        from oracle import c_oracle as co
+        from oracle import scan_oracle as so
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+        co.set_threads(cores)
+        sub = np.linspace(0, n_per - 1, 16 * max(8, cores // 8)).astype(int)
+        for key, np_fn, c_fn, grid in (
+                ("c5_pdm", lambda p: so.pdm_scan(t5, y5, p, 5, 2), lambda p: co.pdm_scan(t5, y5, p, 5, 2), periods),
+                ("c5_stringlength", lambda p: so.stringlength_scan(t5, m, p), lambda p: co.stringlength_scan(t5, m, p),
+                 sl_periods)):
+            t0 = time.perf_counter()
+            np_fn(grid[sub[:6]])
+            dt_np = (time.perf_counter() - t0) / 6
+            c_fn(grid[sub[:cores]])                       # warm-up (OpenMP team)
+            t0 = time.perf_counter()
+            c_fn(grid[sub])
+            dt_c = time.perf_counter() - t0
+            out[key]["cpu_baseline"] = {
+                "numpy_ms_per_period_one_core": round(dt_np * 1e3, 3),
+                "numpy_core_seconds_full_grid": round(dt_np * n_per, 1),
+                "c_openmp_seconds_full_grid": round(dt_c * n_per / sub.size, 2), "cores": cores, "kind": "port",
+                "sample": f"{sub.size} of {n_per} trial periods, scaled linearly"}
     ms = tm.ms(lambda: cabi.check(lib.pdc_aov_scan_dev(dev, stream, bt5.ptr, bx.ptr, n, bp.ptr, n_per, 10, bth.ptr)),
                reps=3)
     out["c5_aov"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), "n_bins": 10}
@@ -586,7 +611,8 @@ def main():
                                        "the headline metric, which counts exact pair evaluations"}
             fwork.free()
             if not args.no_extras:
-                out["extras"] = extra_configs(lib, _cabi, dev, stream, t, y, dy, f0, delta, nf_total)
+                out["extras"] = extra_configs(lib, _cabi, dev, stream, t, y, dy, f0, delta, nf_total,
+                                               with_cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline and n_gpus == 1:
             base, p_fft = cpu_baseline(t, y, dy, freq, df, fmin)
             out["cpu_baseline"] = base

@@ -207,15 +207,15 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     double2 *stage = reinterpret_cast<double2 *>(lds_raw);                  // [kChunk] (t, x')
     // the staging area doubles as the q_over/q_nan exchange ([2][BLOCK] doubles) at the end
     constexpr int kStage = kChunk > BLOCK ? kChunk : BLOCK;
-    double *hsum = reinterpret_cast<double *>(stage + kStage);              // [nbins][BLOCK]
-    unsigned *hcnt = reinterpret_cast<unsigned *>(hsum + (size_t)nbins * BLOCK);  // [nbins][BLOCK]
+    double *hsum = reinterpret_cast<double *>(stage + kStage);              // [nbins][BLOCK] (not with CE: counts only)
+    unsigned *hcnt = reinterpret_cast<unsigned *>(hsum + (CE ? 0 : (size_t)nbins * BLOCK));  // [nbins][BLOCK]
     double *edge = reinterpret_cast<double *>(hcnt + (size_t)nbins * BLOCK);      // [m0 + 2]
     double *red = edge + m0 + 2;                                                  // [BLOCK/64]
     const int tid = threadIdx.x;
 
     for (int k = tid; k < m0 + 2; k += BLOCK) edge[k] = (double)k / (double)m0;  // Python's k / m0
     for (int k = 0; k < nbins; ++k) {
-        hsum[k * BLOCK + tid] = 0.0;
+        if (!CE) hsum[k * BLOCK + tid] = 0.0;
         hcnt[k * BLOCK + tid] = 0u;
     }
 
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
             for (int q = 1; q < SPLIT; ++q) {
                 const int other = tid + 64 * q;
                 for (int k = 0; k < nbins; ++k) {
-                    hsum[k * BLOCK + tid] += hsum[k * BLOCK + other];
+                    if (!CE) hsum[k * BLOCK + tid] += hsum[k * BLOCK + other];
                     hcnt[k * BLOCK + tid] += hcnt[k * BLOCK + other];
                 }
                 q_over += qx[other];
@@ -401,9 +401,9 @@ __global__ __launch_bounds__(64) void pdm_finish_kernel(PdmArgs a) {
     else a.theta[pidx] = theta_from_bins(sum_at, cnt_at, m0, a.nc, q_total, q_nan, q_over, a.sigma);
 }
 
-size_t lds_bytes(int m0, int block) {
+size_t lds_bytes(int m0, int block, int bytes_per_bin = 12) {   // 12: sum + count; 4: counts only (CE)
     const size_t stage = (size_t)(kChunk > block ? kChunk : block) * 16;
-    return stage + (size_t)(m0 + 1) * block * 12 + (size_t)(m0 + 2) * 8 + 64;
+    return stage + (size_t)(m0 + 1) * block * bytes_per_bin + (size_t)(m0 + 2) * 8 + 64;
 }
 
 // dynamic-LDS limit of a kernel, raised once per process (not on every call)
@@ -475,8 +475,9 @@ int phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, cons
             return PDC_OK;
         }
     }
-    if (lds_bytes(last, 256) <= 150 * 1024) {
-        const size_t lds = lds_bytes(last, 256);
+    const int bpb = kind == 2 ? 4 : 12;
+    if (lds_bytes(last, 256, bpb) <= 150 * 1024) {
+        const size_t lds = lds_bytes(last, 256, bpb);
         // waves = ceil(P/64) * SPLIT; aim at >= 4 waves per SIMD (4096 on the chip)
         const int64_t groups = (n_periods + 63) / 64;
         const int split = groups >= 4096 ? 1 : (groups >= 2048 ? 2 : 4);
@@ -498,7 +499,7 @@ int phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, cons
             PDC_TRY(launch(pdm_scan_kernel<256, 1>, 256));
         }
     } else {
-        const size_t lds = lds_bytes(last, 64);
+        const size_t lds = lds_bytes(last, 64, bpb);
         if (kind == 2) {
             PDC_TRY(allow_lds(pdm_scan_kernel<64, 1, false, true>));
             hipLaunchKernelGGL((pdm_scan_kernel<64, 1, false, true>), dim3((unsigned)((n_periods + 63) / 64)), dim3(64),
