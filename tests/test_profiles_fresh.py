@@ -1,0 +1,35 @@
+"""bench.py's roofline block reads executed-instruction counts from profiles/r02_pmc_summary.json and
+refuses entries collected for other kernel sources.  This test keeps the committed summary in step
+with the committed sources of the HEADLINE kernel (re-run tools/collect_pmc.sh on a GPU box after
+touching them), and checks the refusal logic itself."""
+import json
+import os
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_pmc_summary_matches_the_headline_kernel_sources():
+    summ = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+    now = bench.source_hashes()
+    for name in bench.sources_of("gls_scan_kernel<16, 0, 2>"):
+        assert summ["src_sha"].get(name) == now[name], f"{name} changed since the PMC passes: re-collect"
+    k, why = bench.pmc_for("gls_scan_kernel", 27.5)
+    assert why is None and k["SQ_INSTS_VALU"] > 1e10
+    blk, _ = bench.valu_issue_block("gls_scan_kernel", 27.5)
+    assert 0.5 < blk["frac"] <= 1.0                      # an executed-issue fraction, never above 1
+
+
+def test_stale_or_missing_entries_are_refused(tmp_path, monkeypatch):
+    summ = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+    summ["src_sha"]["gls.hip"] = "0" * 16
+    path = tmp_path / "stale.json"
+    path.write_text(json.dumps(summ))
+    monkeypatch.setattr(bench, "PMC_SUMMARY", str(path))
+    k, why = bench.pmc_for("gls_scan_kernel", 27.5)
+    assert k is None and "gls.hip" in why and "stale" in why
+    k, why = bench.pmc_for("gls_scan_kernel", 500.0)     # no profiled launch of that duration
+    assert k is None and "within 25%" in why
+    monkeypatch.setattr(bench, "PMC_SUMMARY", str(tmp_path / "absent.json"))
+    assert bench.pmc_for("gls_scan_kernel", 27.5) == (None, "profiles/r02_pmc_summary.json is missing")
