@@ -56,12 +56,15 @@ bool force_rccl() {
 }
 
 void plan_free(GlsPlan *p) {
+    for (PlanDev &d : p->dev) {   // drain every stream before the communicators go
+        if (d.device < 0 || hipSetDevice(d.device) != hipSuccess) continue;
+        if (d.compute) (void)hipStreamSynchronize(d.compute);
+        if (d.comm) (void)hipStreamSynchronize(d.comm);
+    }
     for (ncclComm_t c : p->comms)
         if (c) ncclCommDestroy(c);
     for (PlanDev &d : p->dev) {
         if (d.device < 0 || hipSetDevice(d.device) != hipSuccess) continue;
-        if (d.compute) (void)hipStreamSynchronize(d.compute);
-        if (d.comm) (void)hipStreamSynchronize(d.comm);
         for (hipEvent_t e : {d.scanned[0], d.scanned[1], d.gathered[0], d.gathered[1], d.k0, d.k1})
             if (e) (void)hipEventDestroy(e);
         if (d.compute) (void)hipStreamDestroy(d.compute);
