@@ -717,16 +717,25 @@ constexpr int kFCap = 255;             // samples a wave ranks by itself: counts
 constexpr int kFine = 1024;            // fine buckets per range, 8-bit counters packed four to a word
 constexpr int kRanges = 320;           // >= capacity / kFWin + 2
 constexpr int kKMax = 52;              // samples per thread in P1/P2 (capacity <= kKMax * kBlock)
-constexpr int kWaveBytes = Lds<unsigned short>::wave_bytes;
-constexpr int kFixed = kWaves * kWaveBytes + 2 * (kRanges + 8) * 2 + 64;
+constexpr int kNBLarge = kBucketsLarge; // coarse buckets of the several-slice instance (N above one slice)
 constexpr int kStatic = 512;           // static __shared__ below, rounded up
 constexpr int kLdsTotalDyn = kLdsTotal - kStatic;
-constexpr int kCapacity = (((kLdsTotal - kFixed - kStatic) / 2) & ~7) - 64;   // (+ 64 dummy slots)
+// LDS layout per index type: 16-bit sample indices while one slice holds all samples, 32-bit beyond
+template <typename IdxT>
+struct FL {
+    static constexpr int wave_bytes = Lds<IdxT>::wave_bytes;
+    static constexpr int fixed = kWaves * wave_bytes + 2 * (kRanges + 8) * 2 + 64;
+    static constexpr int capacity = ((((kLdsTotal - fixed - kStatic) / (int)sizeof(IdxT)) & ~7) - 64);   // (+ 64 dummy slots)
+};
+constexpr int kCapacity = FL<unsigned short>::capacity;   // samples the one-slice instances take
 static_assert(kCapacity / kFWin + 2 <= kRanges, "range table too small");
 static_assert(kFine + 16 <= (kWFine + 4) * 4, "byte counters live in the general kernel's counter area");
 static_assert(kCapacity <= kKMax * kBlock, "P1 keeps one bucket id per sample in registers");
-static_assert(kCapacity < 65536, "16-bit sample indices");
-static_assert(kWaves * kWaveBytes >= (kNB + 64) * 4 && kWaves * kWaveBytes >= kDCap * 10, "aliases must fit");
+static_assert(kCapacity < 65536 && FL<unsigned>::capacity < 65536, "slice positions are 16-bit");
+static_assert(kWaves * FL<unsigned short>::wave_bytes >= (kNB + 64) * 4 && kWaves * FL<unsigned short>::wave_bytes >= kDCap * 10,
+              "aliases must fit");
+static_assert(kWaves * FL<unsigned>::wave_bytes >= kNBLarge * 4 && kWaves * FL<unsigned>::wave_bytes >= kDCap * 12,
+              "aliases must fit");
 
 typedef double rec_t __attribute__((ext_vector_type(2)));   // (t, m)
 
@@ -742,6 +751,7 @@ struct FastArgs {
     int *rcnt;                  // [grid][nr_pad]
     double *rlen;               // [grid][nr_pad]  string length inside each range
     int64_t n_pad, nr_pad;
+    unsigned *ghist;            // [grid][kNBLarge]  first sorted position of every coarse bucket (several slices)
 };
 
 // RN(t / period) without the division: y = RN(1 / period); q0 = RN(t y) is within 1.5 ulp of the
@@ -777,10 +787,11 @@ __device__ __forceinline__ unsigned long long phase_key(double phi) {
     return phi == phi ? (unsigned long long)__double_as_longlong(phi) : 0x7FF8000000000000ull;
 }
 
+template <int NB = kNB>
 __device__ __forceinline__ int coarse_of(double phi) {
-    const unsigned b = (unsigned)(phi * (double)kNB);           // exact product; v_cvt_u32 saturates
-    const unsigned c = b < (unsigned)(kNB - 1) ? b : (unsigned)(kNB - 1);
-    return phi == phi ? (int)c : kNB - 1;
+    const unsigned b = (unsigned)(phi * (double)NB);            // exact product; v_cvt_u32 saturates
+    const unsigned c = b < (unsigned)(NB - 1) ? b : (unsigned)(NB - 1);
+    return phi == phi ? (int)c : NB - 1;
 }
 
 // Wave-wide inclusive scan / maximum by DPP row shifts and row broadcasts (gfx9 encodings: row_shr:n =
@@ -873,19 +884,26 @@ __device__ __forceinline__ void phases4(const double (&t)[4], double period, dou
     for (int u = 0; u < 4; ++u) phi[u] = q[u] - __builtin_floor(q[u]);
 }
 
-template <int KMAX>
+// MULTI = false: all samples fit one LDS slice (KMAX = samples per thread kept in registers between P1
+// and P2, 16-bit indices, NB = 2048).  MULTI = true (kCapacity < N <= 13 slices): one histogram pass over
+// all samples (rolled loop) gives the bucket starts, then the period is worked off in slices of
+// consecutive buckets that fit LDS - all samples folded again and this slice's scattered into order[],
+// range table, P3a, P3b - with 32-bit indices and NB = 8192 coarse buckets.
+template <int KMAX, typename IdxT = unsigned short, int NB = kNB, bool MULTI = false>
 __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
+    constexpr int kWaveBytes = FL<IdxT>::wave_bytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char *wbuf = lds_raw;                                                  // P3a: per-wave scratch
-    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw);                         // P1/P2 alias [kNB + 64]
+    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw);                         // P1/P2 alias [NB + 64]
     unsigned long long *bkeys = reinterpret_cast<unsigned long long *>(lds_raw);    // P3b alias [kDCap]
-    unsigned short *bidx = reinterpret_cast<unsigned short *>(bkeys + kDCap);       // P3b alias [kDCap]
+    IdxT *bidx = reinterpret_cast<IdxT *>(bkeys + kDCap);                           // P3b alias [kDCap]
     unsigned short *bndb = reinterpret_cast<unsigned short *>(lds_raw + kWaves * kWaveBytes);
     unsigned short *bnds = bndb + kRanges + 8;
     unsigned *defer = reinterpret_cast<unsigned *>(bnds + kRanges + 8);             // [16]
-    unsigned short *order = reinterpret_cast<unsigned short *>(defer + 16);         // [n + 64]
+    IdxT *order = reinterpret_cast<IdxT *>(defer + 16);                             // [slice + 64]
     __shared__ unsigned wave_tot[kWaves];
     __shared__ double red[kWaves];
+    __shared__ unsigned s_fill;
     const int tid0 = threadIdx.x, lane = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int n = (int)a.n;
     unsigned long long *gk = a.gkeys + (int64_t)blockIdx.x * a.n_pad;
@@ -897,9 +915,8 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
 
     unsigned long long *keys_w = reinterpret_cast<unsigned long long *>(wbuf + wave * kWaveBytes);
     unsigned *fine_w = reinterpret_cast<unsigned *>(wbuf + wave * kWaveBytes + kRCap * 8);
-    unsigned short *idx_w = reinterpret_cast<unsigned short *>(wbuf + wave * kWaveBytes + kRCap * 8 + (kWFine + 4) * 4);
-
-    const int nranges = (n + kFWin - 1) / kFWin;
+    IdxT *idx_w = reinterpret_cast<IdxT *>(wbuf + wave * kWaveBytes + kRCap * 8 + (kWFine + 4) * 4);
+    unsigned *ghist = MULTI ? a.ghist + (int64_t)blockIdx.x * NB : nullptr;
 
     for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
         const double period = a.periods[p];
@@ -907,12 +924,14 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         const bool safe = period_is_safe(period, t_safe);
         double total = 0.0;
 
+        int consumed = 0, r_base = 0, b0 = 0, b1 = NB, slice_n = n, nranges = 0;
+        if constexpr (!MULTI) {
         // ---- P1: exact phases, coarse histogram; bucket ids stay in registers --------------------
         // (the thread id goes through an opaque copy once per period: the <= 52 per-sample addresses and
         // bounds masks are loop-invariant, and hoisted out of the period loop they would all be spilled)
         int tid = tid0;
         asm volatile("" : "+v"(tid));
-        for (int b = tid; b < kNB + 64; b += kBlock) hist[b] = 0u;
+        for (int b = tid; b < NB + 64; b += kBlock) hist[b] = 0u;
         if (tid < 16) defer[tid] = tid == 15 ? (unsigned)kWaves : 0u;   // [15]: next range to hand out (P3a)
         __syncthreads();
         // Samples past the end (the last trip of a thread) go to one of 64 dummy buckets behind the
@@ -946,7 +965,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 for (int u = 0; u < 4; ++u) {
                     if (k0 + u < KMAX) {
                         const int i = (k0 + u) * kBlock + tid;
-                        const int b = i < n ? coarse_of(phi[u]) : kNB + lane;
+                        const int b = i < n ? coarse_of<NB>(phi[u]) : NB + lane;
                         atomicAdd(&hist[b], 1u);
                         pk[(k0 + u) >> 1] |= (unsigned)b << (((k0 + u) & 1) * 16);
                     }
@@ -955,7 +974,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             }
         }
         __syncthreads();
-        scan_buckets<kNB>(hist, wave_tot);   // hist[b] = first sorted position of bucket b
+        scan_buckets<NB>(hist, wave_tot);   // hist[b] = first sorted position of bucket b
 
         // ---- P2: the permutation, grouped by coarse bucket ----------------------------------------
 #pragma unroll
@@ -973,35 +992,178 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 for (int u = 0; u < 4; ++u) {
                     if (k0 + u < KMAX) {
                         const int i = (k0 + u) * kBlock + tid;
-                        order[i < n ? pos[u] : (unsigned)(n + lane)] = (unsigned short)i;
+                        order[i < n ? pos[u] : (unsigned)(n + lane)] = (IdxT)i;
                     }
                 }
             }
         }
+        } else {
+        // ---- P1 (several slices): histogram of ALL samples, then the grouping by coarse bucket in global
+        // scratch, once per period -------------------------------------------------------------------------
+        const int tid = tid0;
+        for (int b = tid; b < NB; b += kBlock) hist[b] = 0u;
+        __syncthreads();
+        // (eight coalesced loads per trip, the next trip's requested before this one is folded)
+        auto load8 = [&](int i0, double (&v)[8]) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * kBlock;
+                v[u] = a.t[i < n ? i : n - 1];
+            }
+        };
+        auto fold8 = [&](const double (&v)[8], double (&phi)[8]) {
+            double a4[4], p4[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a4[u] = v[4 * h + u];
+                phases4(a4, period, y, safe, p4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) phi[4 * h + u] = p4[u];
+            }
+        };
+        {
+            double nx[8];
+            load8(tid, nx);
+            for (int i0 = tid; i0 < n; i0 += 8 * kBlock) {
+                double tv[8], phi[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tv[u] = nx[u];
+                if (i0 + 8 * kBlock < n) load8(i0 + 8 * kBlock, nx);
+                fold8(tv, phi);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + u * kBlock < n) atomicAdd(&hist[coarse_of<NB>(phi[u])], 1u);
+            }
+        }
+        __syncthreads();
+        scan_buckets<NB>(hist, wave_tot);   // hist[b] = first sorted position of bucket b
+        for (int b = tid; b < NB; b += kBlock) ghist[b] = hist[b];
+        __syncthreads();
+        }
+        const int tid = tid0;
+        do {   // one trip per slice
+        if constexpr (MULTI) {
+            __syncthreads();
+            for (int b = tid; b < NB; b += kBlock) hist[b] = ghist[b];
+            __syncthreads();
+            auto end_of = [&](int b) -> int { return b + 1 < NB ? (int)hist[b + 1] : n; };
+            {   // first bucket that still has unconsumed samples
+                int l = 0, h = NB - 1;
+                while (l < h) {
+                    const int mid = (l + h) >> 1;
+                    if (end_of(mid) > consumed) h = mid; else l = mid + 1;
+                }
+                b0 = l;
+            }
+            const int first_cnt = end_of(b0) - consumed;
+            if (first_cnt > FL<IdxT>::capacity) {
+                // a single coarse bucket larger than a slice (clustered phases): sorted in global scratch
+                const int cnt = first_cnt;
+                int P = 2;
+                while (P < cnt) P <<= 1;
+                __syncthreads();
+                // collect the bucket's samples by folding everything once more
+                if (tid == 0) s_fill = 0u;
+                __syncthreads();
+                for (int i = tid; i < n; i += kBlock) {
+                    const double phi = fast_phase(a.t[i], period, y, safe);
+                    if (coarse_of<NB>(phi) == b0) {
+                        const unsigned slot = atomicAdd(&s_fill, 1u);
+                        gk[slot] = phase_key(phi);
+                        gi[slot] = (unsigned)i;
+                    }
+                }
+                for (int sI = cnt + tid; sI < P; sI += kBlock) {
+                    gk[sI] = ~0ull;
+                    gi[sI] = ~0u;
+                }
+                __syncthreads();
+                bitonic_sort<unsigned>(gk, gi, P);
+                total += segment_sum(gk, gi, cnt, a.m);
+                if (tid == 0) {
+                    rsum[(int64_t)r_base * 4 + 0] = __longlong_as_double((long long)gk[0]);
+                    rsum[(int64_t)r_base * 4 + 1] = a.m[gi[0]];
+                    rsum[(int64_t)r_base * 4 + 2] = __longlong_as_double((long long)gk[cnt - 1]);
+                    rsum[(int64_t)r_base * 4 + 3] = a.m[gi[cnt - 1]];
+                    rcnt[r_base] = cnt;
+                    rlen[r_base] = 0.0;
+                }
+                __syncthreads();
+                r_base += 1;
+                consumed += cnt;
+                continue;
+            }
+            {   // as many consecutive buckets as fit the slice
+                int l = b0 + 1, h = NB;
+                while (l < h) {
+                    const int mid = (l + h + 1) >> 1;
+                    if (end_of(mid - 1) - consumed <= FL<IdxT>::capacity) l = mid; else h = mid - 1;
+                }
+                b1 = l;
+            }
+            slice_n = end_of(b1 - 1) - consumed;
+            __syncthreads();   // every thread has read what it needs from the start offsets
+            if (tid < 16) defer[tid] = tid == 15 ? (unsigned)kWaves : 0u;
+            {
+                // hist[b] still holds the START of every bucket: fold all samples again and keep this slice's.
+                // (Grouping all samples once in global scratch instead costs more up to ~10 slices: a random
+                // 4-byte store to global memory runs at 1.05e11/s, 2.6x slower than a random load.)
+                double nx[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = tid + u * kBlock;
+                    nx[u] = a.t[i < n ? i : n - 1];
+                }
+                for (int i0 = tid; i0 < n; i0 += 8 * kBlock) {
+                    double tv[8], phi[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) tv[u] = nx[u];
+                    if (i0 + 8 * kBlock < n) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + (8 + u) * kBlock;
+                            nx[u] = a.t[i < n ? i : n - 1];
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        double a4[4], p4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) a4[u] = tv[4 * h + u];
+                        phases4(a4, period, y, safe, p4);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) phi[4 * h + u] = p4[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * kBlock;
+                        const int b = coarse_of<NB>(phi[u]);
+                        if (i < n && b >= b0 && b < b1) order[atomicAdd(&hist[b], 1u) - (unsigned)consumed] = (IdxT)i;
+                    }
+                }
+            }
+        }
+        nranges = (slice_n + kFWin - 1) / kFWin;
         __syncthreads();   // hist[b] = END position of bucket b
         // range r starts at the first bucket whose start position is >= r * kWin
         for (int r = tid; r <= nranges; r += kBlock) {
-            int b = 0, s0 = 0;
+            int b = b0, s0 = 0;
             if (r > 0) {
-                const unsigned x = (unsigned)r * kFWin;
-                int l = 0, h = kNB;   // smallest j with end(j) >= x, kNB if none
+                const unsigned x = (unsigned)consumed + (unsigned)r * kFWin;
+                int l = b0, h = b1;   // smallest j in [b0, b1) with end(j) >= x, b1 if none
                 while (l < h) {
                     const int mid = (l + h) >> 1;
                     if (hist[mid] >= x) h = mid; else l = mid + 1;
                 }
-                b = l < kNB ? l + 1 : kNB;
-                s0 = l < kNB ? (int)hist[l] : n;
+                b = l < b1 ? l + 1 : b1;
+                s0 = l < b1 ? (int)hist[l] - consumed : slice_n;
             }
             bndb[r] = (unsigned short)b;
             bnds[r] = (unsigned short)s0;
         }
         __syncthreads();   // (the histogram is dead from here on: its LDS becomes wave scratch)
 
-#ifdef PDC_SL_ONLY_P12   // timing experiment: histogram + scatter + range table only
-        if (tid == 0) a.ell[p] = (double)bnds[nranges];
-        __syncthreads();
-        continue;
-#endif
         // ---- P3a: wave-autonomous ranges -------------------------------------------------------------
         // records of range r (requested one range ahead of their use)
         int n_cnt = 0, n_slo = 0, n_lob = 0, n_hib = 0;
@@ -1038,7 +1200,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             if (lane == 0) ticket = atomicAdd(&defer[15], 1u);
             if (cnt <= 0 || cnt > kFCap) {
                 if (lane == 0) {
-                    if (cnt <= 0) rcnt[r] = 0;
+                    if (cnt <= 0) rcnt[r_base + r] = 0;
                     else atomicOr(&defer[r >> 5], 1u << (r & 31));
                 }
                 r_next = __builtin_amdgcn_readfirstlane((int)ticket);
@@ -1053,7 +1215,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             // (the scale only has to be positive and keep the map inside [0, kFine): a float reciprocal
             // is plenty; indices are clamped anyway)
             const double fsc = (double)((float)(kFine - 1) * __builtin_amdgcn_rcpf((float)(hi_b - lo_b)));
-            const double fmul = (double)kNB * fsc, fadd = -(double)lo_b * fsc;
+            const double fmul = (double)NB * fsc, fadd = -(double)lo_b * fsc;
             reinterpret_cast<uint4 *>(fine32)[lane] = make_uint4(0u, 0u, 0u, 0u);
             if (lane < 4) fine32[kFine / 4 + lane] = 0u;
             wave_sync();
@@ -1134,7 +1296,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 ec[e] = live[e] ? ec[e] - eb0[e] : 0u;
                 park[e] = live[e] ? eb0[e] + er[e] : (unsigned)(lane + e * 64);
                 keys_w[park[e]] = EK(e);
-                idx_w[park[e]] = (unsigned short)ei[e];
+                idx_w[park[e]] = (IdxT)ei[e];
             }
             wave_sync();
             unsigned before[kRPer];
@@ -1205,12 +1367,13 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             // result independent of timing
             inside = wave_sum_fixed(inside);
             if (lane == 0) {
-                rsum[(int64_t)r * 4 + 0] = sphi[0];
-                rsum[(int64_t)r * 4 + 1] = sm[0];
-                rsum[(int64_t)r * 4 + 2] = last_phi;
-                rsum[(int64_t)r * 4 + 3] = last_m;
-                rcnt[r] = cnt;
-                rlen[r] = inside;
+                const int64_t g = r_base + r;
+                rsum[g * 4 + 0] = sphi[0];
+                rsum[g * 4 + 1] = sm[0];
+                rsum[g * 4 + 2] = last_phi;
+                rsum[g * 4 + 3] = last_m;
+                rcnt[g] = cnt;
+                rlen[g] = inside;
             }
             wave_sync();
         };
@@ -1234,16 +1397,16 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 if (cnt <= kDCap) {
                     for (int s = tid; s < P; s += kBlock) {
                         if (s < cnt) {
-                            const unsigned short id = order[s_lo + s];
+                            const IdxT id = order[s_lo + s];
                             bkeys[s] = phase_key(fast_phase(a.t[id], period, y, safe));
                             bidx[s] = id;
                         } else {
                             bkeys[s] = ~0ull;
-                            bidx[s] = (unsigned short)~0u;
+                            bidx[s] = (IdxT)~0u;
                         }
                     }
                     __syncthreads();
-                    bitonic_sort<unsigned short>(bkeys, bidx, P);
+                    bitonic_sort<IdxT>(bkeys, bidx, P);
                     total += segment_sum(bkeys, bidx, cnt, a.m);
                     p0 = __longlong_as_double((long long)bkeys[0]);
                     m0 = a.m[bidx[0]];
@@ -1269,20 +1432,25 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                     m1 = a.m[gi[cnt - 1]];
                 }
                 if (tid == 0) {
-                    rsum[(int64_t)r * 4 + 0] = p0;
-                    rsum[(int64_t)r * 4 + 1] = m0;
-                    rsum[(int64_t)r * 4 + 2] = p1;
-                    rsum[(int64_t)r * 4 + 3] = m1;
-                    rcnt[r] = cnt;
-                    rlen[r] = 0.0;   // (its segments were added to `total` by the whole workgroup, in a fixed order)
+                    const int64_t g = r_base + r;
+                    rsum[g * 4 + 0] = p0;
+                    rsum[g * 4 + 1] = m0;
+                    rsum[g * 4 + 2] = p1;
+                    rsum[g * 4 + 3] = m1;
+                    rcnt[g] = cnt;
+                    rlen[g] = 0.0;   // (its segments were added to `total` by the whole workgroup, in a fixed order)
                 }
                 __syncthreads();
             }
         }
+        r_base += nranges;
+        consumed += slice_n;
+        } while (MULTI && consumed < n);
+        const int nr_all = r_base;
         __syncthreads();  // every summary of this period (global, this workgroup's) is visible
 
         // ---- P3c: links between consecutive non-empty ranges + the closing segment ----------------
-        for (int r = tid; r < nranges; r += kBlock) {
+        for (int r = tid; r < nr_all; r += kBlock) {
             if (rcnt[r] > 0) {
                 total += rlen[r];
                 int q = r - 1;
@@ -1292,12 +1460,12 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                                    rsum[(int64_t)r * 4 + 0] - rsum[(int64_t)q * 4 + 2]);
             }
         }
-        if (tid == 0 && nranges > 0) {
-            int f0 = 0, l0 = nranges - 1;
-            while (f0 < nranges && rcnt[f0] == 0) ++f0;
+        if (tid == 0 && nr_all > 0) {
+            int f0 = 0, l0 = nr_all - 1;
+            while (f0 < nr_all && rcnt[f0] == 0) ++f0;
             while (l0 >= 0 && rcnt[l0] == 0) --l0;
             // closing segment of np.roll(-1): first minus last, no phase wrap (phase.py:50)
-            if (f0 < nranges && l0 >= 0)
+            if (f0 < nr_all && l0 >= 0)
                 total += hypot(rsum[(int64_t)f0 * 4 + 1] - rsum[(int64_t)l0 * 4 + 3],
                                rsum[(int64_t)f0 * 4 + 0] - rsum[(int64_t)l0 * 4 + 2]);
         }
@@ -1355,16 +1523,17 @@ int64_t scratch_bytes(int64_t n, int64_t n_periods, int64_t partition) {
 }
 
 // AoS (t, m) records + flags of the fast path, placed behind the general scratch
-int64_t fast_table_bytes(int64_t n) { return n <= fast::kCapacity ? ((n * 16 + 255) & ~(int64_t)255) + 256 : 0; }
+int64_t fast_table_bytes(int64_t n) { return ((n * 16 + 255) & ~(int64_t)255) + 256; }
 
-template <int KMAX>
+template <int KMAX, typename IdxT = unsigned short, int NB = fast::kNB, bool MULTI = false>
 int launch_fast(const fast::FastArgs &a, int64_t grid, hipStream_t st) {
-    const size_t lds = (size_t)fast::kFixed + (size_t)((a.n + 64 + 7) & ~(int64_t)7) * 2;
-    static const hipError_t attr = hipFuncSetAttribute((const void *)fast::sl_fast_kernel<KMAX>,
+    const int64_t slice = MULTI ? fast::FL<IdxT>::capacity : a.n;
+    const size_t lds = (size_t)fast::FL<IdxT>::fixed + (size_t)((slice + 64 + 7) & ~(int64_t)7) * sizeof(IdxT);
+    static const hipError_t attr = hipFuncSetAttribute((const void *)fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                                        fast::kLdsTotalDyn);
     PDC_HIP(attr);
-    hipLaunchKernelGGL((fast::sl_fast_kernel<KMAX>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     return PDC_OK;
 }
 
@@ -1403,11 +1572,14 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
     a.rsum = reinterpret_cast<double *>(a.gkeys + grid * a.n_pad);
     a.gidx = reinterpret_cast<unsigned *>(a.rsum + grid * a.nr_pad * 4);
     a.rcnt = reinterpret_cast<int *>(a.gidx + grid * a.n_pad);
-    a.gorder = reinterpret_cast<unsigned *>(a.rcnt + grid * a.nr_pad);
+    double *rlen = reinterpret_cast<double *>(a.rcnt + grid * a.nr_pad);   // [grid][nr_pad] (fast kernels)
+    a.gorder = reinterpret_cast<unsigned *>(rlen + grid * a.nr_pad);
     a.ghist = a.gorder + (may_need_partition(n) ? grid * a.n_pad : 0);
     hipStream_t st = (hipStream_t)stream;
     static const bool general_only = [] { const char *e = getenv("PDC_SL_GENERAL"); return e && e[0] == '1'; }();
-    if (n >= 1 && n <= fast::kCapacity && !general_only) {
+    // beyond ~13 slices the per-slice fold of the fast kernel costs more than the general kernel's one-off
+    // grouping in global scratch (x 2048 periods: N = 3e5 21.2 against 22.2 ms, N = 4.5e5 44.5 against 35.5 ms)
+    if (n >= 1 && !general_only && n <= 13 * (int64_t)fast::FL<unsigned>::capacity) {
         fast::FastArgs f;
         f.t = d_t;
         f.m = d_m;
@@ -1419,16 +1591,19 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
         f.gidx = a.gidx;
         f.rsum = a.rsum;
         f.rcnt = a.rcnt;
-        f.rlen = reinterpret_cast<double *>(static_cast<char *>(work) + grid * (a.n_pad * 12 + a.nr_pad * 36));
+        f.rlen = rlen;
         f.n_pad = a.n_pad;
         f.nr_pad = a.nr_pad;
-        char *table = static_cast<char *>(work) + scratch_bytes(n, n_periods, 0);
+        f.ghist = a.ghist;
+        const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
+        char *table = static_cast<char *>(work) + scratch_bytes(n, n_periods, partition);
         f.rec = reinterpret_cast<const fast::rec_t *>(table);
         f.flags = reinterpret_cast<const unsigned *>(table + ((n * 16 + 255) & ~(int64_t)255));
         hipLaunchKernelGGL(fast::sl_prep_kernel, dim3(1), dim3(kBlock), 0, st, d_t, d_m, (int)n,
                            reinterpret_cast<fast::rec_t *>(table), const_cast<unsigned *>(f.flags));
         const int k = (int)((n + kBlock - 1) / kBlock);
-        if (k <= 8) PDC_TRY(launch_fast<8>(f, grid, st));
+        if (n > fast::kCapacity) PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true>(f, grid, st)));
+        else if (k <= 8) PDC_TRY(launch_fast<8>(f, grid, st));
         else if (k <= 20) PDC_TRY(launch_fast<20>(f, grid, st));
         else if (k <= 36) PDC_TRY(launch_fast<36>(f, grid, st));
         else PDC_TRY(launch_fast<fast::kKMax>(f, grid, st));

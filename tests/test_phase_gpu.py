@@ -136,14 +136,15 @@ def test_stringlength_clusters_take_the_scratch_path():
 
 
 def test_stringlength_large_n_runs_in_phase_slices():
-    # more samples than one LDS slice holds (50480 16-bit / 23192 32-bit indices): the kernel groups
+    # more samples than one LDS slice holds (52112 with 16-bit indices): up to 13 slices of ~24k the fast
+    # kernel folds all samples again per slice and keeps that slice's; beyond, the general kernel groups
     # the samples by coarse bucket once per period in global scratch and sorts slice after slice
-    t6, y6 = synth(60_000, 78)                              # 16-bit indices, two slices
+    t6, y6 = synth(60_000, 78)                              # three slices
     m6 = so.stringlength_scale(y6)
     p6 = np.array([0.9, 13.7, 4000.0])
     np.testing.assert_allclose(_cabi.stringlength_scan(t6, m6, p6),
                                co.stringlength_scan(t6, m6, p6), rtol=RTOL)
-    t, y = synth(70_000, 77)                                # 32-bit indices, four slices
+    t, y = synth(70_000, 77)
     m = so.stringlength_scale(y)
     periods = np.array([0.9, 13.7, 333.3, 9000.0])
     np.testing.assert_allclose(_cabi.stringlength_scan(t, m, periods),
@@ -153,6 +154,13 @@ def test_stringlength_large_n_runs_in_phase_slices():
     pe = np.array([1.0, 2.5, 7.3])
     np.testing.assert_allclose(_cabi.stringlength_scan(te, me, pe),
                                co.stringlength_scan(te, me, pe), rtol=RTOL)
+    for n_big, seed in ((311_000, 79), (330_000, 80)):      # last size of the fast kernel's range / general kernel
+        tb, yb = synth(n_big, seed)
+        mb = so.stringlength_scale(yb)
+        pb = np.array([0.7, 13.7, 2.0, 51_234.5])
+        got = _cabi.stringlength_scan(tb, mb, pb)
+        np.testing.assert_allclose(got, co.stringlength_scan(tb, mb, pb), rtol=RTOL)
+        assert np.array_equal(got, _cabi.stringlength_scan(tb, mb, pb))
 
 
 def test_stringlength_edges():

@@ -15,7 +15,12 @@ sp = C.c_void_p()
 _cabi.check(lib.pdc_stream_create(0, C.byref(sp)))
 tm = bench.EventTimer(lib, _cabi, 0, sp.value)
 DB = _cabi.DeviceBuffer
-for n, n_per in ((500, 100_000), (2000, 100_000), (2000, 1000), (10_000, 20_000), (25_000, 100_000), (50_000, 100_000)):
+SHAPES = ((500, 100_000), (2000, 100_000), (2000, 1000), (10_000, 20_000), (25_000, 100_000), (50_000, 100_000))
+if os.environ.get("LARGE"):
+    SHAPES = ((70_000, 20_000), (200_000, 2048), (200_000, 20_000), (1_000_000, 256), (1_000_000, 2048))
+if os.environ.get("SHAPES"):      # SHAPES="300000x2048,600000x1024"
+    SHAPES = tuple(tuple(int(v) for v in s.split("x")) for s in os.environ["SHAPES"].split(","))
+for n, n_per in SHAPES:
     t, y, _ = bench.synth_curve(n, 5, period=13.7)
     m = (y - y.max()) / (2 * (y.max() - y.min())) + 0.25
     df = 0.1 / (t[-1] - t[0])
