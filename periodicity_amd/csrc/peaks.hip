@@ -74,12 +74,27 @@ __global__ __launch_bounds__(kBlock) void highest_peak_kernel(const double *powe
 // one left of the peak and the first one from the peak rightwards (np.diff(np.signbit(..)), core.py:362).
 // Equal heights / prominences rank the lower bin first (numpy's argsort leaves that order open).
 //
-// One workgroup per spectrum.  The walks are what could cost O(nf) per peak: per-block minima and
-// maxima in LDS let a walk hop over every block that cannot stop it (a block holding a NaN never
-// hops: a NaN stops a walk, as x[i] <= x[peak] is false).
+// One workgroup per spectrum.  Only k peaks are wanted, and walking every maximum (6300 per 5e4-bin C3
+// row; what the first version did, 7.9 ms for the C3 batch, 85 % of it in wave-iterations as long as
+// their longest walk) is not needed to rank them:
+//   * prominence <= height - (lowest sample of the row): a maximum with  height - lowest < tau  cannot
+//     be among the k most prominent once k prominences >= tau are known;
+//   * ranked by height, only the k winners need a prominence at all.
+// So the row is swept once through LDS tiles (maxima found and counted; a candidate list in LDS keeps the
+// M highest seen so far: M = k by height, 32 by prominence), the candidates are walked, and - by
+// prominence - a second sweep collects the few maxima with  height - lowest >= tau  (tiles whose block
+// maxima rule that out are not even staged).  Per-block minima and maxima in LDS let a walk hop over
+// every block that cannot stop it (a block holding a NaN never hops: a NaN stops a walk, as
+// x[i] <= x[peak] is false).  Ranking is by successive "best entry strictly after the previous winner" in
+// the total order (key descending, bin ascending), so a maximum collected twice is reported once.
 constexpr int kPkBlock = 256;
 constexpr int kPkMaxBlocks = 4096;   // LDS: two doubles per block
 constexpr int kPkMaxK = 8;
+constexpr int kPkPre = 16;           // by prominence: the first walks go to the 16 highest maxima
+constexpr int kPkChunk = 1024;       // bins per sweep step
+constexpr int kPkFusedShift = 8;     // 256-bin blocks = one wave's stretch of a chunk: extrema come with the sweep
+static_assert(kPkChunk / kPkBlock * 64 == 1 << kPkFusedShift, "a wave's stretch is one block");
+constexpr int kPkCap = 1024;         // candidate slots in LDS (24 B each): a chunk adds at most kPkChunk / 2
 
 struct PeakArgs {
     const double *power;
@@ -90,29 +105,41 @@ struct PeakArgs {
     double *height, *prom;
 };
 
-struct Cand {
-    double key;
-    long long idx;
-};
+// minimum over the wave, valid in lane 63: row shifts and row broadcasts on both halves of the double (DPP),
+// no LDS traffic (lanes without a source keep their own value)
+__device__ __forceinline__ double wave_min_to_lane63(double v) {
+#define PDC_PK_STEP(ctrl)                                                                                    \
+    {                                                                                                        \
+        const long long b = __double_as_longlong(v);                                                         \
+        const int lo = __builtin_amdgcn_update_dpp((int)b, (int)b, ctrl, 0xf, 0xf, false);                   \
+        const int hi = __builtin_amdgcn_update_dpp((int)(b >> 32), (int)(b >> 32), ctrl, 0xf, 0xf, false);   \
+        const double o = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);                         \
+        v = o < v ? o : v;                                                                                   \
+    }
+    PDC_PK_STEP(0x111) PDC_PK_STEP(0x112) PDC_PK_STEP(0x114) PDC_PK_STEP(0x118) PDC_PK_STEP(0x142) PDC_PK_STEP(0x143)
+#undef PDC_PK_STEP
+    return v;
+}
 
 __device__ __forceinline__ bool cand_before(double ka, long long ia, double kb, long long ib) {
     return ib < 0 || (ia >= 0 && (ka > kb || (ka == kb && ia < ib)));
 }
 
-template <int K>
 __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *bmin = reinterpret_cast<double *>(lds_raw);   // [nblk]
     double *bmax = bmin + a.nblk;                         // [nblk]
-    double *tile = bmax + a.nblk + 1;                     // [-1 .. a.tile]: the part of the spectrum being scanned + halo
-    int *plist = reinterpret_cast<int *>(tile + a.tile + 1);  // [a.tile / 2 + 2] peaks of the tile (bin - t0)
-    __shared__ int s_npk;
+    double *ch = bmax + a.nblk;                           // [kPkCap] candidates: height,
+    double *cp = ch + kPkCap;                             //          prominence (NaN: not walked yet),
+    long long *ci = reinterpret_cast<long long *>(cp + kPkCap);   //  bin
+    __shared__ int s_ncand;
+    __shared__ double s_thr;
     __shared__ double red_k[kPkBlock / 64];
     __shared__ long long red_i[kPkBlock / 64];
-    __shared__ int red_t[kPkBlock / 64];
+    __shared__ int red_e[kPkBlock / 64];
     __shared__ long long s_count[kPkBlock / 64];
-    __shared__ double win_key[K], win_h[K], win_p[K];
-    __shared__ long long win_idx[K];
+    __shared__ double win_key[kPkPre], win_h[kPkPre], win_p[kPkPre];
+    __shared__ long long win_idx[kPkPre];
     __shared__ long long s_found;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *x = a.power + (int64_t)blockIdx.x * a.nf;
@@ -121,8 +148,9 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
     const int64_t blk = (int64_t)1 << sh;
     const double inf = __builtin_inf();
 
-    // ---- A: per-block minimum / maximum (a wave per block, coalesced) -----------------------------
-    for (int64_t b = wave; b < a.nblk; b += kPkBlock / 64) {
+    // ---- A: per-block minimum / maximum (a wave per block, coalesced); with 256-bin blocks (rows up to
+    // 1M bins) the first sweep below does this on its way
+    for (int64_t b = wave; b < a.nblk && sh != kPkFusedShift; b += kPkBlock / 64) {
         double mn = inf, mx = -inf;
         bool nan = false;
         const int64_t e = (b + 1) * blk < nf ? (b + 1) * blk : nf;
@@ -143,178 +171,281 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
             bmax[b] = mx;
         }
     }
+    if (tid == 0) {
+        s_ncand = 0;
+        s_thr = -inf;
+    }
     __syncthreads();
-
-    // The spectrum is scanned tile by tile through LDS (tiles are whole blocks): a dependent chain of
-    // global loads costs an L2 round trip per step once 32 waves of walkers thrash the 32 KB L1, an LDS
-    // read ~20x less, and nearly every step of nearly every walk stays inside the tile of its peak.
-    int64_t t0 = 0, t1 = 0;
-
-    // lowest sample met walking from `from` (a bin of the current tile) in direction dir (+1 / -1) while
-    // x[i] <= h (scipy's loop).  Blocks never straddle tiles, so every stepping loop reads either LDS
-    // or global memory, never a per-lane mix.
-    auto walk = [&](int64_t from, int dir, double h, auto start_in_tile) -> double {
-        double low = h;
-        int64_t i = from;
-        // inside the starting block (in the tile, except for a flat top that ran past the tile's end)
-        const int64_t b0 = from >> sh;
-        const int64_t edge = dir > 0 ? (((b0 + 1) << sh) < nf ? ((b0 + 1) << sh) : nf) : (b0 << sh) - 1;
-        while (i != edge) {
-            const double v = decltype(start_in_tile)::value ? tile[i - t0] : x[i];
-            if (!(v <= h)) return low;
-            low = v < low ? v : low;
-            i += dir;
+    // Lowest sample met walking from bin `from` in direction dir (+1 / -1) while x[i] <= h (scipy's loop).
+    // Sixteen lanes walk together (arguments uniform over the group): 64 bins of the first block per step
+    // (four loads per lane in flight), then 16 blocks per step over the block extrema in LDS - whole
+    // blocks that cannot stop the walk are hopped over -, then the block that does stop it.  A step
+    // costs one memory latency instead of one per bin: the highest peak of a 5e4-bin row (900 single
+    // steps) takes ~12.
+    const int gl = lane & 15, gbase = lane & 48;
+    auto group_min = [&](double m) __attribute__((always_inline)) -> double {
+        for (int o = 8; o > 0; o >>= 1) {
+            const double om = __shfl_xor(m, o, 64);
+            m = om < m ? om : m;
         }
-        // whole blocks that cannot stop the walk
+        return m;
+    };
+    auto group_ballot = [&](bool p) __attribute__((always_inline)) -> unsigned {
+        return (unsigned)((__ballot(p) >> gbase) & 0xffffull);
+    };
+    auto walk = [&](int64_t from, int dir, double h) __attribute__((always_inline)) -> double {
+        double low = h;
+        // `count` bins from `start` on in direction dir; true when the walk ended among them
+        auto run = [&](int64_t start, int64_t count) __attribute__((always_inline)) -> bool {
+            for (int64_t o = 0; o < count; o += 64) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t k = o + 16 * u + gl;
+                    v[u] = k < count ? x[start + dir * k] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool valid = o + 16 * u + gl < count;
+                    const unsigned sb = group_ballot(valid && !(v[u] <= h));
+                    const int first = sb ? __builtin_ctz(sb) : 16;
+                    const double m = group_min(valid && gl < first ? v[u] : inf);
+                    low = m < low ? m : low;
+                    if (sb) return true;
+                }
+            }
+            return false;
+        };
+        const int64_t b0 = from >> sh;
+        const int64_t b0_end = ((b0 + 1) << sh) < nf ? ((b0 + 1) << sh) : nf;
+        if (run(from, dir > 0 ? b0_end - from : from - (b0 << sh) + 1)) return low;
         int64_t b = b0 + dir;
-        while (b >= 0 && b < a.nblk && bmax[b] <= h) {
-            low = bmin[b] < low ? bmin[b] : low;
-            b += dir;
+        for (;;) {
+            const int64_t bb = b + dir * gl;
+            const bool pass = bb >= 0 && bb < a.nblk && bmax[bb] <= h;
+            const unsigned fb = group_ballot(!pass);
+            const int first = fb ? __builtin_ctz(fb) : 16;
+            const double m = group_min(gl < first ? bmin[bb] : inf);   // (the lanes below `first` pass: in range)
+            low = m < low ? m : low;
+            if (fb) {
+                b += dir * first;
+                break;
+            }
+            b += 16 * dir;
         }
         if (b < 0 || b >= a.nblk) return low;   // reached the border of the signal
-        i = dir > 0 ? b << sh : (((b + 1) << sh) < nf ? ((b + 1) << sh) : nf) - 1;
-        if (i >= t0 && i < t1) {
-            for (;;) {                           // this block holds a sample > h (or a NaN): the walk ends in it
-                const double v = tile[i - t0];
-                if (!(v <= h)) return low;
-                low = v < low ? v : low;
-                i += dir;
+        const int64_t b_end = ((b + 1) << sh) < nf ? ((b + 1) << sh) : nf;
+        run(dir > 0 ? b << sh : b_end - 1, b_end - (b << sh));   // this block holds a sample > h (or a NaN)
+        return low;
+    };
+    // prominences of the candidates that have none yet: one group of 16 lanes per candidate
+    auto walk_candidates = [&]() __attribute__((always_inline)) {
+        const int n = s_ncand;
+        for (int e = tid >> 4; e < n; e += kPkBlock / 16) {
+            if (cp[e] == cp[e]) continue;
+            const double v = ch[e];
+            const int64_t at = ci[e];
+            const double lo = walk(at, -1, v), hi = walk(at, +1, v);
+            if (gl == 0) cp[e] = v - (lo > hi ? lo : hi);
+        }
+        __syncthreads();
+    };
+    // The m best candidates (by height or by prominence; ties: lower bin first; the same bin only once)
+    // into win_*[0 .. m), by m rounds of "best entry strictly after the previous winner"; the list is then
+    // cut down to those.  Returns how many there are.
+    auto rank_candidates = [&](int m, bool by_prom) __attribute__((always_inline)) -> int {
+        const int n = s_ncand;
+        double pk = inf;          // previous winner (key, bin): everything is "after" (+inf, -1)
+        long long pidx = -1;
+        int found = 0;
+        for (int round = 0; round < m; ++round) {
+            double wk = 0.0;
+            long long wi = -1;
+            int we = -1;
+            for (int e = tid; e < n; e += kPkBlock) {
+                const double key = by_prom ? cp[e] : ch[e];
+                const long long bin = ci[e];
+                const bool after = round == 0 || key < pk || (key == pk && bin > pidx);
+                if (after && cand_before(key, bin, wk, wi)) {
+                    wk = key;
+                    wi = bin;
+                    we = e;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ok = __shfl_down(wk, o, 64);
+                const long long oi = __shfl_down(wi, o, 64);
+                const int oe = __shfl_down(we, o, 64);
+                if (cand_before(ok, oi, wk, wi)) {
+                    wk = ok;
+                    wi = oi;
+                    we = oe;
+                }
+            }
+            __syncthreads();
+            if (lane == 0) {
+                red_k[wave] = wk;
+                red_i[wave] = wi;
+                red_e[wave] = we;
+            }
+            __syncthreads();
+            wk = red_k[0];
+            wi = red_i[0];
+            we = red_e[0];
+            for (int w = 1; w < kPkBlock / 64; ++w)
+                if (cand_before(red_k[w], red_i[w], wk, wi)) {
+                    wk = red_k[w];
+                    wi = red_i[w];
+                    we = red_e[w];
+                }
+            if (wi < 0) break;   // (workgroup-uniform) no entry left
+            if (tid == 0) {
+                win_key[round] = wk;
+                win_idx[round] = wi;
+                win_h[round] = ch[we];
+                win_p[round] = cp[we];
+            }
+            pk = wk;
+            pidx = wi;
+            ++found;
+        }
+        __syncthreads();
+        for (int e = tid; e < found; e += kPkBlock) {
+            ci[e] = win_idx[e];
+            ch[e] = win_h[e];
+            cp[e] = win_p[e];
+        }
+        if (tid == 0) s_ncand = found;
+        __syncthreads();
+        return found;
+    };
+    // One sweep over the row in chunks of 1024 bins, lanes = consecutive bins, straight from global memory
+    // (neighbours by lane shuffles).  FIRST: every maximum is counted; those with height >= s_thr are
+    // collected, and whenever the list is half full it is cut down to the m highest (s_thr = the m-th).
+    // Otherwise (by prominence, second sweep): the maxima with height - row_min >= s_thr are collected
+    // (s_thr = tau), walked and ranked when the list fills up (tau rises to the k-th prominence); chunks
+    // whose block maxima rule out a candidate are not read.
+    long long mine = 0;
+    double row_min = inf;
+    auto sweep = [&](auto first_tag, int m) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const double sub = FIRST ? 0.0 : row_min;
+        const double nan = __builtin_nan("");
+        // a wave reads a stretch of 256 consecutive bins, 64 at a time, + the bin before and after:
+        // every neighbour is a lane shuffle away, and all loads of a chunk are in flight together - in the
+        // first sweep one chunk ahead of the one being examined
+        constexpr int kPer = kPkChunk / kPkBlock;
+        auto load = [&](int64_t c0, double (&v)[kPer], double &halo_lo, double &halo_hi) __attribute__((always_inline)) {
+            const int64_t w0 = c0 + (int64_t)wave * (64 * kPer);
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const int64_t i = w0 + j * 64 + lane;
+                v[j] = i < nf ? x[i] : nan;
+            }
+            halo_lo = (w0 >= 1 && w0 <= nf) ? x[w0 - 1] : nan;
+            halo_hi = w0 + 64 * kPer < nf ? x[w0 + 64 * kPer] : nan;
+        };
+        double v[kPer], halo_lo, halo_hi, vn[kPer], next_lo = nan, next_hi = nan;
+        if (FIRST) load(0, v, halo_lo, halo_hi);
+        for (int64_t c0 = 0; c0 < nf; c0 += kPkChunk) {
+            const int64_t c1 = c0 + kPkChunk < nf ? c0 + kPkChunk : nf;
+            if (FIRST) load(c0 + kPkChunk, vn, next_lo, next_hi);
+            __syncthreads();   // everyone is done with the previous chunk (and sees s_thr / s_ncand)
+            if (s_ncand > kPkCap / 2) {   // (workgroup-uniform) a chunk adds at most kPkChunk / 2 maxima
+                if (!FIRST) walk_candidates();
+                const int got = rank_candidates(m, !FIRST);
+                if (tid == 0 && got == m) s_thr = win_key[m - 1];
+                __syncthreads();
+            }
+            const double thr = s_thr;
+            if (!FIRST) {   // (workgroup-uniform) no block of this chunk reaches the threshold
+                double tmx = -inf;
+                for (int64_t b = c0 >> sh; b < ((c1 + blk - 1) >> sh); ++b) tmx = bmax[b] > tmx ? bmax[b] : tmx;
+                if (!(tmx - sub >= thr)) continue;
+            }
+            if (!FIRST) load(c0, v, halo_lo, halo_hi);
+            const int64_t w0 = c0 + (int64_t)wave * (64 * kPer);
+            if (FIRST && sh == kPkFusedShift && w0 < nf) {   // (wave-uniform) this wave's stretch is one block
+                double mn = inf, mx = -inf;
+                bool isnan = false;
+#pragma unroll
+                for (int j = 0; j < kPer; ++j) {
+                    const double q = v[j];
+                    isnan = isnan || (w0 + j * 64 + lane < nf && q != q);
+                    mn = q < mn ? q : mn;
+                    mx = q > mx ? q : mx;
+                }
+                mn = wave_min_to_lane63(mn);
+                mx = -wave_min_to_lane63(-mx);
+                if (__any(isnan)) mx = inf;
+                if (lane == 63) {
+                    bmin[w0 >> kPkFusedShift] = mn;
+                    bmax[w0 >> kPkFusedShift] = mx;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const int64_t i = w0 + j * 64 + lane;
+                double prev = __shfl_up(v[j], 1, 64), next = __shfl_down(v[j], 1, 64);
+                const double before = j == 0 ? halo_lo : __shfl(v[j > 0 ? j - 1 : 0], 63, 64);
+                const double behind = j == kPer - 1 ? halo_hi : __shfl(v[j < kPer - 1 ? j + 1 : j], 0, 64);
+                prev = lane == 0 ? before : prev;
+                next = lane == 63 ? behind : next;
+                // a maximum: strict rise, flat tops -> midpoint, edges and NaN never peaks
+                const double vv = v[j];
+                if (!(i >= 1 && i < nf - 1 && prev < vv)) continue;
+                if (!FIRST && !(vv - sub >= thr)) continue;
+                int64_t ahead = i + 1;
+                if (!(next < vv)) {
+                    if (!(next == vv)) continue;
+                    while (ahead < nf - 1 && x[ahead] == vv) ++ahead;   // a flat top: global reads from here on
+                    if (!(x[ahead] < vv)) continue;
+                }
+                if (FIRST) ++mine;
+                if (FIRST && !(vv >= thr)) continue;
+                const int slot = atomicAdd(&s_ncand, 1);
+                ci[slot] = (i + ahead - 1) / 2;
+                ch[slot] = vv;
+                cp[slot] = nan;
+            }
+            if (FIRST) {
+#pragma unroll
+                for (int j = 0; j < kPer; ++j) v[j] = vn[j];
+                halo_lo = next_lo;
+                halo_hi = next_hi;
             }
         }
-        for (;;) {                               // ... the same in a block of another tile
-            const double v = x[i];
-            if (!(v <= h)) return low;
-            low = v < low ? v : low;
-            i += dir;
-        }
+        __syncthreads();
     };
 
-    // ---- B: peaks of this thread's bins, their prominences, its own top K --------------------------
-    Cand best[K];
-    double best_h[K], best_p[K];
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-        best[q].key = 0.0;
-        best[q].idx = -1;
-        best_h[q] = best_p[q] = 0.0;
+    const int K = a.k < kPkMaxK ? a.k : kPkMaxK;
+    sweep(std::true_type{}, a.by_prominence ? kPkPre : K);
+    // lowest sample of the row (NaN aside): prominence <= height - row_min
+    for (int64_t b = tid; b < a.nblk; b += kPkBlock) row_min = bmin[b] < row_min ? bmin[b] : row_min;
+    for (int o = 32; o > 0; o >>= 1) {
+        const double om = __shfl_xor(row_min, o, 64);
+        row_min = om < row_min ? om : row_min;
     }
-    long long mine = 0;
-    for (t0 = 0; t0 < nf; t0 += a.tile) {
-    t1 = t0 + a.tile < nf ? t0 + a.tile : nf;
-    __syncthreads();   // everyone is done with the previous tile
-    for (int64_t i = t0 - 1 + tid; i <= t1; i += kPkBlock) tile[i - t0] = (i >= 0 && i < nf) ? x[i] : 0.0;
+    if (lane == 0) red_k[wave] = row_min;
     __syncthreads();
-    if (tid == 0) s_npk = 0;
+    for (int w = 0; w < kPkBlock / 64; ++w) row_min = red_k[w] < row_min ? red_k[w] : row_min;
     __syncthreads();
-    // (1) the tile's maxima, compacted into a list: with lanes = bins only every eighth lane would hold a
-    // peak and every 64-bin window would cost the longest walk among its few peaks
-    for (int64_t i = (t0 > 0 ? t0 : 1) + tid; i < t1 && i < nf - 1; i += kPkBlock) {
-        const double v = tile[i - t0];
-        if (!(tile[i - 1 - t0] < v)) continue;
-        int64_t ahead = i + 1;   // (a flat top may run past the tile and its halo: global reads from there on)
-        while (ahead < nf - 1 && (ahead <= t1 ? tile[ahead - t0] : x[ahead]) == v) ++ahead;
-        if (!((ahead <= t1 ? tile[ahead - t0] : x[ahead]) < v)) continue;
-        plist[atomicAdd(&s_npk, 1)] = (int)((i + ahead - 1) / 2 - t0);
-    }
-    __syncthreads();
-    const int npk = s_npk;
-    mine += tid == 0 ? npk : 0;
-    // (2) lanes = consecutive entries of the list: prominence walks, per-thread top K
-    for (int pi = tid; pi < npk; pi += kPkBlock) {
-        const int64_t mid = t0 + plist[pi];
-        const bool inside = mid < t1;
-        const double v = inside ? tile[mid - t0] : x[mid];
-        double lo, hi;
-        if (inside) {
-            lo = walk(mid, -1, v, std::true_type{});
-            hi = walk(mid, +1, v, std::true_type{});
-        } else {
-            lo = walk(mid, -1, v, std::false_type{});
-            hi = walk(mid, +1, v, std::false_type{});
-        }
-        const double prom = v - (lo > hi ? lo : hi);
-        const double ckey = a.by_prominence ? prom : v;
-        // insertion into the sorted list (descending key, then bin): slot = number of entries that stay
-        // ahead of the newcomer; the tail moves down one place
-        int pos = 0;
-#pragma unroll
-        for (int q = 0; q < K; ++q) pos += cand_before(ckey, (long long)mid, best[q].key, best[q].idx) ? 0 : 1;
-#pragma unroll
-        for (int q = K - 1; q > 0; --q) {
-            if (q > pos) {
-                best[q] = best[q - 1];
-                best_h[q] = best_h[q - 1];
-                best_p[q] = best_p[q - 1];
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < K; ++q) {
-            if (q == pos) {
-                best[q].key = ckey;
-                best[q].idx = mid;
-                best_h[q] = v;
-                best_p[q] = prom;
-            }
-        }
-    }
-    }
+
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
     if (lane == 0) s_count[wave] = mine;
-
-    // ---- C: the K best of the workgroup: K rounds of "best head of any thread" --------------------
-    int head = 0;
-    for (int round = 0; round < K; ++round) {
-        double hk = 0.0, hh = 0.0, hp = 0.0;
-        long long hi_ = -1;
-#pragma unroll
-        for (int q = 0; q < K; ++q)
-            if (q == head) {
-                hk = best[q].key;
-                hi_ = best[q].idx;
-                hh = best_h[q];
-                hp = best_p[q];
-            }
-        double wk = hk;
-        long long wi = hi_;
-        int wt = tid;
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ok = __shfl_down(wk, o, 64);
-            const long long oi = __shfl_down(wi, o, 64);
-            const int ot = __shfl_down(wt, o, 64);
-            if (cand_before(ok, oi, wk, wi)) {
-                wk = ok;
-                wi = oi;
-                wt = ot;
-            }
-        }
-        __syncthreads();
-        if (lane == 0) {
-            red_k[wave] = wk;
-            red_i[wave] = wi;
-            red_t[wave] = wt;
-        }
-        __syncthreads();
-        wk = red_k[0];
-        wi = red_i[0];
-        wt = red_t[0];
-        for (int w = 1; w < kPkBlock / 64; ++w)
-            if (cand_before(red_k[w], red_i[w], wk, wi)) {
-                wk = red_k[w];
-                wi = red_i[w];
-                wt = red_t[w];
-            }
-        if (wi >= 0 && tid == wt) {   // the winner publishes its candidate and moves on
-            win_key[round] = hk;
-            win_idx[round] = hi_;
-            win_h[round] = hh;
-            win_p[round] = hp;
-            ++head;
-        }
-        if (wi < 0 && tid == 0) {
-            win_key[round] = __builtin_nan("");
-            win_idx[round] = -1;
-            win_h[round] = win_p[round] = __builtin_nan("");
-        }
+    int nwin;
+    if (!a.by_prominence) {
+        nwin = rank_candidates(K, false);
+        walk_candidates();                       // the winners' prominences
+        if (tid < nwin) win_p[tid] = cp[tid];
+    } else {
+        rank_candidates(kPkPre, false);
+        walk_candidates();                       // the highest maxima
+        nwin = rank_candidates(K, true);
+        if (tid == 0) s_thr = nwin == K ? win_key[K - 1] : -inf;   // tau
+        sweep(std::false_type{}, K);
+        walk_candidates();
+        nwin = rank_candidates(K, true);
     }
     __syncthreads();
     const int64_t ob = (int64_t)blockIdx.x * a.k;
@@ -324,7 +455,7 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
         if (a.count) a.count[blockIdx.x] = total;
     }
     if (tid < a.k) {
-        const bool ok = tid < K;
+        const bool ok = tid < nwin;
         if (a.idx) a.idx[ob + tid] = ok ? win_idx[tid] : -1;
         if (a.height) a.height[ob + tid] = ok ? win_h[tid] : __builtin_nan("");
         if (a.prom) a.prom[ob + tid] = ok ? win_p[tid] : __builtin_nan("");
@@ -332,8 +463,8 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
 
     // ---- D: half-maximum crossings of every ranked peak (periods_at_half_max) -------------------
     if (!a.half_lo && !a.half_hi) return;
-    for (int r = 0; r < a.k && r < K; ++r) {
-        const long long idmax = win_idx[r];
+    for (int r = 0; r < a.k; ++r) {
+        const long long idmax = r < nwin ? win_idx[r] : -1;
         long long lo_abs = -1, hi_abs = -1;
         if (idmax >= 0) {
             const double half = x[idmax] - win_key[r] / 2;     // core.py:972 (height or prominence)
@@ -377,11 +508,6 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
             if (a.half_hi) a.half_hi[ob + r] = hi_abs;
         }
     }
-    if (tid == 0)
-        for (int r = K; r < a.k; ++r) {
-            if (a.half_lo) a.half_lo[ob + r] = -1;
-            if (a.half_hi) a.half_hi[ob + r] = -1;
-        }
 }
 
 }  // namespace
@@ -425,25 +551,18 @@ int pdc_highest_peak(const double *power, int64_t n_curves, int64_t nf, int64_t 
 namespace {
 
 int launch_topk(hipStream_t st, PeakArgs a, int64_t n_curves) {
-    int sh = 6;
+    int sh = kPkFusedShift;
     while (((a.nf + ((int64_t)1 << sh) - 1) >> sh) > kPkMaxBlocks) ++sh;
     a.blk_shift = sh;
     a.nblk = (a.nf + ((int64_t)1 << sh) - 1) >> sh;
-    // tile of the spectrum staged in LDS: whole blocks, ~2048 bins (16 KB + halo: five workgroups per CU
-    // at 5e4 bins), or the whole row
-    const int64_t blk = (int64_t)1 << sh;
-    a.tile = blk > 2048 ? blk : 2048;
-    if (a.tile > a.nf) a.tile = ((a.nf > 0 ? a.nf : 1) + blk - 1) / blk * blk;
-    const size_t lds = (size_t)(a.nblk > 0 ? a.nblk : 1) * 16 + (size_t)(a.tile + 2) * 8 + (size_t)(a.tile / 2 + 4) * 4 + 16;
-    static const hipError_t attr[3] = {
-        hipFuncSetAttribute((const void *)peaks_topk_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
-        hipFuncSetAttribute((const void *)peaks_topk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
-        hipFuncSetAttribute((const void *)peaks_topk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)};
-    for (hipError_t e : attr) PDC_HIP(e);
-    const dim3 grid((unsigned)n_curves), block(kPkBlock);
-    if (a.k <= 1) hipLaunchKernelGGL((peaks_topk_kernel<1>), grid, block, lds, st, a);
-    else if (a.k <= 4) hipLaunchKernelGGL((peaks_topk_kernel<4>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((peaks_topk_kernel<8>), grid, block, lds, st, a);
+    // LDS: 24 KB of candidate slots + 12.5 KB of block extrema at 5e4 bins - four workgroups per CU
+    a.tile = 0;
+    const size_t lds = (size_t)(a.nblk > 0 ? a.nblk : 1) * 16 + (size_t)kPkCap * 24 + 16;
+    PDC_REQUIRE(lds <= 150 * 1024, "peaks_topk: %lld bins per spectrum need %zu bytes of LDS", (long long)a.nf, lds);
+    static const hipError_t attr =
+        hipFuncSetAttribute((const void *)peaks_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    PDC_HIP(attr);
+    hipLaunchKernelGGL(peaks_topk_kernel, dim3((unsigned)n_curves), dim3(kPkBlock), lds, st, a);
     PDC_HIP(hipGetLastError());
     return PDC_OK;
 }

@@ -118,8 +118,56 @@ def test_topk_prominences_and_half_max_follow_scipy():
                 check_topk(np.asarray(x, dtype=float), k, by_prominence)
 
 
+def test_topk_candidate_list_and_chunk_edges():
+    """The kernel walks only candidates (the highest maxima, then those whose height above the row's minimum
+    reaches the k-th prominence found): rows that keep the candidate list filling up and being cut down,
+    maxima and flat tops on the edges of the 1024-bin chunks and 256-bin wave stretches, infinities."""
+    rng = np.random.default_rng(17)
+    n = 9000
+    saw = np.where(np.arange(n) % 2 == 1, 1.0, -1.0)
+    rows = [saw + 1e-3 * np.arange(n),                           # every maximum beats all before it
+            saw - 1e-3 * np.arange(n),                           # ... or none
+            saw * (1 + 0.2 * rng.random(n)) + 3 * np.sin(np.arange(n) / 700.0),
+            np.tile([0.0, 1.0, 1.0, 1.0, 0.0, 2.0, 2.0], 1500),   # flat tops everywhere, tied heights and prominences
+            rng.standard_normal(n).round(0)]
+    for edge in (255, 256, 257, 1023, 1024, 1025, 2047, 2048):
+        x = rng.standard_normal(4100) * 0.1
+        x[edge] = 5.0                                            # a maximum on the edge
+        x[edge + 1000] = 4.0
+        rows.append(x)
+        y = rng.standard_normal(4100) * 0.1
+        y[edge - 2:edge + 3] = 3.0                               # a flat top across it
+        rows.append(y)
+    for m in (1023, 1024, 1025, 2049, 255, 257, 3):
+        rows.append(rng.standard_normal(m))
+    infs = rng.standard_normal(3000)
+    infs[[100, 2000]] = -np.inf
+    infs[1500] = np.inf
+    rows.append(infs)
+    for x in rows:
+        for k in (1, 4, 8):
+            for by_prominence in (False, True):
+                check_topk(np.asarray(x, dtype=float), k, by_prominence)
+    batch = rng.standard_normal((23, 5000)).cumsum(axis=1)        # random walks: long prominence walks
+    got = _cabi.peaks_topk(batch, k=5, by_prominence=True)
+    for b in range(23):
+        count, idx, height, prom = scipy_ranked(batch[b], 5, True)
+        assert got["count"][b] == count
+        np.testing.assert_array_equal(got["indices"][b], idx)
+        np.testing.assert_array_equal(got["prominences"][b], prom)
+
+
+def test_topk_rows_beyond_a_million_bins_use_coarser_blocks():
+    rng = np.random.default_rng(19)
+    n = 1_200_000
+    x = np.convolve(rng.standard_normal(n), np.ones(31) / 31, mode="same") + 0.2 * np.sin(np.arange(n) / 9000.0)
+    x[[5, 700_000]] = np.nan
+    for by_prominence in (False, True):
+        check_topk(x, 6, by_prominence)
+
+
 def test_topk_long_rows_hop_blocks_and_match_fseries():
-    """Rows longer than 64 x 4096 bins use coarser blocks; the consumers' own answers come out."""
+    """A long row (walks hop over many blocks); the consumers' own answers come out."""
     rng = np.random.default_rng(11)
     n = 300_000
     x = np.convolve(rng.standard_normal(n), np.ones(101) / 101, mode="same") + 0.3 * np.sin(np.arange(n) / 4000.0)
