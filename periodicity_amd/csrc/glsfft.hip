@@ -85,20 +85,46 @@ struct Dft<1> {
     static __device__ __forceinline__ void run(cplx *) {}
 };
 
+// The extirpolated grids are empty beyond the last sample's position (80 % of the cells at the default
+// five samples per peak): the deposit kernel does not write those cells and the FIRST pass does not read
+// them.  ord = {tmin, tmax, sorted} of the curve (see glsfft_deposit_kernel); nullptr: every cell is live.
+struct LiveArgs {
+    const double *ord;
+    int ord_stride, ngrid, g_first;
+    double df;
+};
+
+__device__ __forceinline__ bool deposit_in_order(const double *ord, double nfftd, double dfg) {
+    return ord[2] != 0.0 && ((ord[1] - ord[0]) * nfftd) * dfg < nfftd;
+}
+
+// cells [0, live) of transform `y` of the launch may be non-zero
+__device__ __forceinline__ int64_t live_cells(const LiveArgs &l, int64_t y, int64_t nfft) {
+    if (!l.ord) return nfft;
+    const int64_t curve = y / l.ngrid;
+    const int g = l.g_first + (int)(y - curve * l.ngrid);
+    const double *ord = l.ord + curve * l.ord_stride;
+    const double nfftd = (double)nfft, dfg = g == 1 ? 2.0 * l.df : l.df;
+    if (!deposit_in_order(ord, nfftd, dfg)) return nfft;
+    const int64_t live = (int64_t)(((ord[1] - ord[0]) * nfftd) * dfg) + 4;   // last position + its neighbours
+    return live < nfft ? live : nfft;
+}
+
 // One Stockham pass: N points, sub-transforms of length Ns become length Ns*R.
 template <int R>
 __global__ __launch_bounds__(kBlock) void fft_pass_kernel(const cplx *__restrict__ in,
                                                           cplx *__restrict__ out, int64_t N,
-                                                          int64_t Ns, int64_t keep) {
+                                                          int64_t Ns, int64_t keep, LiveArgs lv) {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t T = N / R;
     if (j >= T) return;
+    const int64_t live = live_cells(lv, blockIdx.y, N);
     in += (int64_t)blockIdx.y * N;   // batch of independent transforms, one per blockIdx.y
     out += (int64_t)blockIdx.y * N;
     const int64_t k = j & (Ns - 1);
     cplx v[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[r] = in[j + r * T];
+    for (int r = 0; r < R; ++r) v[r] = j + r * T < live ? in[j + r * T] : cplx{0.0, 0.0};
     const double inv = 1.0 / (double)(Ns * R);  // power of two: exact
 #pragma unroll
     for (int r = 1; r < R; ++r) {
@@ -124,13 +150,14 @@ __global__ __launch_bounds__(kBlock) void fft_pass_kernel(const cplx *__restrict
 template <int RB>
 __global__ __launch_bounds__(256) void fft_pass_lds_kernel(const cplx *__restrict__ in,
                                                             cplx *__restrict__ out, int64_t N,
-                                                            int64_t Ns, int64_t keep) {
+                                                            int64_t Ns, int64_t keep, LiveArgs lv) {
     constexpr int R = 16 * RB;
     constexpr int JT = 256 / RB;          // butterflies per workgroup
     constexpr int ROW = R + 16;           // padded LDS row per butterfly
     __shared__ cplx tile[JT * ROW];       // [jj][r1][s2]
     __shared__ cplx wR[R];
     const int tid = threadIdx.x;
+    const int64_t live = live_cells(lv, blockIdx.y, N);
     in += (int64_t)blockIdx.y * N;
     out += (int64_t)blockIdx.y * N;
     if (tid < R) {
@@ -147,7 +174,10 @@ __global__ __launch_bounds__(256) void fft_pass_lds_kernel(const cplx *__restric
         const int64_t k = j & (Ns - 1);
         cplx v[16];
 #pragma unroll
-        for (int r2 = 0; r2 < 16; ++r2) v[r2] = in[j + (int64_t)(r1 + RB * r2) * T];
+        for (int r2 = 0; r2 < 16; ++r2) {
+            const int64_t at = j + (int64_t)(r1 + RB * r2) * T;
+            v[r2] = at < live ? in[at] : cplx{0.0, 0.0};
+        }
         if (Ns > 1) {
             // outer twiddle e^{2 pi i r k / (R Ns)}, r = r1 + RB r2: tw(r1) * tw(RB)^r2
             const double inv = 1.0 / (double)(Ns * R);
@@ -203,9 +233,9 @@ struct FftPrepArgs {
     int64_t n;
     int fit_mean, nparts;
     double *wy, *w;
-    double *part;   // [3][kMaxPart]: sum err^-2 | sum err^-2 y | min t
+    double *part;   // [5][kMaxPart]: sum err^-2 | sum err^-2 y | min t | -max t | out-of-order pairs
     double *ypart;  // [kMaxPart]: partial YY
-    double *scal;   // {YY (filled by the epilogue's reduction), Werr, tmin}
+    double *scal;   // {YY (filled by the epilogue's reduction), Werr, tmin, tmax, sorted}
 };
 
 __device__ __forceinline__ double block_min_256(double v, double *red) {
@@ -223,21 +253,28 @@ __device__ __forceinline__ double block_min_256(double v, double *red) {
 
 __global__ __launch_bounds__(kBlock) void glsfft_prep_a_kernel(FftPrepArgs a) {
     __shared__ double red[kBlock / 64];
-    double sw = 0.0, swy = 0.0, tmin = __builtin_inf();
+    double sw = 0.0, swy = 0.0, tmin = __builtin_inf(), ntmax = __builtin_inf(), disorder = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
         const double e = a.dy ? a.dy[i] : 1.0;
         const double wr = 1.0 / (e * e);
         sw += wr;
         swy += wr * a.y[i];
-        tmin = a.t[i] < tmin ? a.t[i] : tmin;
+        const double ti = a.t[i];
+        tmin = ti < tmin ? ti : tmin;
+        ntmax = -ti < ntmax ? -ti : ntmax;
+        if (i > 0 && !(ti >= a.t[i - 1])) disorder = 1.0;   // (a NaN counts as disorder)
     }
     sw = block_sum<kBlock>(sw, red);
     swy = block_sum<kBlock>(swy, red);
     tmin = block_min_256(tmin, red);
+    ntmax = block_min_256(ntmax, red);
+    disorder = block_sum<kBlock>(disorder, red);
     if (threadIdx.x == 0) {
         a.part[blockIdx.x] = sw;
         a.part[kMaxPart + blockIdx.x] = swy;
         a.part[2 * kMaxPart + blockIdx.x] = tmin;
+        a.part[3 * kMaxPart + blockIdx.x] = ntmax;
+        a.part[4 * kMaxPart + blockIdx.x] = disorder;
     }
 }
 
@@ -258,6 +295,13 @@ __global__ __launch_bounds__(kBlock) void glsfft_prep_c_kernel(FftPrepArgs a) {
         tmin = u < tmin ? u : tmin;
     }
     tmin = block_min_256(tmin, red);
+    double ntmax = __builtin_inf();
+    for (int i = threadIdx.x; i < a.nparts; i += kBlock) {
+        const double u = a.part[3 * kMaxPart + i];
+        ntmax = u < ntmax ? u : ntmax;
+    }
+    ntmax = block_min_256(ntmax, red);
+    const double disorder = reduce_partials(a.part + 4 * kMaxPart, a.nparts, red);
     double yy = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * kBlock) {
         const double e = a.dy ? a.dy[i] : 1.0;
@@ -273,6 +317,8 @@ __global__ __launch_bounds__(kBlock) void glsfft_prep_c_kernel(FftPrepArgs a) {
         if (blockIdx.x == 0) {
             a.scal[1] = W;
             a.scal[2] = tmin;
+            a.scal[3] = -ntmax;                        // latest time stamp
+            a.scal[4] = disorder == 0.0 ? 1.0 : 0.0;   // time stamps in non-decreasing order
         }
     }
 }
@@ -280,8 +326,8 @@ __global__ __launch_bounds__(kBlock) void glsfft_prep_c_kernel(FftPrepArgs a) {
 // ---- extirpolation: spectral.py:18-33 ---------------------------------------------------------------
 struct SpreadArgs {
     const double *t, *h;   // h = weights of this transform
-    const double *scal;    // scal[2] = tmin (nullptr -> tmin_value)
-    double tmin_value;
+    const double *scal;    // scal[2..4] = {tmin, tmax, sorted}
+    double tmin_value;     // (unused)
     int64_t n, nfft;
     double df, fmin;
     double *grid;          // [nfft] complex, zeroed
@@ -295,7 +341,8 @@ __device__ __forceinline__ void grid_add(double *grid, int64_t idx, double re, d
 __global__ __launch_bounds__(kBlock) void glsfft_spread_kernel(SpreadArgs a) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
-    const double tmin = a.scal ? a.scal[2] : a.tmin_value;
+    const double tmin = a.scal[2];
+    if (deposit_in_order(a.scal + 2, (double)a.nfft, a.df)) return;   // glsfft_deposit_kernel has done it
     const double dt = a.t[i] - tmin;
     // w * np.exp(2j * np.pi * fmin * (t - tmin)): the phase is fl(fl(2 pi fmin) * dt) radians
     const double ang = (6.283185307179586 * a.fmin) * dt;
@@ -325,7 +372,8 @@ __global__ __launch_bounds__(kBlock) void glsfft_spread_kernel(SpreadArgs a) {
 }
 
 __device__ __forceinline__ void spread_one(double *grid, int64_t nfft, double dt, double h, double df,
-                                           double fmin) {
+                                           double fmin, const double *ord) {
+    if (deposit_in_order(ord, (double)nfft, df)) return;   // glsfft_deposit_kernel has done this grid
     const double ang = (6.283185307179586 * fmin) * dt;
     double sn, cs;
     sincos(ang, &sn, &cs);
@@ -351,6 +399,103 @@ __device__ __forceinline__ void spread_one(double *grid, int64_t nfft, double dt
     }
 }
 
+// ---- the same deposits without atomics, in a fixed order ---------------------------------------------
+// With time stamps in non-decreasing order and a grid that does not wrap ((tmax - tmin) nfft df < nfft -
+// always so for the default n >= 1 samples per peak), grid positions rise with the sample index, so the
+// samples that touch a cell are consecutive.  One thread owns four consecutive cells: a binary search
+// finds the first sample that can reach them, the deposits are added in sample order and stored once -
+// bitwise reproducible (the atomic kernels above add in arrival order), and the memset goes away: every
+// cell up to the last sample's reach is written (the empty ones with zero), the rest is read by nobody.
+// Otherwise this kernel only zeroes the grid and the atomic kernels do the work (`deposit_in_order` is
+// false for them exactly then).
+struct DepositArgs {
+    const double *t, *h0, *h1;   // h0: weights of grid 0 (w y); h1: weights of grids 1 (@ 2 df) and 2 (@ df)
+    const int64_t *offsets;      // per-curve sample ranges; nullptr: one curve of n samples
+    int64_t n;
+    int shared_t, ngrid, g_first; // this launch fills grids g_first .. g_first + ngrid - 1 of every curve
+    const double *ord;           // ord[curve * ord_stride + {0, 1, 2}] = {tmin, tmax, sorted}
+    int ord_stride;
+    int64_t nfft;
+    double df, fmin;
+    double *grids;               // [curve][ngrid][nfft] complex: every live cell is written
+};
+
+constexpr int kDepCells = 4;
+
+__global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
+    const int64_t curve = blockIdx.y / a.ngrid;
+    const int slot = (int)(blockIdx.y - curve * a.ngrid), g = a.g_first + slot;
+    const int64_t g0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kDepCells;
+    // (cells from `live` on are never read: the first FFT pass takes them as zero)
+    if (g0 >= live_cells(LiveArgs{a.ord, a.ord_stride, a.ngrid, a.g_first, a.df}, blockIdx.y, a.nfft)) return;
+    const int64_t off = a.offsets ? a.offsets[curve] : 0;
+    const int64_t n = a.offsets ? a.offsets[curve + 1] - off : a.n;
+    const double *t = a.t + (a.shared_t ? 0 : off);
+    const double *h = (g == 0 ? a.h0 : a.h1) + off;
+    const double *ord = a.ord + curve * a.ord_stride;
+    const double dfg = g == 1 ? 2.0 * a.df : a.df, fming = g == 1 ? 2.0 * a.fmin : a.fmin;
+    const double nfftd = (double)a.nfft, tmin = ord[0];
+    double *out = a.grids + 2 * ((curve * a.ngrid + slot) * a.nfft + g0);
+    double acc_re[kDepCells], acc_im[kDepCells];
+#pragma unroll
+    for (int c = 0; c < kDepCells; ++c) acc_re[c] = acc_im[c] = 0.0;
+    auto position = [&](int64_t i) -> double {   // tnorm of sample i (no wrap: fmod changes nothing, kept for form)
+        return fmod(((t[i] - tmin) * nfftd) * dfg, nfftd);
+    };
+    const double lo = (double)(g0 - 4), hi = (double)(g0 + kDepCells + 4);
+    if (n > 0 && deposit_in_order(ord, nfftd, dfg) && lo <= ((ord[1] - tmin) * nfftd) * dfg) {
+        int64_t first = 0, last = n;   // first sample with position >= lo
+        while (first < last) {
+            const int64_t mid = (first + last) >> 1;
+            if (position(mid) >= lo) last = mid; else first = mid + 1;
+        }
+        for (int64_t i = first; i < n; ++i) {
+            const double tn = position(i);
+            if (!(tn < hi)) break;
+            const double dt = t[i] - tmin;
+            const double ang = (6.283185307179586 * fming) * dt;
+            double sn, cs;
+            sincos(ang, &sn, &cs);
+            const double hre = h[i] * cs, him = h[i] * sn;
+            if (tn - __builtin_floor(tn) == 0.0) {   // whole position: one deposit
+                const int64_t ind = (int64_t)tn;
+#pragma unroll
+                for (int c = 0; c < kDepCells; ++c)
+                    if (ind == g0 + c) {
+                        acc_re[c] += hre;
+                        acc_im[c] += him;
+                    }
+                continue;
+            }
+            int64_t ilo = (int64_t)(tn - 2.0);
+            ilo = ilo < 0 ? 0 : (ilo > a.nfft - 4 ? a.nfft - 4 : ilo);
+            if (ilo + 3 < g0 || ilo >= g0 + kDepCells) continue;
+            const double x = tn - (double)ilo;
+            const double prod = ((x * (x - 1.0)) * (x - 2.0)) * (x - 3.0);
+            const double nre = hre * prod, nim = him * prod;
+            const double den[4] = {6.0, -2.0, 2.0, -6.0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t ind = ilo + (3 - j);
+                const double d = den[j] * (tn - (double)ind);
+                const double vre = nre / d, vim = nim / d;
+#pragma unroll
+                for (int c = 0; c < kDepCells; ++c)
+                    if (ind == g0 + c) {
+                        acc_re[c] += vre;
+                        acc_im[c] += vim;
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < kDepCells; ++c)
+        if (g0 + c < a.nfft) {
+            out[2 * c] = acc_re[c];
+            out[2 * c + 1] = acc_im[c];
+        }
+}
+
 // All three (or two) grids of one curve in a single launch: (w*y @ df), (w @ 2 df), (w @ df).
 struct Spread3Args {
     const double *t, *wy, *w, *scal;
@@ -364,9 +509,9 @@ __global__ __launch_bounds__(kBlock) void glsfft_spread3_kernel(Spread3Args a) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
     const double dt = a.t[i] - a.scal[2];
-    spread_one(a.grids, a.nfft, dt, a.wy[i], a.df, a.fmin);
-    spread_one(a.grids + 2 * a.nfft, a.nfft, dt, a.w[i], 2.0 * a.df, 2.0 * a.fmin);   // (:110)
-    if (a.fit_mean) spread_one(a.grids + 4 * a.nfft, a.nfft, dt, a.w[i], a.df, a.fmin);
+    spread_one(a.grids, a.nfft, dt, a.wy[i], a.df, a.fmin, a.scal + 2);
+    spread_one(a.grids + 2 * a.nfft, a.nfft, dt, a.w[i], 2.0 * a.df, 2.0 * a.fmin, a.scal + 2);   // (:110)
+    if (a.fit_mean) spread_one(a.grids + 4 * a.nfft, a.nfft, dt, a.w[i], a.df, a.fmin, a.scal + 2);
 }
 
 // ---- epilogue: spectral.py:34-39 then :113-132 ----------------------------------------------------------
@@ -450,7 +595,7 @@ struct FftBatchArgs {
     int64_t nfft, nf;
     double df, fmin;
     double *w, *wy;   // [n_total]
-    double *scal;     // [B][4] = {YY, Werr, tmin, -}
+    double *scal;     // [B][8] = {YY, Werr, tmin, tmax, sorted, -, -, -}
     cplx *grids;      // [B][ngrid][nfft]
     const cplx *result;  // where the transforms ended up (grids or scratch), same layout
     double *power;    // [B][nf]
@@ -463,22 +608,32 @@ __global__ __launch_bounds__(1024) void glsfft_prep_batch_kernel(FftBatchArgs a)
     const double *t = a.shared_t ? a.t : a.t + off;
     const double *y = a.y + off;
     const double *dy = a.dy ? a.dy + off : nullptr;
-    double acc = 0.0, tmin = __builtin_inf();
+    double acc = 0.0, tmin = __builtin_inf(), ntmax = __builtin_inf(), disorder = 0.0;
     for (int64_t i = tid; i < n; i += 1024) {
         const double e = dy ? dy[i] : 1.0;
         acc += 1.0 / (e * e);
-        tmin = t[i] < tmin ? t[i] : tmin;
+        const double ti = t[i];
+        tmin = ti < tmin ? ti : tmin;
+        ntmax = -ti < ntmax ? -ti : ntmax;
+        if (i > 0 && !(ti >= t[i - 1])) disorder = 1.0;   // (a NaN counts as disorder)
     }
     const double W = block_sum<1024>(acc, red);
-    for (int o = 32; o > 0; o >>= 1) {
-        const double u = __shfl_down(tmin, o, 64);
-        tmin = u < tmin ? u : tmin;
-    }
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = tmin;
-    __syncthreads();
-    tmin = red[0];
-    for (int w = 1; w < 16; ++w) tmin = red[w] < tmin ? red[w] : tmin;
+    disorder = block_sum<1024>(disorder, red);
+    auto block_min = [&](double v) -> double {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double u = __shfl_down(v, o, 64);
+            v = u < v ? u : v;
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        v = red[0];
+        for (int w = 1; w < 16; ++w) v = red[w] < v ? red[w] : v;
+        __syncthreads();
+        return v;
+    };
+    tmin = block_min(tmin);
+    ntmax = block_min(ntmax);
     double ybar = 0.0;
     if (a.fit_mean) {
         acc = 0.0;
@@ -499,10 +654,12 @@ __global__ __launch_bounds__(1024) void glsfft_prep_batch_kernel(FftBatchArgs a)
     }
     yy = block_sum<1024>(yy, red);
     if (tid == 0) {
-        double *s = a.scal + (int64_t)blockIdx.x * 4;
+        double *s = a.scal + (int64_t)blockIdx.x * 8;
         s[0] = yy;
         s[1] = W;
         s[2] = tmin;
+        s[3] = -ntmax;
+        s[4] = disorder == 0.0 ? 1.0 : 0.0;
     }
 }
 
@@ -512,11 +669,12 @@ __global__ __launch_bounds__(kBlock) void glsfft_spread_batch_kernel(FftBatchArg
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const double *t = a.shared_t ? a.t : a.t + off;
-    const double dt = t[i] - a.scal[b * 4 + 2];
+    const double *ord = a.scal + b * 8 + 2;
+    const double dt = t[i] - ord[0];
     double *g0 = reinterpret_cast<double *>(a.grids + (b * a.ngrid) * a.nfft);
-    spread_one(g0, a.nfft, dt, a.wy[off + i], a.df, a.fmin);
-    spread_one(g0 + 2 * a.nfft, a.nfft, dt, a.w[off + i], 2.0 * a.df, 2.0 * a.fmin);
-    if (a.fit_mean) spread_one(g0 + 4 * a.nfft, a.nfft, dt, a.w[off + i], a.df, a.fmin);
+    spread_one(g0, a.nfft, dt, a.wy[off + i], a.df, a.fmin, ord);
+    spread_one(g0 + 2 * a.nfft, a.nfft, dt, a.w[off + i], 2.0 * a.df, 2.0 * a.fmin, ord);
+    if (a.fit_mean) spread_one(g0 + 4 * a.nfft, a.nfft, dt, a.w[off + i], a.df, a.fmin, ord);
 }
 
 __global__ __launch_bounds__(kBlock) void glsfft_epilogue_batch_kernel(FftBatchArgs a) {
@@ -524,7 +682,7 @@ __global__ __launch_bounds__(kBlock) void glsfft_epilogue_batch_kernel(FftBatchA
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= a.nf) return;
     const double nfftd = (double)a.nfft, scale = 1.0 / nfftd;
-    const double *sc = a.scal + b * 4;
+    const double *sc = a.scal + b * 8;
     const double tmin = sc[2];
     const cplx *g = a.result + (b * a.ngrid) * a.nfft;
     const double f = a.fmin + a.df * (double)j;
@@ -602,23 +760,26 @@ int64_t fft_length(int64_t nf) {
 
 template <int R>
 void launch_pass(hipStream_t st, const cplx *in, cplx *out, int64_t N, int64_t Ns, int batch,
-                 int64_t keep) {
+                 int64_t keep, const LiveArgs &lv) {
     const int64_t T = N / R;
     hipLaunchKernelGGL(fft_pass_kernel<R>, dim3((unsigned)((T + kBlock - 1) / kBlock), (unsigned)batch),
-                       dim3(kBlock), 0, st, in, out, N, Ns, keep);
+                       dim3(kBlock), 0, st, in, out, N, Ns, keep, lv);
 }
 
 // Unnormalised inverse FFT of `batch` contiguous arrays of N = 2^bits points in `a`, using `b` (same
 // size) as the other half of the ping-pong; returns the buffer that holds the results.  Only the first
 // `keep_out` outputs of every transform are needed by the caller (spectral.py:34 keeps [:nf]): the
 // final pass skips the stores beyond them.
-cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1, int64_t keep_out = -1) {
+cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1, int64_t keep_out = -1,
+                  LiveArgs input_live = LiveArgs{nullptr, 0, 1, 0, 0.0}) {
     int bits = 0;
     while (((int64_t)1 << bits) < N) ++bits;
     int64_t Ns = 1;
     cplx *src = a, *dst = b;
     static const bool no_lds = [] { const char *e = getenv("PDC_FFT_NO256"); return e && e[0] == '1'; }();
+    const LiveArgs all_live{nullptr, 0, 1, 0, 0.0};
     while (bits > 0) {
+        const LiveArgs &lv = Ns == 1 ? input_live : all_live;   // only the first pass reads the deposits
         int r = bits >= 4 ? 4 : bits;
         if (bits == 5) r = 3;  // 5 = 3 + 2 rather than 4 + 1
         // LDS-blocked passes (radix 16 x RB in one trip through HBM): 8 bits at a time, then the
@@ -632,10 +793,10 @@ cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1, in
             const int jt = 256 / (int)(R / 16);
             const dim3 grid((unsigned)((N / R) / jt), (unsigned)batch);
             switch (lds_bits) {
-                case 8: hipLaunchKernelGGL(fft_pass_lds_kernel<16>, grid, dim3(256), 0, st, src, dst, N, Ns, keep); break;
-                case 7: hipLaunchKernelGGL(fft_pass_lds_kernel<8>, grid, dim3(256), 0, st, src, dst, N, Ns, keep); break;
-                case 6: hipLaunchKernelGGL(fft_pass_lds_kernel<4>, grid, dim3(256), 0, st, src, dst, N, Ns, keep); break;
-                default: hipLaunchKernelGGL(fft_pass_lds_kernel<2>, grid, dim3(256), 0, st, src, dst, N, Ns, keep); break;
+                case 8: hipLaunchKernelGGL(fft_pass_lds_kernel<16>, grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv); break;
+                case 7: hipLaunchKernelGGL(fft_pass_lds_kernel<8>, grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv); break;
+                case 6: hipLaunchKernelGGL(fft_pass_lds_kernel<4>, grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv); break;
+                default: hipLaunchKernelGGL(fft_pass_lds_kernel<2>, grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv); break;
             }
             Ns <<= lds_bits;
             bits -= lds_bits;
@@ -646,10 +807,10 @@ cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1, in
         }
         const int64_t keep = (bits == r && keep_out >= 0) ? keep_out : N;  // final pass only
         switch (r) {
-            case 4: launch_pass<16>(st, src, dst, N, Ns, batch, keep); break;
-            case 3: launch_pass<8>(st, src, dst, N, Ns, batch, keep); break;
-            case 2: launch_pass<4>(st, src, dst, N, Ns, batch, keep); break;
-            default: launch_pass<2>(st, src, dst, N, Ns, batch, keep); break;
+            case 4: launch_pass<16>(st, src, dst, N, Ns, batch, keep, lv); break;
+            case 3: launch_pass<8>(st, src, dst, N, Ns, batch, keep, lv); break;
+            case 2: launch_pass<4>(st, src, dst, N, Ns, batch, keep, lv); break;
+            default: launch_pass<2>(st, src, dst, N, Ns, batch, keep, lv); break;
         }
         Ns <<= r;
         bits -= r;
@@ -658,6 +819,12 @@ cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1, in
         dst = tmp;
     }
     return src;
+}
+
+void launch_deposit(hipStream_t st, const DepositArgs &d, int64_t n_curves) {
+    const int64_t threads = (d.nfft + kDepCells - 1) / kDepCells;
+    hipLaunchKernelGGL(glsfft_deposit_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock), (unsigned)(n_curves * d.ngrid)),
+                       dim3(kBlock), 0, st, d);
 }
 
 struct FftLayout {
@@ -670,7 +837,7 @@ FftLayout fft_layout(int64_t n, int64_t nfft) {
     L.wy = 0;
     L.w = up(n * 8);
     L.scal = L.w + up(n * 8);
-    int64_t off = L.scal + up((4 * kMaxPart + 8) * 8);  // scal[8] | part[3][kMaxPart] | ypart[kMaxPart]
+    int64_t off = L.scal + up((6 * kMaxPart + 8) * 8);  // scal[8] | part[5][kMaxPart] | ypart[kMaxPart]
     for (int g = 0; g < 3; ++g) L.grid[g] = off + g * nfft * 16;  // contiguous: batched FFT stride = nfft
     off += up(3 * nfft * 16);
     L.scratch = off;
@@ -708,7 +875,7 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
 
     int nparts = (int)((n + 4 * kBlock - 1) / (4 * kBlock));
     nparts = nparts < 1 ? 1 : (nparts > kMaxPart ? kMaxPart : nparts);
-    FftPrepArgs p{d_t, d_y, d_dy, n, fit_mean, nparts, wy, w, scal + 8, scal + 8 + 3 * kMaxPart, scal};
+    FftPrepArgs p{d_t, d_y, d_dy, n, fit_mean, nparts, wy, w, scal + 8, scal + 8 + 5 * kMaxPart, scal};
     hipLaunchKernelGGL(glsfft_prep_a_kernel, dim3(nparts), dim3(kBlock), 0, st, p);
     hipLaunchKernelGGL(glsfft_prep_c_kernel, dim3(nparts), dim3(kBlock), 0, st, p);
     PDC_HIP(hipGetLastError());
@@ -722,7 +889,8 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
     const cplx *result[3] = {nullptr, nullptr, nullptr};
     if (nfft * 32 <= mall && (int64_t)ngrid * nfft * 32 > mall) {
         for (int g = 0; g < ngrid; ++g) {
-            PDC_HIP(hipMemsetAsync(grid[g], 0, (size_t)nfft * 16, st));
+            launch_deposit(st, DepositArgs{d_t, wy, w, nullptr, n, 0, 1, g, scal + 2, 0, nfft, df, fmin,
+                                           reinterpret_cast<double *>(grid[g])}, 1);
             SpreadArgs sp;
             sp.t = d_t;
             sp.h = g == 0 ? wy : w;
@@ -736,16 +904,17 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
             if (n > 0)
                 hipLaunchKernelGGL(glsfft_spread_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
                                    dim3(kBlock), 0, st, sp);
-            result[g] = inverse_fft(st, grid[g], scratch + g * nfft, nfft, 1, nf);
+            result[g] = inverse_fft(st, grid[g], scratch + g * nfft, nfft, 1, nf, LiveArgs{scal + 2, 0, 1, g, df});
         }
     } else {
-        PDC_HIP(hipMemsetAsync(grid[0], 0, (size_t)ngrid * nfft * 16, st));
+        launch_deposit(st, DepositArgs{d_t, wy, w, nullptr, n, 0, ngrid, 0, scal + 2, 0, nfft, df, fmin,
+                                       reinterpret_cast<double *>(grid[0])}, 1);
         if (n > 0) {
             Spread3Args s3{d_t, wy, w, scal, n, nfft, df, fmin, reinterpret_cast<double *>(grid[0]), fit_mean};
             hipLaunchKernelGGL(glsfft_spread3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
                                dim3(kBlock), 0, st, s3);
         }
-        const cplx *res = inverse_fft(st, grid[0], scratch, nfft, ngrid, nf);
+        const cplx *res = inverse_fft(st, grid[0], scratch, nfft, ngrid, nf, LiveArgs{scal + 2, 0, ngrid, 0, df});
         for (int g = 0; g < ngrid; ++g) result[g] = res + g * nfft;
     }
     PDC_HIP(hipGetLastError());
@@ -828,7 +997,7 @@ int pdc_gls_scan_fft_batch(const double *t, const double *y, const double *dy, c
     chunk = chunk > 65535 / ngrid ? 65535 / ngrid : chunk;
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
     const int64_t o_w = 0, o_wy = up(n_total * 8), o_scal = o_wy + up(n_total * 8);
-    const int64_t o_grid = o_scal + up(n_curves * 32);
+    const int64_t o_grid = o_scal + up(n_curves * 64);
     const int64_t o_scratch = o_grid + up(chunk * ngrid * nfft * 16);
     const int64_t o_pow = o_scratch + up(chunk * ngrid * nfft * 16);
     const int64_t wb = o_pow + up(chunk * nf * 8);
@@ -873,15 +1042,16 @@ int pdc_gls_scan_fft_batch(const double *t, const double *y, const double *dy, c
         const int64_t bc = n_curves - c0 < chunk ? n_curves - c0 : chunk;
         FftBatchArgs c = a;
         c.offsets = a.offsets + c0;
-        c.scal = const_cast<double *>(scal_all) + c0 * 4;
-        PDC_HIP(hipMemsetAsync(c.grids, 0, (size_t)(bc * ngrid * nfft * 16), st));
+        c.scal = const_cast<double *>(scal_all) + c0 * 8;
+        launch_deposit(st, DepositArgs{a.t, a.wy, a.w, c.offsets, 0, shared_t, ngrid, 0, c.scal + 2, 8, nfft, df, fmin,
+                                       reinterpret_cast<double *>(c.grids)}, bc);
         if (n_max > 0) {
             hipLaunchKernelGGL(glsfft_spread_batch_kernel,
                                dim3((unsigned)((n_max + kBlock - 1) / kBlock), (unsigned)bc), dim3(kBlock),
                                0, st, c);
             PDC_HIP(hipGetLastError());
         }
-        c.result = inverse_fft(st, c.grids, scratch, nfft, (int)(bc * ngrid), nf);
+        c.result = inverse_fft(st, c.grids, scratch, nfft, (int)(bc * ngrid), nf, LiveArgs{c.scal + 2, 8, ngrid, 0, df});
         PDC_HIP(hipGetLastError());
         hipLaunchKernelGGL(glsfft_epilogue_batch_kernel,
                            dim3((unsigned)((nf + kBlock - 1) / kBlock), (unsigned)bc), dim3(kBlock), 0, st, c);
@@ -909,8 +1079,14 @@ int pdc_trig_sums_fft(const double *t, const double *h, int64_t n, double df, in
     PDC_TRY(use_device(device));
     DeviceLock lock(device);
     const int64_t nfft = fft_length(nf);
-    double tmin = t[0];
-    for (int64_t i = 1; i < n; ++i) tmin = t[i] < tmin ? t[i] : tmin;
+    double tmin = t[0], tmax = t[0];
+    bool sorted = t[0] == t[0];
+    for (int64_t i = 1; i < n; ++i) {
+        tmin = t[i] < tmin ? t[i] : tmin;
+        tmax = t[i] > tmax ? t[i] : tmax;
+        sorted = sorted && t[i] >= t[i - 1];
+    }
+    const double scal_host[8] = {0.0, 0.0, tmin, tmax, sorted ? 1.0 : 0.0, 0.0, 0.0, 0.0};
     void *d_t, *d_h, *d_s, *d_c, *d_work;
     PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
     PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_h));
@@ -921,13 +1097,16 @@ int pdc_trig_sums_fft(const double *t, const double *h, int64_t n, double df, in
     cplx *grid = reinterpret_cast<cplx *>(d_work), *scratch = grid + nfft;
     PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_h, h, n * 8, hipMemcpyHostToDevice, st));
-    PDC_HIP(hipMemsetAsync(grid, 0, (size_t)nfft * 16, st));
-    SpreadArgs s{(double *)d_t, (double *)d_h, nullptr, tmin, n, nfft, df, fmin,
+    double *scal = reinterpret_cast<double *>(static_cast<char *>(d_work) + nfft * 32);
+    PDC_HIP(hipMemcpyAsync(scal, scal_host, sizeof(scal_host), hipMemcpyHostToDevice, st));
+    launch_deposit(st, DepositArgs{(double *)d_t, (double *)d_h, (double *)d_h, nullptr, n, 0, 1, 0, scal + 2, 0, nfft, df,
+                                   fmin, reinterpret_cast<double *>(grid)}, 1);
+    SpreadArgs s{(double *)d_t, (double *)d_h, scal, tmin, n, nfft, df, fmin,
                  reinterpret_cast<double *>(grid)};
     hipLaunchKernelGGL(glsfft_spread_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock),
                        0, st, s);
     PDC_HIP(hipGetLastError());
-    cplx *res = inverse_fft(st, grid, scratch, nfft, 1, nf);
+    cplx *res = inverse_fft(st, grid, scratch, nfft, 1, nf, LiveArgs{scal + 2, 0, 1, 0, df});
     PDC_HIP(hipGetLastError());
     FftEpiArgs e{};
     e.gh = res;

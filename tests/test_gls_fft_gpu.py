@@ -130,6 +130,48 @@ def test_fft_sizes_cover_every_radix_combination():
         assert np.max(np.abs(S - Sr)) <= 1e-12 * amp and np.max(np.abs(C - Cr)) <= 1e-12 * amp, k
 
 
+def test_fft_path_is_bitwise_reproducible_and_order_free_deposits_agree_with_the_atomic_ones():
+    """Sorted time stamps on a grid that does not wrap: the extirpolation deposits are added in sample order
+    by the threads that own the cells (no atomics) - the same bits on every call, for single curves, batches
+    and bootstrap replicates.  Shuffled time stamps (raw C-ABI callers) take the atomic kernels: same
+    periodogram to rounding."""
+    t, y, dy = synth(20_000, 91)
+    nf = 60_000
+    df = 1.0 / (t[-1] - t[0]) / 5
+    fmin = 0.5 * df
+    first = _cabi.gls_scan_fft(t, y, dy, fmin, df, nf)
+    for _ in range(3):
+        assert np.array_equal(_cabi.gls_scan_fft(t, y, dy, fmin, df, nf), first)
+    perm = np.random.default_rng(5).permutation(t.size)
+    shuffled = _cabi.gls_scan_fft(t[perm], y[perm], dy[perm], fmin, df, nf)
+    assert_tier_f(shuffled, first, 1e-9, 1e-12)
+    assert_tier_f(first, so.gls(t, y, dy, fmin=fmin, fmax=fmin + (nf - 1.5) * df)[1], 1e-9, 1e-12)
+    # clustered stamps: thousands of samples reach the same cells
+    tc = np.sort(np.concatenate([np.full(3000, 17.25), np.linspace(0.0, 40.0, 2000), 17.25 + 1e-9 * np.arange(3000)]))
+    yc = np.sin(tc) + 0.1 * np.cos(37 * tc)
+    dfc = 1.0 / 40.0 / 5
+    pc = _cabi.gls_scan_fft(tc, yc, None, 0.5 * dfc, dfc, 500)
+    assert np.array_equal(_cabi.gls_scan_fft(tc, yc, None, 0.5 * dfc, dfc, 500), pc)
+    assert_tier_f(pc, so.gls(tc, yc, None, fmin=0.5 * dfc, fmax=0.5 * dfc + 498.5 * dfc)[1], 1e-9, 1e-11)
+    S, C = _cabi.trig_sums_fft(t, y, df, nf, fmin)
+    S2, C2 = _cabi.trig_sums_fft(t, y, df, nf, fmin)
+    assert np.array_equal(S, S2) and np.array_equal(C, C2)
+    # batches and bootstrap replicates
+    lens = [700, 701, 333]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    tb = np.concatenate([np.sort(np.random.default_rng(s).uniform(0, 700.0, n)) for s, n in enumerate(lens)])
+    yb = np.sin(tb / 3.0) + 0.2 * np.random.default_rng(9).standard_normal(tb.size)
+    b1 = _cabi.gls_scan_fft_batch(tb, yb, None, offs, 0.001, 0.0003, 4000)[0]
+    b2 = _cabi.gls_scan_fft_batch(tb, yb, None, offs, 0.001, 0.0003, 4000)[0]
+    assert np.array_equal(b1, b2)
+    for b in range(3):
+        sl = slice(offs[b], offs[b + 1])
+        assert_tier_f(b1[b], _cabi.gls_scan_fft(tb[sl], yb[sl], None, 0.001, 0.0003, 4000), 1e-9, 1e-12)   # (other prologue)
+    ls = GLS(method="fft")
+    ls(TSeries(t[:3000], y[:3000]), err=dy[:3000])
+    assert np.array_equal(ls.bootstrap(40, random_seed=7), ls.bootstrap(40, random_seed=7))
+
+
 def test_full_size_c2_matches_cpu_reference_path():
     n, nf = 100_000, 1_000_000
     t, y, dy = synth(n, 20241010)
