@@ -412,7 +412,9 @@ struct DepositArgs {
     const double *t, *h0, *h1;   // h0: weights of grid 0 (w y); h1: weights of grids 1 (@ 2 df) and 2 (@ df)
     const int64_t *offsets;      // per-curve sample ranges; nullptr: one curve of n samples
     int64_t n;
-    int shared_t, ngrid, g_first; // this launch fills grids g_first .. g_first + ngrid - 1 of every curve
+    int shared_t, ngrid;         // ngrid = grids per curve in `grids` (3 with fit_mean, else 2)
+    int slot_first, nslots;      // slots of this launch: slot 0 = grid 0 (and grid 2, which shares its
+                                 // positions and phases, when ngrid == 3); slot 1 = grid 1
     const double *ord;           // ord[curve * ord_stride + {0, 1, 2}] = {tmin, tmax, sorted}
     int ord_stride;
     int64_t nfft;
@@ -420,79 +422,148 @@ struct DepositArgs {
     double *grids;               // [curve][ngrid][nfft] complex: every live cell is written
 };
 
-constexpr int kDepCells = 4;
+constexpr int kDepCells = 4;                     // cells per thread
+constexpr int kDepSpan = kDepCells * kBlock;     // cells per workgroup
+constexpr int kDepStage = 1024;                  // positions of a workgroup's samples kept in LDS
 
 __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
-    const int64_t curve = blockIdx.y / a.ngrid;
-    const int slot = (int)(blockIdx.y - curve * a.ngrid), g = a.g_first + slot;
-    const int64_t g0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kDepCells;
+    __shared__ double s_pos[kDepStage];
+    __shared__ unsigned long long s_ballot[2][kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t curve = blockIdx.y / a.nslots;
+    const int g = a.slot_first + (int)(blockIdx.y - curve * a.nslots);
+    const bool twin = g == 0 && a.ngrid == 3;
+    const int64_t G0 = (int64_t)blockIdx.x * kDepSpan, g0 = G0 + (int64_t)tid * kDepCells;
     // (cells from `live` on are never read: the first FFT pass takes them as zero)
-    if (g0 >= live_cells(LiveArgs{a.ord, a.ord_stride, a.ngrid, a.g_first, a.df}, blockIdx.y, a.nfft)) return;
+    const int64_t live = live_cells(LiveArgs{a.ord, a.ord_stride, 1, g, a.df}, curve, a.nfft);
+    if (G0 >= live) return;   // (workgroup-uniform)
     const int64_t off = a.offsets ? a.offsets[curve] : 0;
     const int64_t n = a.offsets ? a.offsets[curve + 1] - off : a.n;
     const double *t = a.t + (a.shared_t ? 0 : off);
-    const double *h = (g == 0 ? a.h0 : a.h1) + off;
+    const double *h = (g == 0 ? a.h0 : a.h1) + off, *h2 = a.h1 + off;
     const double *ord = a.ord + curve * a.ord_stride;
     const double dfg = g == 1 ? 2.0 * a.df : a.df, fming = g == 1 ? 2.0 * a.fmin : a.fmin;
     const double nfftd = (double)a.nfft, tmin = ord[0];
-    double *out = a.grids + 2 * ((curve * a.ngrid + slot) * a.nfft + g0);
-    double acc_re[kDepCells], acc_im[kDepCells];
+    double acc_re[kDepCells], acc_im[kDepCells], twin_re[kDepCells], twin_im[kDepCells];
 #pragma unroll
-    for (int c = 0; c < kDepCells; ++c) acc_re[c] = acc_im[c] = 0.0;
+    for (int c = 0; c < kDepCells; ++c) acc_re[c] = acc_im[c] = twin_re[c] = twin_im[c] = 0.0;
     auto position = [&](int64_t i) -> double {   // tnorm of sample i (no wrap: fmod changes nothing, kept for form)
         return fmod(((t[i] - tmin) * nfftd) * dfg, nfftd);
     };
-    const double lo = (double)(g0 - 4), hi = (double)(g0 + kDepCells + 4);
-    if (n > 0 && deposit_in_order(ord, nfftd, dfg) && lo <= ((ord[1] - tmin) * nfftd) * dfg) {
-        int64_t first = 0, last = n;   // first sample with position >= lo
+    if (n > 0 && deposit_in_order(ord, nfftd, dfg)) {
+        // The samples that can reach this workgroup's cells, [w_first, w_last): first sample at or beyond
+        // G0 - 4 and first at or beyond G0 + span + 4, by a 256-ary search made by the whole workgroup
+        // (three rounds for 1e5 samples instead of 17 dependent loads per thread).
+        const double bound[2] = {(double)(G0 - 4), (double)(G0 + kDepSpan + 4)};
+        int64_t lo[2] = {0, 0}, hi[2] = {n, n};   // the answer lies in [lo, hi]
+        for (;;) {
+            const int64_t w0 = hi[0] - lo[0], w1 = hi[1] - lo[1];
+            if (w0 <= 0 && w1 <= 0) break;        // (workgroup-uniform)
+            bool pred[2];
+            int64_t step[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int64_t w = hi[q] - lo[q];
+                step[q] = (w + kBlock - 1) / kBlock;
+                const int64_t at = lo[q] + (int64_t)tid * step[q];
+                pred[q] = w > 0 && at < hi[q] && position(at) >= bound[q];
+            }
+            __syncthreads();
+            const unsigned long long b0 = __ballot(pred[0]), b1 = __ballot(pred[1]);
+            if (lane == 0) {
+                s_ballot[0][wave] = b0;
+                s_ballot[1][wave] = b1;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (hi[q] - lo[q] <= 0) continue;
+                int first = kBlock;               // first probe at or beyond the bound
+                for (int w = kBlock / 64 - 1; w >= 0; --w)
+                    if (s_ballot[q][w]) first = w * 64 + __builtin_ctzll(s_ballot[q][w]);
+                const int64_t probes = (hi[q] - lo[q] + step[q] - 1) / step[q];   // probes inside [lo, hi)
+                const int64_t new_hi = first < probes ? lo[q] + (int64_t)first * step[q] : hi[q];
+                const int64_t new_lo = first > 0 ? lo[q] + (int64_t)((first < probes ? first : probes) - 1) * step[q] + 1 : lo[q];
+                lo[q] = new_lo < new_hi ? new_lo : new_hi;
+                hi[q] = new_hi;
+            }
+        }
+        const int64_t w_first = lo[0], w_last = lo[1];
+        const bool staged = w_last - w_first <= kDepStage;   // (workgroup-uniform)
+        if (staged)
+            for (int64_t i = w_first + tid; i < w_last; i += kBlock) s_pos[i - w_first] = position(i);
+        __syncthreads();
+        auto pos_at = [&](int64_t i) -> double { return staged ? s_pos[i - w_first] : position(i); };
+        const double lo_t = (double)(g0 - 4), hi_t = (double)(g0 + kDepCells + 4);
+        int64_t first = w_first, last = w_last;   // first sample of the workgroup's range at or beyond lo_t
         while (first < last) {
             const int64_t mid = (first + last) >> 1;
-            if (position(mid) >= lo) last = mid; else first = mid + 1;
+            if (pos_at(mid) >= lo_t) last = mid; else first = mid + 1;
         }
-        for (int64_t i = first; i < n; ++i) {
-            const double tn = position(i);
-            if (!(tn < hi)) break;
+        for (int64_t i = first; i < w_last && g0 < live; ++i) {
+            const double tn = pos_at(i);
+            if (!(tn < hi_t)) break;
+            int64_t ilo = 0;
+            const bool whole = tn - __builtin_floor(tn) == 0.0;
+            if (!whole) {
+                ilo = (int64_t)(tn - 2.0);
+                ilo = ilo < 0 ? 0 : (ilo > a.nfft - 4 ? a.nfft - 4 : ilo);
+                if (ilo + 3 < g0 || ilo >= g0 + kDepCells) continue;
+            } else if ((int64_t)tn < g0 || (int64_t)tn >= g0 + kDepCells) {
+                continue;
+            }
             const double dt = t[i] - tmin;
             const double ang = (6.283185307179586 * fming) * dt;
             double sn, cs;
             sincos(ang, &sn, &cs);
             const double hre = h[i] * cs, him = h[i] * sn;
-            if (tn - __builtin_floor(tn) == 0.0) {   // whole position: one deposit
+            const double kre = twin ? h2[i] * cs : 0.0, kim = twin ? h2[i] * sn : 0.0;
+            if (whole) {   // one deposit
                 const int64_t ind = (int64_t)tn;
 #pragma unroll
                 for (int c = 0; c < kDepCells; ++c)
                     if (ind == g0 + c) {
                         acc_re[c] += hre;
                         acc_im[c] += him;
+                        twin_re[c] += kre;
+                        twin_im[c] += kim;
                     }
                 continue;
             }
-            int64_t ilo = (int64_t)(tn - 2.0);
-            ilo = ilo < 0 ? 0 : (ilo > a.nfft - 4 ? a.nfft - 4 : ilo);
-            if (ilo + 3 < g0 || ilo >= g0 + kDepCells) continue;
             const double x = tn - (double)ilo;
             const double prod = ((x * (x - 1.0)) * (x - 2.0)) * (x - 3.0);
-            const double nre = hre * prod, nim = him * prod;
+            const double nre = hre * prod, nim = him * prod, mre = kre * prod, mim = kim * prod;
             const double den[4] = {6.0, -2.0, 2.0, -6.0};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int64_t ind = ilo + (3 - j);
+                if (ind < g0 || ind >= g0 + kDepCells) continue;
                 const double d = den[j] * (tn - (double)ind);
                 const double vre = nre / d, vim = nim / d;
+                const double ure = twin ? mre / d : 0.0, uim = twin ? mim / d : 0.0;
 #pragma unroll
                 for (int c = 0; c < kDepCells; ++c)
                     if (ind == g0 + c) {
                         acc_re[c] += vre;
                         acc_im[c] += vim;
+                        twin_re[c] += ure;
+                        twin_im[c] += uim;
                     }
             }
         }
     }
+    if (g0 >= live) return;
+    double *out = a.grids + 2 * ((curve * a.ngrid + g) * a.nfft + g0);
+    double *out2 = a.grids + 2 * ((curve * a.ngrid + 2) * a.nfft + g0);
 #pragma unroll
     for (int c = 0; c < kDepCells; ++c)
         if (g0 + c < a.nfft) {
             out[2 * c] = acc_re[c];
             out[2 * c + 1] = acc_im[c];
+            if (twin) {
+                out2[2 * c] = twin_re[c];
+                out2[2 * c + 1] = twin_im[c];
+            }
         }
 }
 
@@ -822,8 +893,7 @@ cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1, in
 }
 
 void launch_deposit(hipStream_t st, const DepositArgs &d, int64_t n_curves) {
-    const int64_t threads = (d.nfft + kDepCells - 1) / kDepCells;
-    hipLaunchKernelGGL(glsfft_deposit_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock), (unsigned)(n_curves * d.ngrid)),
+    hipLaunchKernelGGL(glsfft_deposit_kernel, dim3((unsigned)((d.nfft + kDepSpan - 1) / kDepSpan), (unsigned)(n_curves * d.nslots)),
                        dim3(kBlock), 0, st, d);
 }
 
@@ -889,8 +959,9 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
     const cplx *result[3] = {nullptr, nullptr, nullptr};
     if (nfft * 32 <= mall && (int64_t)ngrid * nfft * 32 > mall) {
         for (int g = 0; g < ngrid; ++g) {
-            launch_deposit(st, DepositArgs{d_t, wy, w, nullptr, n, 0, 1, g, scal + 2, 0, nfft, df, fmin,
-                                           reinterpret_cast<double *>(grid[g])}, 1);
+            if (g < 2)   // (slot 0 fills grid 2 along with grid 0: same positions and phases)
+                launch_deposit(st, DepositArgs{d_t, wy, w, nullptr, n, 0, ngrid, g, 1, scal + 2, 0, nfft, df, fmin,
+                                               reinterpret_cast<double *>(grid[0])}, 1);
             SpreadArgs sp;
             sp.t = d_t;
             sp.h = g == 0 ? wy : w;
@@ -907,7 +978,7 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
             result[g] = inverse_fft(st, grid[g], scratch + g * nfft, nfft, 1, nf, LiveArgs{scal + 2, 0, 1, g, df});
         }
     } else {
-        launch_deposit(st, DepositArgs{d_t, wy, w, nullptr, n, 0, ngrid, 0, scal + 2, 0, nfft, df, fmin,
+        launch_deposit(st, DepositArgs{d_t, wy, w, nullptr, n, 0, ngrid, 0, 2, scal + 2, 0, nfft, df, fmin,
                                        reinterpret_cast<double *>(grid[0])}, 1);
         if (n > 0) {
             Spread3Args s3{d_t, wy, w, scal, n, nfft, df, fmin, reinterpret_cast<double *>(grid[0]), fit_mean};
@@ -1043,7 +1114,7 @@ int pdc_gls_scan_fft_batch(const double *t, const double *y, const double *dy, c
         FftBatchArgs c = a;
         c.offsets = a.offsets + c0;
         c.scal = const_cast<double *>(scal_all) + c0 * 8;
-        launch_deposit(st, DepositArgs{a.t, a.wy, a.w, c.offsets, 0, shared_t, ngrid, 0, c.scal + 2, 8, nfft, df, fmin,
+        launch_deposit(st, DepositArgs{a.t, a.wy, a.w, c.offsets, 0, shared_t, ngrid, 0, 2, c.scal + 2, 8, nfft, df, fmin,
                                        reinterpret_cast<double *>(c.grids)}, bc);
         if (n_max > 0) {
             hipLaunchKernelGGL(glsfft_spread_batch_kernel,
@@ -1099,7 +1170,7 @@ int pdc_trig_sums_fft(const double *t, const double *h, int64_t n, double df, in
     PDC_HIP(hipMemcpyAsync(d_h, h, n * 8, hipMemcpyHostToDevice, st));
     double *scal = reinterpret_cast<double *>(static_cast<char *>(d_work) + nfft * 32);
     PDC_HIP(hipMemcpyAsync(scal, scal_host, sizeof(scal_host), hipMemcpyHostToDevice, st));
-    launch_deposit(st, DepositArgs{(double *)d_t, (double *)d_h, (double *)d_h, nullptr, n, 0, 1, 0, scal + 2, 0, nfft, df,
+    launch_deposit(st, DepositArgs{(double *)d_t, (double *)d_h, (double *)d_h, nullptr, n, 0, 1, 0, 1, scal + 2, 0, nfft, df,
                                    fmin, reinterpret_cast<double *>(grid)}, 1);
     SpreadArgs s{(double *)d_t, (double *)d_h, scal, tmin, n, nfft, df, fmin,
                  reinterpret_cast<double *>(grid)};
