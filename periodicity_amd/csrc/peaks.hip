@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void highest_peak_kernel(const double *powe
 constexpr int kPkBlock = 256;
 constexpr int kPkMaxBlocks = 4096;   // LDS: two doubles per block
 constexpr int kPkMaxK = 8;
-constexpr int kPkPre = 16;           // by prominence: the first walks go to the 16 highest maxima
+constexpr int kPkPre = 16;           // by prominence: the first walks go to the min(k + 4, 16) highest maxima
 constexpr int kPkChunk = 1024;       // bins per sweep step
 constexpr int kPkFusedShift = 8;     // 256-bin blocks = one wave's stretch of a chunk: extrema come with the sweep
 static_assert(kPkChunk / kPkBlock * 64 == 1 << kPkFusedShift, "a wave's stretch is one block");
@@ -419,7 +419,8 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
     };
 
     const int K = a.k < kPkMaxK ? a.k : kPkMaxK;
-    sweep(std::true_type{}, a.by_prominence ? kPkPre : K);
+    const int pre = K + 4 < kPkPre ? K + 4 : kPkPre;   // by prominence: the first walks go to the `pre` highest maxima
+    sweep(std::true_type{}, a.by_prominence ? pre : K);
     // lowest sample of the row (NaN aside): prominence <= height - row_min
     for (int64_t b = tid; b < a.nblk; b += kPkBlock) row_min = bmin[b] < row_min ? bmin[b] : row_min;
     for (int o = 32; o > 0; o >>= 1) {
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
         walk_candidates();                       // the winners' prominences
         if (tid < nwin) win_p[tid] = cp[tid];
     } else {
-        rank_candidates(kPkPre, false);
+        rank_candidates(pre, false);
         walk_candidates();                       // the highest maxima
         nwin = rank_candidates(K, true);
         if (tid == 0) s_thr = nwin == K ? win_key[K - 1] : -inf;   // tau
