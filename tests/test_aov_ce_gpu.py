@@ -29,6 +29,18 @@ def test_aov_matches_published_formula(n, n_periods, n_bins):
     assert np.argmax(got) == np.argmax(want)
 
 
+def test_aov_agrees_with_the_reference_pinned_pdm_kernel():
+    """Non-overlapping bins: Theta_AoV = ((N - 1) / theta_PDM - (N - r)) / (r - 1) - the AoV scan against the
+    PDM scan whose parity is pinned by the reference's own goldens (G7)."""
+    t, x = curve(6000, 77, t_shift=-250.0)
+    n = t.size
+    periods = np.linspace(2.0, 60.0, 500)
+    sigma = float(np.var(x, ddof=1))
+    for r in (5, 10, 16):
+        theta = _cabi.pdm_scan(t, x, periods, r, 1, sigma)
+        np.testing.assert_allclose(_cabi.aov_scan(t, x, periods, r), ((n - 1) / theta - (n - r)) / (r - 1), rtol=1e-9)
+
+
 def test_aov_split_mode_negative_times_and_edges():
     t, x = curve(40_000, 5, t_shift=-12345.5)                   # few periods x many samples: split mode
     periods = np.linspace(3.0, 40.0, 90)

@@ -137,3 +137,34 @@ def test_stringlength_seam(golden_dir):
                                rtol=1e-13)
     np.testing.assert_allclose(co.stringlength_scan(g["t_even"], g["m_even"], g["periods_even"]),
                                g["ell_even"], rtol=1e-13)
+
+
+# ---- the two scans the reference only lists as TODO (phase.py:11-15) ---------------------------------
+def test_aov_restatement_is_tied_to_the_reference_pdm():
+    """With non-overlapping bins (nc = 1) Stellingwerf's theta and the AoV statistic are functions of the
+    same two sums of squares: Theta_AoV = ((N - 1) / theta - (N - r)) / (r - 1).  `pdm_scan` is pinned bit
+    for bit to the reference's `_pdm` (test_oracle_vs_reference, G7), so this ties the AoV restatement -
+    its bins, means and degrees of freedom - to code the reference does have."""
+    rng = np.random.default_rng(41)
+    n = 3000
+    t = np.sort(rng.uniform(0, float(n), n)) - 400.0
+    x = 1.0 + 0.5 * np.sin(2 * np.pi * t / 13.7) + 0.1 * rng.standard_normal(n)
+    periods = np.linspace(2.0, 50.0, 60)
+    for r in (5, 10, 16):
+        theta = so.pdm_scan(t, x, periods, nb=r, nc=1)
+        np.testing.assert_allclose(so.aov_scan(t, x, periods, r), ((n - 1) / theta - (n - r)) / (r - 1), rtol=1e-10)
+
+
+def test_conditional_entropy_restatement_equals_joint_minus_marginal_entropy():
+    """H_c = H(m, phi) - H(phi), computed here with numpy's own 2-d histogram and scipy's entropy."""
+    from scipy.stats import entropy
+    rng = np.random.default_rng(43)
+    n = 4000
+    t = np.sort(rng.uniform(0, float(n), n))
+    x = np.sin(2 * np.pi * t / 7.3) + 0.3 * rng.standard_normal(n)
+    mag = so.magnitude_bins(x, 6)
+    for period in (3.1, 7.3, 14.6, 29.0):
+        phi = (t / period) % 1
+        cells, _, _ = np.histogram2d(phi, mag, bins=(12, 6), range=((0.0, 1.0), (-0.5, 5.5)))
+        want = entropy(cells.ravel()) - entropy(cells.sum(axis=1))
+        np.testing.assert_allclose(so.cond_entropy(t, mag, period, 12, 6), want, rtol=1e-10)
