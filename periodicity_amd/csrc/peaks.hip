@@ -404,8 +404,10 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
                 if (FIRST) ++mine;
                 if (FIRST && !(vv >= thr)) continue;
                 const int slot = atomicAdd(&s_ncand, 1);
-                ci[slot] = (i + ahead - 1) / 2;
-                ch[slot] = vv;
+                const int64_t mid = (i + ahead - 1) / 2;
+                ci[slot] = mid;
+                ch[slot] = mid == i ? vv : x[mid];   // (a flat top of zeros may mix +0.0 and -0.0: the reported
+                                                     // height is the midpoint's own bits, as scipy's x[peaks])
                 cp[slot] = nan;
             }
             if (FIRST) {

@@ -92,6 +92,7 @@ def check_topk(x, k, by_prominence):
     assert got["count"][0] == count
     np.testing.assert_array_equal(got["indices"][0], idx)
     np.testing.assert_array_equal(got["heights"][0], height)
+    assert np.array_equal(np.signbit(got["heights"][0]), np.signbit(height))    # (-0.0 stays -0.0)
     np.testing.assert_array_equal(got["prominences"][0], prom)     # same subtraction: bit-exact
     for r in range(k):
         if idx[r] < 0:
@@ -140,6 +141,8 @@ def test_topk_candidate_list_and_chunk_edges():
         rows.append(y)
     for m in (1023, 1024, 1025, 2049, 255, 257, 3):
         rows.append(rng.standard_normal(m))
+    zeros = rng.standard_normal(2000) * (rng.random(2000) < 0.03) * 5     # flat floors of mixed +0.0 / -0.0
+    rows.append(zeros)
     infs = rng.standard_normal(3000)
     infs[[100, 2000]] = -np.inf
     infs[1500] = np.inf
