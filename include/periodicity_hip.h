@@ -173,7 +173,7 @@ int pdc_gls_batch_highest_peak(const double *t, const double *y, const double *d
                                double f0, double delta, int64_t nf, int fit_mean, int psd,
                                int64_t *idx_out, double *val_out, int device);
 
-/* The k <= 8 highest (by_prominence == 0: FSeries.psort_by_peak, core.py:944-946) or most prominent
+/* The k <= 16 highest (by_prominence == 0: FSeries.psort_by_peak, core.py:944-946) or most prominent
  * (psort_by_prominence :948-950, period_at_highest_prominence :957-961) find_peaks() maxima of each
  * spectrum, found and ranked on the device: count[b] = number of maxima scipy.signal.find_peaks(x,
  * prominence=0.0) reports; idx/height/prominence are [n_curves][k], ranked descending, padded with

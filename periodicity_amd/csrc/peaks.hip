@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void highest_peak_kernel(const double *powe
 // scipy prominences (scipy.signal.peak_prominences, wlen=None: walk left and right from the peak while
 // x[i] <= x[peak], remember the lowest sample on each side, prominence = x[peak] - max of the two),
 // ranked by height (psort_by_peak, core.py:944-946) or by prominence (psort_by_prominence :948-950,
-// period_at_highest_prominence :957-961); only the first k <= 8 come back, together with the two
+// period_at_highest_prominence :957-961); only the first k <= 16 come back, together with the two
 // sign changes of x - (x[peak] - height/2) that periods_at_half_max (:963-978) looks up: the last
 // one left of the peak and the first one from the peak rightwards (np.diff(np.signbit(..)), core.py:362).
 // Equal heights / prominences rank the lower bin first (numpy's argsort leaves that order open).
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(kBlock) void highest_peak_kernel(const double *powe
 // the total order (key descending, bin ascending), so a maximum collected twice is reported once.
 constexpr int kPkBlock = 256;
 constexpr int kPkMaxBlocks = 4096;   // LDS: two doubles per block
-constexpr int kPkMaxK = 8;
-constexpr int kPkPre = 16;           // by prominence: the first walks go to the min(k + 4, 16) highest maxima
+constexpr int kPkMaxK = 16;
+constexpr int kPkPre = 20;           // by prominence: the first walks go to the k + 4 highest maxima
 constexpr int kPkChunk = 1024;       // bins per sweep step
 constexpr int kPkFusedShift = 8;     // 256-bin blocks = one wave's stretch of a chunk: extrema come with the sweep
 static_assert(kPkChunk / kPkBlock * 64 == 1 << kPkFusedShift, "a wave's stretch is one block");
@@ -421,7 +421,8 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
     };
 
     const int K = a.k < kPkMaxK ? a.k : kPkMaxK;
-    const int pre = K + 4 < kPkPre ? K + 4 : kPkPre;   // by prominence: the first walks go to the `pre` highest maxima
+    const int pre = K + 4;   // by prominence: the first walks go to the `pre` highest maxima
+    static_assert(kPkMaxK + 4 <= kPkPre && kPkPre <= kPkCap / 4, "win_* and the candidate list hold the first walks");
     sweep(std::true_type{}, a.by_prominence ? pre : K);
     // lowest sample of the row (NaN aside): prominence <= height - row_min
     for (int64_t b = tid; b < a.nblk; b += kPkBlock) row_min = bmin[b] < row_min ? bmin[b] : row_min;
