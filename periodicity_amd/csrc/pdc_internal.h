@@ -32,6 +32,11 @@ int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr);
 // hipSetDevice + range check; every entry point starts here.
 int use_device(int device);
 
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) on the CURRENT device,
+// once per (device, kernel): the attribute belongs to the device's copy of the kernel, so a process that
+// drives several GPUs has to set it on each of them.
+int allow_dynamic_lds(const void *kernel, int bytes);
+
 // Serialises the host-level entry points that share the cached workspace of one device.
 struct DeviceLock {
     explicit DeviceLock(int device);

@@ -406,13 +406,10 @@ size_t lds_bytes(int m0, int block, int bytes_per_bin = 12) {   // 12: sum + cou
     return stage + (size_t)(m0 + 1) * block * bytes_per_bin + (size_t)(m0 + 2) * 8 + 64;
 }
 
-// dynamic-LDS limit of a kernel, raised once per process (not on every call)
+// dynamic-LDS limit of a kernel, raised once per device (not on every call)
 template <typename Kernel>
 int allow_lds(Kernel kernel) {
-    static const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    150 * 1024);
-    PDC_HIP(e);
-    return PDC_OK;
+    return allow_dynamic_lds((const void *)kernel, 150 * 1024);
 }
 
 // kind 0: PDM theta; 1: AoV over nb phase bins; 2: conditional entropy over nb x nc cells

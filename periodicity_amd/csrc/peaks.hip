@@ -563,9 +563,7 @@ int launch_topk(hipStream_t st, PeakArgs a, int64_t n_curves) {
     a.tile = 0;
     const size_t lds = (size_t)(a.nblk > 0 ? a.nblk : 1) * 16 + (size_t)kPkCap * 24 + 16;
     PDC_REQUIRE(lds <= 150 * 1024, "peaks_topk: %lld bins per spectrum need %zu bytes of LDS", (long long)a.nf, lds);
-    static const hipError_t attr =
-        hipFuncSetAttribute((const void *)peaks_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    PDC_HIP(attr);
+    PDC_TRY(allow_dynamic_lds((const void *)peaks_topk_kernel, 150 * 1024));
     hipLaunchKernelGGL(peaks_topk_kernel, dim3((unsigned)n_curves), dim3(kPkBlock), lds, st, a);
     PDC_HIP(hipGetLastError());
     return PDC_OK;

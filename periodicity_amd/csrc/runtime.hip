@@ -124,6 +124,29 @@ static int release_stream_scratch() {
     return PDC_OK;
 }
 
+int allow_dynamic_lds(const void *kernel, int bytes) {
+    struct Done {
+        int device;
+        const void *kernel;
+        int bytes;
+    };
+    static std::mutex mu;
+    static std::vector<Done> done;
+    int device = -1;
+    PDC_HIP(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lk(mu);
+    for (Done &d : done)
+        if (d.device == device && d.kernel == kernel) {
+            if (d.bytes >= bytes) return PDC_OK;
+            PDC_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            d.bytes = bytes;
+            return PDC_OK;
+        }
+    PDC_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.push_back({device, kernel, bytes});
+    return PDC_OK;
+}
+
 DeviceLock::DeviceLock(int d) : device(d) {
     if (d >= 0 && d < (int)g_devices.size()) g_devices[d]->call_mutex.lock();
 }

@@ -1529,10 +1529,7 @@ template <int KMAX, typename IdxT = unsigned short, int NB = fast::kNB, bool MUL
 int launch_fast(const fast::FastArgs &a, int64_t grid, hipStream_t st) {
     const int64_t slice = MULTI ? fast::FL<IdxT>::capacity : a.n;
     const size_t lds = (size_t)fast::FL<IdxT>::fixed + (size_t)((slice + 64 + 7) & ~(int64_t)7) * sizeof(IdxT);
-    static const hipError_t attr = hipFuncSetAttribute((const void *)fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       fast::kLdsTotalDyn);
-    PDC_HIP(attr);
+    PDC_TRY(allow_dynamic_lds((const void *)fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI>, fast::kLdsTotalDyn));
     hipLaunchKernelGGL((fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     return PDC_OK;
 }
@@ -1611,14 +1608,12 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
         using L = Lds<unsigned short>;
         const int64_t slice = n < L::capacity ? n : L::capacity;
         const size_t lds = (size_t)L::fixed + (size_t)((slice + 7) & ~(int64_t)7) * 2;
-        PDC_HIP(hipFuncSetAttribute((const void *)sl_scan_kernel<unsigned short, kBuckets>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDC_TRY(allow_dynamic_lds((const void *)sl_scan_kernel<unsigned short, kBuckets>, (int)lds));
         hipLaunchKernelGGL((sl_scan_kernel<unsigned short, kBuckets>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     } else {
         using L = Lds<unsigned>;
         const size_t lds = (size_t)L::fixed + (size_t)L::capacity * 4;
-        PDC_HIP(hipFuncSetAttribute((const void *)sl_scan_kernel<unsigned, kBucketsLarge>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PDC_TRY(allow_dynamic_lds((const void *)sl_scan_kernel<unsigned, kBucketsLarge>, (int)lds));
         hipLaunchKernelGGL((sl_scan_kernel<unsigned, kBucketsLarge>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     }
     PDC_HIP(hipGetLastError());
