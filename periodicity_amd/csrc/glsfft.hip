@@ -402,7 +402,7 @@ __device__ __forceinline__ void spread_one(double *grid, int64_t nfft, double dt
 // ---- the same deposits without atomics, in a fixed order ---------------------------------------------
 // With time stamps in non-decreasing order and a grid that does not wrap ((tmax - tmin) nfft df < nfft -
 // always so for the default n >= 1 samples per peak), grid positions rise with the sample index, so the
-// samples that touch a cell are consecutive.  One thread owns four consecutive cells: a binary search
+// samples that touch a cell are consecutive.  A thread owns groups of four consecutive cells: a search
 // finds the first sample that can reach them, the deposits are added in sample order and stored once -
 // bitwise reproducible (the atomic kernels above add in arrival order), and the memset goes away: every
 // cell up to the last sample's reach is written (the empty ones with zero), the rest is read by nobody.
@@ -423,7 +423,8 @@ struct DepositArgs {
 };
 
 constexpr int kDepCells = 4;                     // cells per thread
-constexpr int kDepSpan = kDepCells * kBlock;     // cells per workgroup
+constexpr int kDepIters = 4;                     // groups of cells per thread: the workgroup's search is shared
+constexpr int kDepSpan = kDepCells * kBlock * kDepIters;   // cells per workgroup
 constexpr int kDepStage = 1024;                  // positions of a workgroup's samples kept in LDS
 
 __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
     const int64_t curve = blockIdx.y / a.nslots;
     const int g = a.slot_first + (int)(blockIdx.y - curve * a.nslots);
     const bool twin = g == 0 && a.ngrid == 3;
-    const int64_t G0 = (int64_t)blockIdx.x * kDepSpan, g0 = G0 + (int64_t)tid * kDepCells;
+    const int64_t G0 = (int64_t)blockIdx.x * kDepSpan;
     // (cells from `live` on are never read: the first FFT pass takes them as zero)
     const int64_t live = live_cells(LiveArgs{a.ord, a.ord_stride, 1, g, a.df}, curve, a.nfft);
     if (G0 >= live) return;   // (workgroup-uniform)
@@ -444,13 +445,13 @@ __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
     const double *ord = a.ord + curve * a.ord_stride;
     const double dfg = g == 1 ? 2.0 * a.df : a.df, fming = g == 1 ? 2.0 * a.fmin : a.fmin;
     const double nfftd = (double)a.nfft, tmin = ord[0];
-    double acc_re[kDepCells], acc_im[kDepCells], twin_re[kDepCells], twin_im[kDepCells];
-#pragma unroll
-    for (int c = 0; c < kDepCells; ++c) acc_re[c] = acc_im[c] = twin_re[c] = twin_im[c] = 0.0;
-    auto position = [&](int64_t i) -> double {   // tnorm of sample i (no wrap: fmod changes nothing, kept for form)
-        return fmod(((t[i] - tmin) * nfftd) * dfg, nfftd);
+    auto position = [&](int64_t i) -> double {   // tnorm of sample i; used only when the grid does not wrap,
+        return ((t[i] - tmin) * nfftd) * dfg;    // where the reference's "% nfft" (fmod) returns its argument
     };
-    if (n > 0 && deposit_in_order(ord, nfftd, dfg)) {
+    const bool ordered = n > 0 && deposit_in_order(ord, nfftd, dfg);   // (workgroup-uniform)
+    int64_t w_first = 0, w_last = 0;
+    bool staged = false;
+    if (ordered) {
         // The samples that can reach this workgroup's cells, [w_first, w_last): first sample at or beyond
         // G0 - 4 and first at or beyond G0 + span + 4, by a 256-ary search made by the whole workgroup
         // (three rounds for 1e5 samples instead of 17 dependent loads per thread).
@@ -488,19 +489,28 @@ __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
                 hi[q] = new_hi;
             }
         }
-        const int64_t w_first = lo[0], w_last = lo[1];
-        const bool staged = w_last - w_first <= kDepStage;   // (workgroup-uniform)
+        w_first = lo[0];
+        w_last = lo[1];
+        staged = w_last - w_first <= kDepStage;   // (workgroup-uniform)
         if (staged)
             for (int64_t i = w_first + tid; i < w_last; i += kBlock) s_pos[i - w_first] = position(i);
         __syncthreads();
-        auto pos_at = [&](int64_t i) -> double { return staged ? s_pos[i - w_first] : position(i); };
+    }
+    auto pos_at = [&](int64_t i) -> double { return staged ? s_pos[i - w_first] : position(i); };
+    for (int it = 0; it < kDepIters; ++it) {
+    const int64_t g0 = G0 + ((int64_t)it * kBlock + tid) * kDepCells;
+    if (g0 >= live) break;
+    double acc_re[kDepCells], acc_im[kDepCells], twin_re[kDepCells], twin_im[kDepCells];
+#pragma unroll
+    for (int c = 0; c < kDepCells; ++c) acc_re[c] = acc_im[c] = twin_re[c] = twin_im[c] = 0.0;
+    if (ordered) {
         const double lo_t = (double)(g0 - 4), hi_t = (double)(g0 + kDepCells + 4);
         int64_t first = w_first, last = w_last;   // first sample of the workgroup's range at or beyond lo_t
         while (first < last) {
             const int64_t mid = (first + last) >> 1;
             if (pos_at(mid) >= lo_t) last = mid; else first = mid + 1;
         }
-        for (int64_t i = first; i < w_last && g0 < live; ++i) {
+        for (int64_t i = first; i < w_last; ++i) {
             const double tn = pos_at(i);
             if (!(tn < hi_t)) break;
             int64_t ilo = 0;
@@ -552,7 +562,6 @@ __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
             }
         }
     }
-    if (g0 >= live) return;
     double *out = a.grids + 2 * ((curve * a.ngrid + g) * a.nfft + g0);
     double *out2 = a.grids + 2 * ((curve * a.ngrid + 2) * a.nfft + g0);
 #pragma unroll
@@ -565,6 +574,7 @@ __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
                 out2[2 * c + 1] = twin_im[c];
             }
         }
+    }
 }
 
 // All three (or two) grids of one curve in a single launch: (w*y @ df), (w @ 2 df), (w @ df).
