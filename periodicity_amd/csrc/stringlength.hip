@@ -752,6 +752,7 @@ struct FastArgs {
     double *rlen;               // [grid][nr_pad]  string length inside each range
     int64_t n_pad, nr_pad;
     unsigned *ghist;            // [grid][kNBLarge]  first sorted position of every coarse bucket (several slices)
+    unsigned short *gbucket;    // [grid][2 n_pad]   coarse bucket of every sample, written by P1 (several slices)
 };
 
 // RN(t / period) without the division: y = RN(1 / period); q0 = RN(t y) is within 1.5 ulp of the
@@ -885,9 +886,10 @@ __device__ __forceinline__ void phases4(const double (&t)[4], double period, dou
 }
 
 // MULTI = false: all samples fit one LDS slice (KMAX = samples per thread kept in registers between P1
-// and P2, 16-bit indices, NB = 2048).  MULTI = true (kCapacity < N <= 13 slices): one histogram pass over
-// all samples (rolled loop) gives the bucket starts, then the period is worked off in slices of
-// consecutive buckets that fit LDS - all samples folded again and this slice's scattered into order[],
+// and P2, 16-bit indices, NB = 2048).  MULTI = true (kCapacity < N <= 16 slices): one histogram pass over
+// all samples (rolled loop) gives the bucket starts and leaves every sample's bucket id in global scratch,
+// then the period is worked off in slices of consecutive buckets that fit LDS - the bucket ids read back
+// and this slice's samples scattered into order[],
 // range table, P3a, P3b - with 32-bit indices and NB = 8192 coarse buckets.
 template <int KMAX, typename IdxT = unsigned short, int NB = kNB, bool MULTI = false>
 __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
@@ -917,6 +919,8 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
     unsigned *fine_w = reinterpret_cast<unsigned *>(wbuf + wave * kWaveBytes + kRCap * 8);
     IdxT *idx_w = reinterpret_cast<IdxT *>(wbuf + wave * kWaveBytes + kRCap * 8 + (kWFine + 4) * 4);
     unsigned *ghist = MULTI ? a.ghist + (int64_t)blockIdx.x * NB : nullptr;
+    unsigned short *gb = MULTI ? a.gbucket + (int64_t)blockIdx.x * a.n_pad * 2 : nullptr;
+    static_assert(!MULTI || NB <= 65536, "bucket ids are kept as 16-bit numbers");
 
     for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
         const double period = a.periods[p];
@@ -1033,7 +1037,11 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 fold8(tv, phi);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (i0 + u * kBlock < n) atomicAdd(&hist[coarse_of<NB>(phi[u])], 1u);
+                    if (i0 + u * kBlock < n) {
+                        const int b = coarse_of<NB>(phi[u]);
+                        atomicAdd(&hist[b], 1u);
+                        gb[i0 + u * kBlock] = (unsigned short)b;   // (read back once per slice: no second fold)
+                    }
             }
         }
         __syncthreads();
@@ -1106,39 +1114,22 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             __syncthreads();   // every thread has read what it needs from the start offsets
             if (tid < 16) defer[tid] = tid == 15 ? (unsigned)kWaves : 0u;
             {
-                // hist[b] still holds the START of every bucket: fold all samples again and keep this slice's.
-                // (Grouping all samples once in global scratch instead costs more up to ~10 slices: a random
-                // 4-byte store to global memory runs at 1.05e11/s, 2.6x slower than a random load.)
-                double nx[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = tid + u * kBlock;
-                    nx[u] = a.t[i < n ? i : n - 1];
-                }
+                // hist[b] still holds the START of every bucket: every sample's bucket id is read back (2
+                // bytes, coalesced) and this slice's samples go to order[].  (Grouping all samples once in
+                // global scratch instead costs a random 4-byte store per sample and period - 1.05e11/s, 2.6x
+                // slower than a random load; folding every sample again per slice - the first version of this
+                // path - cost as much as the ranges from five slices on.)
                 for (int i0 = tid; i0 < n; i0 += 8 * kBlock) {
-                    double tv[8], phi[8];
+                    unsigned short bk[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) tv[u] = nx[u];
-                    if (i0 + 8 * kBlock < n) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int i = i0 + (8 + u) * kBlock;
-                            nx[u] = a.t[i < n ? i : n - 1];
-                        }
-                    }
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        double a4[4], p4[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) a4[u] = tv[4 * h + u];
-                        phases4(a4, period, y, safe, p4);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) phi[4 * h + u] = p4[u];
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * kBlock;
+                        bk[u] = gb[i < n ? i : n - 1];
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int i = i0 + u * kBlock;
-                        const int b = coarse_of<NB>(phi[u]);
+                        const int b = (int)bk[u];
                         if (i < n && b >= b0 && b < b1) order[atomicAdd(&hist[b], 1u) - (unsigned)consumed] = (IdxT)i;
                     }
                 }
@@ -1574,9 +1565,11 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
     a.ghist = a.gorder + (may_need_partition(n) ? grid * a.n_pad : 0);
     hipStream_t st = (hipStream_t)stream;
     static const bool general_only = [] { const char *e = getenv("PDC_SL_GENERAL"); return e && e[0] == '1'; }();
-    // beyond ~13 slices the per-slice fold of the fast kernel costs more than the general kernel's one-off
-    // grouping in global scratch (x 2048 periods: N = 3e5 21.2 against 22.2 ms, N = 4.5e5 44.5 against 35.5 ms)
-    if (n >= 1 && !general_only && n <= 13 * (int64_t)fast::FL<unsigned>::capacity) {
+    // beyond ~16 slices the general kernel (one-off grouping of the indices in global scratch) is ahead: the
+    // fast kernel's per-slice passes over the bucket ids and its 16-byte gathers (table > L2) grow with N
+    // (x 2048 periods: N = 3.3e5 20.5 against 23.2 ms, N = 4.5e5 39.3 against 35.3 ms); PDC_SL_FAST_SLICES moves it
+    static const int max_slices = [] { const char *e = getenv("PDC_SL_FAST_SLICES"); return e ? atoi(e) : 16; }();
+    if (n >= 1 && !general_only && n <= max_slices * (int64_t)fast::FL<unsigned>::capacity) {
         fast::FastArgs f;
         f.t = d_t;
         f.m = d_m;
@@ -1592,6 +1585,7 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
         f.n_pad = a.n_pad;
         f.nr_pad = a.nr_pad;
         f.ghist = a.ghist;
+        f.gbucket = reinterpret_cast<unsigned short *>(a.gorder);   // (the general kernel's grouping area: [grid][n_pad] words)
         const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
         char *table = static_cast<char *>(work) + scratch_bytes(n, n_periods, partition);
         f.rec = reinterpret_cast<const fast::rec_t *>(table);

@@ -15,7 +15,7 @@ from periodicity_amd import _cabi  # noqa: E402
 
 def one_case(rng):
     n = int(rng.choice([1, 2, 5, 64, 255, 256, 257, 1000, 4096, 9000, 20481, 36865, 50000, 52112, 52113, 70000,
-                        131071, 208000, 311689],
+                        131071, 208000, 383617],
                        p=[.04, .04, .04, .05, .05, .05, .05, .15, .1, .1, .08, .06, .06, .04, .03, .03, .01, .01, .01]))
     kind = rng.integers(0, 6)
     if kind == 0:
