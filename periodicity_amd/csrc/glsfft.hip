@@ -95,7 +95,8 @@ struct LiveArgs {
 };
 
 __device__ __forceinline__ bool deposit_in_order(const double *ord, double nfftd, double dfg) {
-    return ord[2] != 0.0 && ((ord[1] - ord[0]) * nfftd) * dfg < nfftd;
+    const double span = ord[1] - ord[0];   // (NaN or -inf when no time stamp is a number: the atomic kernels then)
+    return ord[2] != 0.0 && span >= 0.0 && (span * nfftd) * dfg < nfftd;
 }
 
 // cells [0, live) of transform `y` of the launch may be non-zero
