@@ -55,6 +55,11 @@ struct GlsArgs {
     double *raw_c;
     double *blk_max;   // [n_curves * tiles] or nullptr
     int64_t *blk_arg;
+    // few frequencies x many samples (single curve): the samples are cut into gridDim.y parts of z_len
+    // (a multiple of the chunk size); every part leaves its six sums per frequency in `partial`
+    // ([part][6][nf]) and gls_finish_kernel adds the parts in order and applies the epilogue
+    int64_t z_len = 0;
+    double *partial = nullptr;
 };
 
 struct PrepArgs {
@@ -287,7 +292,9 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         return make_double2(__builtin_fma(x.x, y.y, x.y * y.x), __builtin_fma(x.y, y.y, -(x.x * y.x)));
     };
     const int slot_a = col * 8 + (lane >> 3), slot_b = COLS * 8 + (lane & 7);
-    for (int64_t base = 0; base < n; base += kChunk) {
+    const int64_t s_begin = a.partial ? (int64_t)blockIdx.y * a.z_len : 0;
+    const int64_t s_end = a.partial ? (s_begin + a.z_len < n ? s_begin + a.z_len : n) : n;
+    for (int64_t base = s_begin; base < s_end; base += kChunk) {
         __syncthreads();  // everyone is done with the previous chunk's tables
         // ---- per-sample rotation tables (two threads per sample) ------------------------------------
         // Thread (col, lane) starts at phase theta_tile + (64 col + 8 a + b) Theta with a = lane / 8,
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         if (tid < 2 * kChunk) {
             const int il = tid >> 1;
             // (rows past the end of the curve are never accumulated; they only need finite input)
-            const bool live = base + il < n;
+            const bool live = base + il < s_end;
             const double tp = live ? a.rec[(off + base + il) * 6 + 5] : 0.0;
             const double sqw = live ? a.rec[(off + base + il) * 6 + 1] : 0.0;
             double2 step1, cur;
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
             }
         }
         __syncthreads();
-        const int cnt = (int)((n - base) < kChunk ? (n - base) : kChunk);
+        const int cnt = (int)((s_end - base) < kChunk ? (s_end - base) : kChunk);
         const int i_end = cnt < (part + 1) * (kChunk / SPLIT) ? cnt : (part + 1) * (kChunk / SPLIT);
         const int i_beg = part * (kChunk / SPLIT);
         // Software pipeline: everything sample i+1 needs is requested while sample i is accumulated;
@@ -443,6 +450,23 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     }
     const bool owner = part == 0;  // only part 0 holds complete sums
 
+    if (MODE != MODE_RAW && a.partial) {   // (workgroup-uniform) this sample part's sums; gls_finish_kernel does the rest
+        double *out = a.partial + (int64_t)blockIdx.y * 6 * a.nf;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int64_t j = jl + k;
+            if (owner && j < a.nf) {
+                out[j] = Sh[k];
+                out[a.nf + j] = Ch[k];
+                out[2 * a.nf + j] = S[k];
+                out[3 * a.nf + j] = C[k];
+                out[4 * a.nf + j] = SS[k];
+                out[5 * a.nf + j] = SC[k];
+            }
+        }
+        return;
+    }
+
     const double *sc = a.scal + curve * 4;
     if (MODE == MODE_RAW) {
         // undo the t0 shift: sums were taken over t' = t - t0
@@ -502,6 +526,68 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
             }
             a.blk_max[L] = best;
             a.blk_arg[L] = best_j;
+        }
+    }
+}
+
+// Sample parts of gls_scan_kernel (GlsArgs::partial) added up in a fixed order + the epilogue: four lanes
+// per frequency (lane q of the quad takes parts q, q + 4, ...; the quad's four sums are then added in a
+// fixed tree), 64 frequencies and one block maximum (for the peak reduction) per workgroup.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void gls_finish_kernel(GlsArgs a, int parts) {
+    __shared__ double red_v[4];
+    __shared__ long long red_i[4];
+    const int tid = threadIdx.x, q4 = tid & 3;
+    const int64_t j = (int64_t)blockIdx.x * (kBlock / 4) + (tid >> 2);
+    double best = 0.0;
+    long long best_j = -1;
+    const bool live = j < a.nf;
+    double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (live) {
+        for (int z = q4; z < parts; z += 4) {
+            const double *in = a.partial + (int64_t)z * 6 * a.nf + j;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) v[q] += in[q * a.nf];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {   // (lane ^ 1, then lane ^ 2: the same tree in every quad)
+        v[q] += __shfl_xor(v[q], 1, 64);
+        v[q] += __shfl_xor(v[q], 2, 64);
+    }
+    if (live && q4 == 0) {
+        const double *sc = a.scal;
+        const double p = gls_power<MODE>(v[0], v[1], v[2], v[3], v[4], v[5], sc[0], sc[1], sc[2], a.psd);
+        if (a.power) a.power[j] = p;
+        if (p == p) {
+            best = p;
+            best_j = j;
+        }
+    }
+    if (a.blk_max) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_down(best, o, 64);
+            const long long oj = __shfl_down(best_j, o, 64);
+            if (oj >= 0 && (best_j < 0 || ov > best || (ov == best && oj < best_j))) {
+                best = ov;
+                best_j = oj;
+            }
+        }
+        if ((tid & 63) == 0) {
+            red_v[tid >> 6] = best;
+            red_i[tid >> 6] = best_j;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int wv = 1; wv < 4; ++wv) {
+                if (red_i[wv] >= 0 && (best_j < 0 || red_v[wv] > best)) {
+                    best = red_v[wv];
+                    best_j = red_i[wv];
+                }
+            }
+            a.blk_max[blockIdx.x] = best;
+            a.blk_arg[blockIdx.x] = best_j;
         }
     }
 }
@@ -713,29 +799,50 @@ __global__ __launch_bounds__(64) void gls_peak_kernel(const double *blk_max, con
 // share its issue slots, so time ~ ceil(waves / 1024) * (12 + 8K) / S (up to a constant): few large
 // tiles when the grid fills the chip, many small ones when it does not.  A lone wave per SIMD cannot
 // hide its own LDS/dependency stalls (+10 %).  PDC_GLS_K / PDC_GLS_S override for experiments.
-void tile_shape(int64_t n_curves, int64_t nf, int *K_out, int *S_out) {
+// sample parts (GlsArgs::partial): single curves only, parts x nf <= 2^20 cells of six sums (50 MB)
+constexpr int64_t kPartialCells = (int64_t)1 << 20;
+constexpr int kPartsMax = 512;
+
+void tile_shape(int64_t n_curves, int64_t nf, int64_t n_total, bool may_split, int *K_out, int *S_out, int *Z_out) {
     static const int envK = [] { const char *e = getenv("PDC_GLS_K"); return e ? atoi(e) : 0; }();
     static const int envS = [] { const char *e = getenv("PDC_GLS_S"); return e ? atoi(e) : 0; }();
+    static const int envZ = [] { const char *e = getenv("PDC_GLS_Z"); return e ? atoi(e) : 0; }();
+    // parts of at least 2048 samples, and no more cells of partial sums than the workspace holds
+    int64_t z_max = 1;
+    if (may_split && n_curves == 1 && n_total >= 16384) {
+        z_max = n_total / 2048;
+        const int64_t room = kPartialCells / (nf > 0 ? nf : 1);
+        z_max = z_max < room ? z_max : room;
+        z_max = z_max > kPartsMax ? kPartsMax : (z_max < 1 ? 1 : z_max);
+    }
     double best = 1e300;
-    int bk = 8, bs = 1;
+    int bk = 8, bs = 1, bz = 1;
     for (int K : {16, 8, 4}) {
         if (envK && K != envK) continue;
         for (int S : {1, 2, 4}) {
             if (envS && S != envS) continue;
-            const double waves = (double)n_curves * (double)((nf + 64 * K - 1) / (64 * K)) * S;
+            const double tile_waves = (double)n_curves * (double)((nf + 64 * K - 1) / (64 * K)) * S;
+            // a short grid over a long curve: cut the samples into parts until every SIMD has ~2 waves
+            int64_t Z = (int64_t)__builtin_ceil(2048.0 / tile_waves);
+            Z = Z > z_max ? z_max : (Z < 1 ? 1 : Z);
+            if (envZ) Z = envZ > z_max ? z_max : envZ;
+            const double waves = tile_waves * (double)Z;
             const double rounds = __builtin_ceil(waves / 1024.0);
-            double cost = rounds * (12.0 + 8.0 * K) / S;
+            double cost = rounds * (12.0 + 8.0 * K) / ((double)S * (double)Z);
             if (waves / 1024.0 <= 1.0) cost *= 1.10;
             cost *= 1.0 + 0.02 * (S > 2 ? S - 2 : 2 - S);  // measured: two waves per tile is the sweet spot
+            if (Z > 1) cost *= 1.02;                       // (the finishing launch)
             if (cost < best) {
                 best = cost;
                 bk = K;
                 bs = S;
+                bz = (int)Z;
             }
         }
     }
     *K_out = bk;
     *S_out = bs;
+    *Z_out = bz;
 }
 
 template <int MODE, int S>
@@ -757,8 +864,9 @@ void launch_scan(int K, int S, dim3 grid, hipStream_t st, const GlsArgs &a) {
 }
 
 struct WorkLayout {
-    int64_t rec, scal, parts, blk_max, blk_arg, total;
+    int64_t rec, scal, parts, blk_max, blk_arg, partial, total;
 };
+
 
 WorkLayout layout(int64_t n_total, int64_t n_curves, int64_t nf) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
@@ -769,7 +877,10 @@ WorkLayout layout(int64_t n_total, int64_t n_curves, int64_t nf) {
     w.parts = w.scal + up(n_curves * 32);
     w.blk_max = w.parts + up(4 * kPrepParts * 8);
     w.blk_arg = w.blk_max + up(n_curves * tiles_max * 8);
-    w.total = w.blk_arg + up(n_curves * tiles_max * 8);
+    w.partial = w.blk_arg + up(n_curves * tiles_max * 8);
+    // (grows with nf: a plan sized for a long grid also serves short ones)
+    const int64_t cells = kPartsMax * nf < kPartialCells ? kPartsMax * nf : kPartialCells;
+    w.total = w.partial + (n_curves == 1 ? up(cells * 6 * 8) : 0);
     return w;
 }
 
@@ -871,8 +982,8 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     }
     PDC_HIP(hipGetLastError());
 
-    int K, S;
-    tile_shape(n_curves, nf, &K, &S);
+    int K, S, parts;
+    tile_shape(n_curves, nf, n_total, mode != MODE_RAW, &K, &S, &parts);
     GlsArgs a;
     a.rec = p.rec;
     a.offsets = d_offsets;
@@ -892,7 +1003,16 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     a.blk_max = peaks ? reinterpret_cast<double *>(base + w.blk_max) : nullptr;
     a.blk_arg = peaks ? reinterpret_cast<int64_t *>(base + w.blk_arg) : nullptr;
     const int64_t G = a.n_curves * a.tiles;
-    const dim3 grid((unsigned)(((G + 7) / 8) * 8));
+    dim3 grid((unsigned)(((G + 7) / 8) * 8));
+    // A short grid over a long curve leaves most of the chip idle (nf = 1e4: 40 tiles of four waves for
+    // 1024 SIMDs): tile_shape then cuts the samples into parts as well.
+    if (parts > 1) {
+        const int64_t chunk = 128;
+        a.z_len = ((n_total + parts - 1) / parts + chunk - 1) / chunk * chunk;
+        parts = (int)((n_total + a.z_len - 1) / a.z_len);
+        a.partial = reinterpret_cast<double *>(base + w.partial);
+        grid.y = (unsigned)parts;
+    }
     if (mode == MODE_FIT_MEAN) {
         launch_scan<MODE_FIT_MEAN>(K, S, grid, st, a);
     } else if (mode == MODE_NO_MEAN) {
@@ -901,9 +1021,18 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
         launch_scan<MODE_RAW>(K, S, grid, st, a);
     }
     PDC_HIP(hipGetLastError());
+    int64_t peak_tiles = a.tiles;
+    if (a.partial) {
+        peak_tiles = (nf + kBlock / 4 - 1) / (kBlock / 4);   // 64 frequencies per finishing workgroup
+        if (mode == MODE_FIT_MEAN)
+            hipLaunchKernelGGL(gls_finish_kernel<MODE_FIT_MEAN>, dim3((unsigned)peak_tiles), dim3(kBlock), 0, st, a, parts);
+        else
+            hipLaunchKernelGGL(gls_finish_kernel<MODE_NO_MEAN>, dim3((unsigned)peak_tiles), dim3(kBlock), 0, st, a, parts);
+        PDC_HIP(hipGetLastError());
+    }
     if (peaks) {
         hipLaunchKernelGGL(gls_peak_kernel, dim3((unsigned)n_curves), dim3(64), 0, st, a.blk_max,
-                           a.blk_arg, a.tiles, d_amax, d_argmax);
+                           a.blk_arg, peak_tiles, d_amax, d_argmax);
         PDC_HIP(hipGetLastError());
     }
     return PDC_OK;

@@ -213,6 +213,29 @@ def test_shared_time_axis_many_curves_share_the_trigonometry(with_dy, fit_mean, 
     assert np.array_equal(amax, amax2) and np.array_equal(argmax, argmax2)
 
 
+def test_short_grid_over_a_long_curve_splits_the_samples():
+    """Few frequencies x many samples (a zoom on one peak, a small slab of a sharded grid): the scan cuts the
+    samples into parts as well, every part leaves six sums per frequency and a finishing kernel adds them in a
+    fixed order.  Same answers as the exact sums, as an unsplit call (a two-curve batch never splits), the
+    same bits on every call, and the device-side peak reduction follows."""
+    t, y, dy = synth(60_000, 31, period=12.3)
+    for nf, fit_mean, psd in ((3000, True, False), (700, False, True), (37, True, True), (20_000, True, False)):
+        delta = 2e-7                                                  # a zoom on the peak
+        f0 = 1 / 12.3 - (nf // 2) * delta
+        freq = f0 + np.arange(nf) * delta                             # (the device's own fill rule)
+        got = _cabi.gls_scan(t, y, dy, f0, delta, nf, fit_mean, psd)
+        assert np.array_equal(got, _cabi.gls_scan(t, y, dy, f0, delta, nf, fit_mean, psd))
+        pick = np.unique(np.linspace(0, nf - 1, 300).astype(int))        # (the exact sums cost N x nf in long double)
+        assert_tier_e(got[pick], co.gls_power_exact(t, y, dy, freq[pick], fit_mean, psd))
+        offsets = np.array([0, t.size, 2 * t.size])
+        twice, amax, argmax = _cabi.gls_scan_batch(np.tile(t, 2), np.tile(y, 2), np.tile(dy, 2), offsets, f0, delta, nf,
+                                                   fit_mean, psd, want_power=True, want_peaks=True)
+        np.testing.assert_allclose(got, twice[0], rtol=1e-9, atol=1e-14 * np.nanmax(got))   # (other summation order)
+        _, a1, j1 = _cabi.gls_scan_batch(t, y, dy, offsets[:2], f0, delta, nf, fit_mean, psd, want_power=False,
+                                         want_peaks=True)
+        assert j1[0] == int(np.nanargmax(got)) and a1[0] == got[j1[0]]
+
+
 def test_slabs_tile_the_grid_bitwise():
     t, y, dy = synth(3000, 21)
     freq = np.arange(0.0001, 0.9, 0.00011)
