@@ -100,6 +100,24 @@ def test_gls_direct_random_cases(seed=2024):
         assert_close_spectrum(got, want, 1e-6, 1e-9, extra=wobble), case
 
 
+def test_gls_long_curves_on_short_grids_random(seed=77):
+    """n >= 16384 samples on grids short enough for the scan to cut the samples into parts as well."""
+    rng = np.random.default_rng(seed)
+    for case in range(10):
+        n = int(rng.choice([16384, 20001, 50000, 131072]))
+        t, y, dy = random_curve(rng, n)
+        nf = int(rng.choice([1, 5, 64, 300, 1000, 5000, 40000]))
+        span = max(t[-1] - t[0], 1.0)
+        f0, delta = rng.uniform(0.05, 2.0) / span, rng.uniform(0.01, 0.3) / span
+        fit_mean, psd = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        err = dy if rng.integers(0, 3) else None
+        got = _cabi.gls_scan(t, y, err, f0, delta, nf, fit_mean, psd)
+        assert np.array_equal(got, _cabi.gls_scan(t, y, err, f0, delta, nf, fit_mean, psd), equal_nan=True), case
+        pick = np.unique(np.linspace(0, nf - 1, 64).astype(int))
+        want, wobble = exact_power_and_sensitivity(t, y, err, f0 + delta * pick, fit_mean, psd)
+        assert_close_spectrum(got[pick], want, 1e-6, 1e-9, extra=wobble), case
+
+
 def test_gls_batch_random_ragged(seed=7):
     rng = np.random.default_rng(seed)
     for case in range(8):
