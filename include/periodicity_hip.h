@@ -122,7 +122,9 @@ int pdc_trig_sums(const double *t, const double *w, int64_t n,
 
 /* Device-resident form used by bench.py: inputs already in HBM, no synchronisation.
  * `work` is scratch of at least pdc_gls_work_bytes(n_total, n_curves, nf) bytes on the same
- * device.  d_offsets may be NULL for a single curve of n_total samples. */
+ * device (non-decreasing in n_total and in nf: a buffer sized for the largest call serves all; for a
+ * single curve it includes up to 48 MiB for the partial sums of short grids, whose samples are cut
+ * into parts as well).  d_offsets may be NULL for a single curve of n_total samples. */
 int64_t pdc_gls_work_bytes(int64_t n_total, int64_t n_curves, int64_t nf);
 int pdc_gls_scan_dev(int device, void *stream,
                      const double *d_t, const double *d_y, const double *d_dy,
