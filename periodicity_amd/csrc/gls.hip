@@ -59,6 +59,7 @@ struct GlsArgs {
     // (a multiple of the chunk size); every part leaves its six sums per frequency in `partial`
     // ([part][6][nf]) and gls_finish_kernel adds the parts in order and applies the epilogue
     int64_t z_len = 0;
+    int parts = 1, parts_by_xcd = 0;   // parts_by_xcd: part z runs on XCD z % 8 (1-D grid), see the kernel
     double *partial = nullptr;
 };
 
@@ -267,7 +268,16 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     // contiguous run of logical tiles so the tiles of one curve share that XCD's L2.
     const int64_t G = a.n_curves * a.tiles;
     const int64_t per_xcd = (G + 7) / 8;
-    const int64_t L = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    int64_t L = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    int zpart = blockIdx.y;
+    if (a.parts_by_xcd) {
+        // sample parts (8 or more): XCD e takes the parts e, e + 8, ... with all their tiles, so that an XCD's
+        // L2 streams one or two stretches of the records at a time instead of all of them
+        const int64_t q = blockIdx.x / 8, zi = q / G;
+        L = q - zi * G;
+        zpart = (int)(blockIdx.x % 8) + 8 * (int)zi;
+        if (zpart >= a.parts) return;
+    }
     if (L >= G) return;
     const int64_t curve = L / a.tiles;
     const int64_t tile = L - curve * a.tiles;
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         return make_double2(__builtin_fma(x.x, y.y, x.y * y.x), __builtin_fma(x.y, y.y, -(x.x * y.x)));
     };
     const int slot_a = col * 8 + (lane >> 3), slot_b = COLS * 8 + (lane & 7);
-    const int64_t s_begin = a.partial ? (int64_t)blockIdx.y * a.z_len : 0;
+    const int64_t s_begin = a.partial ? (int64_t)zpart * a.z_len : 0;
     const int64_t s_end = a.partial ? (s_begin + a.z_len < n ? s_begin + a.z_len : n) : n;
     for (int64_t base = s_begin; base < s_end; base += kChunk) {
         __syncthreads();  // everyone is done with the previous chunk's tables
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     const bool owner = part == 0;  // only part 0 holds complete sums
 
     if (MODE != MODE_RAW && a.partial) {   // (workgroup-uniform) this sample part's sums; gls_finish_kernel does the rest
-        double *out = a.partial + (int64_t)blockIdx.y * 6 * a.nf;
+        double *out = a.partial + (int64_t)zpart * 6 * a.nf;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int64_t j = jl + k;
@@ -825,6 +835,7 @@ void tile_shape(int64_t n_curves, int64_t nf, int64_t n_total, bool may_split, i
             // a short grid over a long curve: cut the samples into parts until every SIMD has ~2 waves
             int64_t Z = (int64_t)__builtin_ceil(2048.0 / tile_waves);
             Z = Z > z_max ? z_max : (Z < 1 ? 1 : Z);
+            if (Z >= 8) Z -= Z % 8;   // eight or more parts are dealt to the 8 XCDs: equal shares
             if (envZ) Z = envZ > z_max ? z_max : envZ;
             const double waves = tile_waves * (double)Z;
             const double rounds = __builtin_ceil(waves / 1024.0);
@@ -1011,7 +1022,13 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
         a.z_len = ((n_total + parts - 1) / parts + chunk - 1) / chunk * chunk;
         parts = (int)((n_total + a.z_len - 1) / a.z_len);
         a.partial = reinterpret_cast<double *>(base + w.partial);
-        grid.y = (unsigned)parts;
+        a.parts = parts;
+        if (parts >= 8) {
+            a.parts_by_xcd = 1;
+            grid.x = (unsigned)(8 * ((parts + 7) / 8) * G);
+        } else {
+            grid.y = (unsigned)parts;
+        }
     }
     if (mode == MODE_FIT_MEAN) {
         launch_scan<MODE_FIT_MEAN>(K, S, grid, st, a);
