@@ -434,9 +434,10 @@ int phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, cons
     static const int env_split = [] { const char *e = getenv("PDC_PDM_SPLIT"); return e ? atoi(e) : -1; }();
     const int64_t groups0 = (n_periods + 63) / 64;
     const int nbins = last + 1;
-    if (kind != 2 && env_split != 0 && groups0 * 4 < 1024 && n >= 32 * kChunk && lds_bytes(last, 256) <= 150 * 1024 &&
+    // (four workgroups of four waves fit a CU: below ~3000 waves the period grid alone leaves SIMD slots empty)
+    if (kind != 2 && env_split != 0 && groups0 * 4 < 3072 && n >= 32 * kChunk && lds_bytes(last, 256) <= 150 * 1024 &&
         (size_t)nbins * 64 * 16 <= 150 * 1024) {
-        int64_t n_z = (2048 + groups0 * 4 - 1) / (groups0 * 4);
+        int64_t n_z = (4096 + groups0 * 4 - 1) / (groups0 * 4);
         const int64_t max_z = n / (8 * kChunk);
         n_z = n_z < max_z ? n_z : max_z;
         const int64_t z_len = ((n + n_z - 1) / n_z + kChunk - 1) / kChunk * kChunk;
