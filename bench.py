@@ -74,12 +74,12 @@ def throughput_grid(t, nf):
 
 # which sources a profiled kernel was built from: a PMC summary entry is refused once any of them changed
 KERNEL_SOURCES = {
-    "gls_": ("gls.hip", "gls_epilogue.h", "pdc_internal.h"),
-    "pdm_": ("pdm.hip", "pdc_internal.h"),
-    "sl_": ("stringlength.hip", "pdc_internal.h"),
-    "fft_": ("glsfft.hip", "pdc_internal.h"),
-    "glsfft_": ("glsfft.hip", "gls_epilogue.h", "pdc_internal.h"),
-    "peak": ("peaks.hip", "pdc_internal.h"),
+    "gls_": ("gls.hip", "gls_epilogue.h", "pdc_device.h"),
+    "pdm_": ("pdm.hip", "pdc_device.h"),
+    "sl_": ("stringlength.hip", "pdc_device.h"),
+    "fft_": ("glsfft.hip", "pdc_device.h"),
+    "glsfft_": ("glsfft.hip", "gls_epilogue.h", "pdc_device.h"),
+    "peak": ("peaks.hip", "pdc_device.h"),
 }
 
 

@@ -45,6 +45,10 @@ int pdc_device_count(int *count);
 int pdc_device_info(int device, char *name, int name_len, int *cu_count, int64_t *hbm_bytes,
                     int *clock_khz);
 int pdc_release(void);                                   /* free all cached device workspaces */
+/* How many device (hipMalloc) and page-locked host (hipHostMalloc) allocations the library has made in
+ * this process so far: a cached path (plans, the one-shot `_multi` entry points, the per-device
+ * workspaces) shows no increase on its second call with the same sizes. */
+int pdc_alloc_counts(int64_t *device_allocs, int64_t *pinned_allocs);
 
 /* device memory + events for callers that keep data resident (bench.py, tests) */
 int pdc_malloc(int device, int64_t bytes, void **dptr);
@@ -85,6 +89,16 @@ int pdc_gls_scan_batch(const double *t, const double *y, const double *dy,
                        int fit_mean, int psd,
                        double *power_out, double *amax_out, int64_t *argmax_out, int device);
 
+/* A batch of curves dealt to `n_devices` GPU slots in contiguous groups of ceil(n_curves / n_devices)
+ * curves (batches shard over curves, no exchange); arguments and outputs as
+ * pdc_gls_scan_batch.  With shared_t != 0 this is GLS.bootstrap (spectral.py:140-152) over several GPUs.
+ * A device may be listed more than once; per-slot buffers are kept between calls. */
+int pdc_gls_scan_batch_multi(const double *t, const double *y, const double *dy,
+                             const int64_t *offsets, int64_t n_curves, int shared_t,
+                             double f0, double delta, int64_t nf, int fit_mean, int psd,
+                             double *power_out, double *amax_out, int64_t *argmax_out,
+                             const int *devices, int n_devices);
+
 /* One periodogram with the grid split into contiguous equal slabs over `n_devices` GPUs of this
  * node (one process, one stream per device), gathered with one RCCL all-gather over xGMI. */
 int pdc_gls_scan_multi(const double *t, const double *y, const double *dy, int64_t n,
@@ -106,6 +120,16 @@ int pdc_gls_scan_multi(const double *t, const double *y, const double *dy, int64
  *            holds the whole array after the gather)
  *   kernel_ms  HIP-event time of the latest slab scan on devices[0] */
 int pdc_gls_plan_create(const int *devices, int n_devices, int64_t n_max, int64_t nf_max, void **plan);
+/* The same plan with `n_slots` LOGICAL slots on ONE physical device ("loopback"): every slot has its own
+ * buffers, streams and events, scans its own slab, and the all-gather is replaced by the equivalent
+ * device-to-device copies on the communication streams (RCCL refuses two ranks on one device).  The slab
+ * arithmetic, padded tails (nf % n_slots != 0, nf < n_slots), generation reuse and event ordering are
+ * those of the N-GPU plan, so they can be tested on a 1-GPU box.  PDC_PLAN_EXCHANGE=copy makes
+ * pdc_gls_plan_create use the copy exchange between distinct devices too (hipMemcpyPeerAsync). */
+int pdc_gls_plan_create_loopback(int device, int n_slots, int64_t n_max, int64_t nf_max, void **plan);
+/* n_slots; the size RCCL reports for the plan's communicator (ncclCommCount; 0 = no communicator);
+ * exchange: 0 none (one slot), 1 RCCL all-gather, 2 device-to-device copies.  Any pointer may be NULL. */
+int pdc_gls_plan_info(void *plan, int *n_slots, int *rccl_ranks, int *exchange);
 int pdc_gls_plan_upload(void *plan, const double *t, const double *y, const double *dy, int64_t n);
 int pdc_gls_plan_scan(void *plan, double f0, double delta, int64_t nf, int fit_mean, int psd);
 int pdc_gls_plan_wait(void *plan);
@@ -228,12 +252,47 @@ int pdc_cond_entropy_scan_dev(int device, void *stream, const double *d_t, const
                               int64_t n, const double *d_periods, int64_t n_periods, int n_phase,
                               int n_mag, double *d_entropy);
 
+/* The four phase-fold statistics behind one device-resident entry with an EXPLICIT workspace (nothing is
+ * cached per stream, nothing is allocated): kind 0 = PDM theta (nb, nc, sigma as pdc_pdm_scan), 1 = AoV
+ * (nb = n_bins), 2 = conditional entropy (nb = n_phase, nc = n_mag, v = magnitude bins), 3 = StringLength
+ * (v = m; nb, nc, sigma ignored).  `work` holds at least pdc_phase_work_bytes(kind, n, n_periods, nb, nc)
+ * bytes (0 for most PDM shapes: only short period grids over long curves split the samples and need
+ * scratch for partial histograms). */
+int64_t pdc_phase_work_bytes(int kind, int64_t n, int64_t n_periods, int nb, int nc);
+int pdc_phase_scan_dev(int kind, int device, void *stream, const double *d_t, const double *d_v, int64_t n,
+                       const double *d_periods, int64_t n_periods, int nb, int nc, double sigma,
+                       double *d_out, void *work, int64_t work_bytes);
+
 /* The period grid cut into contiguous slabs over `n_devices` GPUs of this node (one process, one
  * stream per slab; a device may be listed more than once).  Replaces the multiprocessing.Pool
- * fan-out of phase.py:182-186; trial periods are independent, so there is no exchange step. */
+ * fan-out of phase.py:182-186; trial periods are independent, so there is no exchange step.  The
+ * per-slot buffers, streams and page-locked staging are kept between calls, keyed by the device list
+ * (pdc_release() frees them): a second call of the same size allocates nothing. */
 int pdc_pdm_scan_multi(const double *t, const double *x, int64_t n,
                        const double *periods, int64_t n_periods, int nb, int nc, double sigma,
                        double *theta_out, const int *devices, int n_devices);
+int pdc_aov_scan_multi(const double *t, const double *x, int64_t n, const double *periods, int64_t n_periods,
+                       int n_bins, double *theta_out, const int *devices, int n_devices);
+int pdc_cond_entropy_scan_multi(const double *t, const double *mag_bin, int64_t n, const double *periods,
+                                int64_t n_periods, int n_phase, int n_mag, double *entropy_out,
+                                const int *devices, int n_devices);
+
+/* The same fan-out as a persistent plan for callers that scan repeatedly or want the samples resident
+ * (bench.py, a survey loop): replaces Pool(cores).map of phase.py:69-70,185-186.
+ *   create    streams, events and (for n_max / n_periods_max > 0) buffers per slot; a device may repeat
+ *   upload    replicate (t, v) on every slot through page-locked staging (async)
+ *   scan      kind as pdc_phase_scan_dev; enqueue per slot: its slab of `periods` H2D, the scan, its slab
+ *             of results D2H into page-locked memory; returns without waiting
+ *   wait / download   drain; copy the n_periods results of the latest scan to `out`
+ *   kernel_ms HIP-event time of the latest scan's kernels, the slowest slot */
+int pdc_phase_plan_create(const int *devices, int n_devices, int64_t n_max, int64_t n_periods_max, void **plan);
+int pdc_phase_plan_upload(void *plan, const double *t, const double *v, int64_t n);
+int pdc_phase_plan_scan(void *plan, int kind, const double *periods, int64_t n_periods, int nb, int nc,
+                        double sigma);
+int pdc_phase_plan_wait(void *plan);
+int pdc_phase_plan_download(void *plan, double *out, int64_t n_periods);
+int pdc_phase_plan_kernel_ms(void *plan, float *ms);
+int pdc_phase_plan_destroy(void *plan);
 
 /* ---- String Length -----------------------------------------------------------------------------
  * Replaces pool.map(StringLength._stringlength, periods) (phase.py:45-51, 69-70) including the

@@ -27,6 +27,7 @@ PROTOTYPES = {
     "pdc_device_count": (_I, [C.POINTER(_I)]),
     "pdc_device_info": (_I, [_I, C.c_char_p, _I, C.POINTER(_I), c_int64_p, C.POINTER(_I)]),
     "pdc_release": (_I, []),
+    "pdc_alloc_counts": (_I, [c_int64_p, c_int64_p]),
     "pdc_malloc": (_I, [_I, _L, C.POINTER(_VP)]),
     "pdc_free": (_I, [_I, _VP]),
     "pdc_memcpy_h2d": (_I, [_I, _VP, _VP, _L]),
@@ -43,8 +44,11 @@ PROTOTYPES = {
     "pdc_gls_scan": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _L, _I, _I, _VP, _I]),
     "pdc_gls_scan_batch": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _L, _I, _I,
                                 _VP, _VP, _VP, _I]),
+    "pdc_gls_scan_batch_multi": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _I, _I, _VP, _VP, _VP, _VP, _I]),
     "pdc_gls_scan_multi": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _I, _I, _VP, _VP, _I]),
     "pdc_gls_plan_create": (_I, [_VP, _I, _L, _L, C.POINTER(_VP)]),
+    "pdc_gls_plan_create_loopback": (_I, [_I, _I, _L, _L, C.POINTER(_VP)]),
+    "pdc_gls_plan_info": (_I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "pdc_gls_plan_upload": (_I, [_VP, _VP, _VP, _VP, _L]),
     "pdc_gls_plan_scan": (_I, [_VP, _D, _D, _L, _I, _I]),
     "pdc_gls_plan_wait": (_I, [_VP]),
@@ -76,7 +80,18 @@ PROTOTYPES = {
     "pdc_stringlength_scan": (_I, [_VP, _VP, _L, _VP, _L, _VP, _I]),
     "pdc_stringlength_work_bytes": (_L, [_L, _L]),
     "pdc_stringlength_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _VP, _VP, _L]),
+    "pdc_phase_work_bytes": (_L, [_I, _L, _L, _I, _I]),
+    "pdc_phase_scan_dev": (_I, [_I, _I, _VP, _VP, _VP, _L, _VP, _L, _I, _I, _D, _VP, _VP, _L]),
     "pdc_pdm_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _I, _I, _D, _VP, _VP, _I]),
+    "pdc_aov_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _I, _VP, _VP, _I]),
+    "pdc_cond_entropy_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _I, _I, _VP, _VP, _I]),
+    "pdc_phase_plan_create": (_I, [_VP, _I, _L, _L, C.POINTER(_VP)]),
+    "pdc_phase_plan_upload": (_I, [_VP, _VP, _VP, _L]),
+    "pdc_phase_plan_scan": (_I, [_VP, _I, _VP, _L, _I, _I, _D]),
+    "pdc_phase_plan_wait": (_I, [_VP]),
+    "pdc_phase_plan_download": (_I, [_VP, _VP, _L]),
+    "pdc_phase_plan_kernel_ms": (_I, [_VP, C.POINTER(C.c_float)]),
+    "pdc_phase_plan_destroy": (_I, [_VP]),
     "pdc_stringlength_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _VP, _VP, _I]),
 }
 
@@ -129,6 +144,13 @@ def device_info(device=0):
             "clock_khz": clk.value}
 
 
+def alloc_counts():
+    """(device, pinned-host) allocations the library has made so far in this process."""
+    dev, pin = C.c_int64(0), C.c_int64(0)
+    check(lib().pdc_alloc_counts(C.byref(dev), C.byref(pin)))
+    return dev.value, pin.value
+
+
 def default_device():
     return int(os.environ.get("PERIODICITY_AMD_DEVICE", "0"))
 
@@ -170,7 +192,7 @@ def gls_scan(t, y, dy, f0, delta, nf, fit_mean=True, psd=False, j_begin=0, devic
 
 
 def gls_scan_batch(t, y, dy, offsets, f0, delta, nf, fit_mean=True, psd=False, shared_t=False,
-                   want_power=True, want_peaks=False, j_begin=0, device=None):
+                   want_power=True, want_peaks=False, j_begin=0, device=None, devices=None):
     t, y = _f64(t, "t"), _f64(y, "y")
     dy = None if dy is None else _f64(dy, "dy")
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
@@ -182,6 +204,17 @@ def gls_scan_batch(t, y, dy, offsets, f0, delta, nf, fit_mean=True, psd=False, s
     power = np.empty((nb, nf), dtype=np.float64) if want_power else None
     amax = np.empty(nb, dtype=np.float64) if want_peaks else None
     argmax = np.empty(nb, dtype=np.int64) if want_peaks else None
+    if devices is not None and len(devices) > 1:
+        # curves dealt to the device slots in contiguous groups, no exchange (pdc_gls_scan_batch_multi)
+        if j_begin:
+            raise ValueError("a batch sharded over devices scans the whole grid (j_begin must be 0)")
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        check(lib().pdc_gls_scan_batch_multi(_ptr(t), _ptr(y), _ptr(dy), _ptr(offsets), nb, int(shared_t),
+                                             f0, delta, nf, int(bool(fit_mean)), int(bool(psd)),
+                                             _ptr(power), _ptr(amax), _ptr(argmax), _ptr(devs), devs.size))
+        return power, amax, argmax
+    if devices is not None and device is None:
+        device = devices[0]
     dev = default_device() if device is None else device
     check(lib().pdc_gls_scan_batch(_ptr(t), _ptr(y), _ptr(dy), _ptr(offsets), nb, int(shared_t),
                                    f0, delta, j_begin, nf, int(bool(fit_mean)), int(bool(psd)),
@@ -206,13 +239,30 @@ class GlsPlan:
     """A persistent multi-GPU GLS plan (``pdc_gls_plan_*``): buffers, streams and RCCL communicators
     are created once; ``scan`` only enqueues (double-buffered), ``download`` waits and copies."""
 
-    def __init__(self, devices, n_max, nf_max):
+    def __init__(self, devices, n_max, nf_max, loopback_slots=None):
+        """``loopback_slots=k``: k logical slots on the ONE device listed, the all-gather replaced by the
+        equivalent device-to-device copies (``pdc_gls_plan_create_loopback``) - how the N > 1 logic runs
+        on a single GPU."""
         devs = np.ascontiguousarray(devices, dtype=np.int32)
-        self.devices = [int(d) for d in devs]
         self._plan = C.c_void_p()
-        check(lib().pdc_gls_plan_create(_ptr(devs), devs.size, int(n_max), int(nf_max),
-                                        C.byref(self._plan)))
+        if loopback_slots is not None:
+            if devs.size != 1:
+                raise ValueError("a loopback plan lives on one device")
+            self.devices = [int(devs[0])] * int(loopback_slots)
+            check(lib().pdc_gls_plan_create_loopback(int(devs[0]), int(loopback_slots), int(n_max),
+                                                     int(nf_max), C.byref(self._plan)))
+        else:
+            self.devices = [int(d) for d in devs]
+            check(lib().pdc_gls_plan_create(_ptr(devs), devs.size, int(n_max), int(nf_max),
+                                            C.byref(self._plan)))
         self.nf = 0
+
+    def info(self):
+        """``{"n_slots", "rccl_ranks", "exchange"}`` - the communicator size as RCCL reports it and which
+        exchange the plan performs ("none", "rccl", "copy")."""
+        n, r, x = C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().pdc_gls_plan_info(self._plan, C.byref(n), C.byref(r), C.byref(x)))
+        return {"n_slots": n.value, "rccl_ranks": r.value, "exchange": ("none", "rccl", "copy")[x.value]}
 
     def upload(self, t, y, dy=None):
         t, y = _f64(t, "t"), _f64(y, "y")
@@ -399,27 +449,42 @@ def pdm_scan(t, x, periods, nb, nc, sigma, device=None, devices=None):
     return out
 
 
-def aov_scan(t, x, periods, n_bins, device=None):
-    """Analysis-of-Variance statistic at every trial period (``pdc_aov_scan``)."""
+def aov_scan(t, x, periods, n_bins, device=None, devices=None):
+    """Analysis-of-Variance statistic at every trial period (``pdc_aov_scan``; ``devices`` as in
+    :func:`pdm_scan`)."""
     t, x, periods = _f64(t, "t"), _f64(x, "x"), _f64(periods, "periods")
     if x.size != t.size:
         raise ValueError("Input arrays have incompatible lengths.")
     out = np.empty(periods.size, dtype=np.float64)
+    if devices is not None and len(devices) > 1:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        check(lib().pdc_aov_scan_multi(_ptr(t), _ptr(x), t.size, _ptr(periods), periods.size, int(n_bins),
+                                       _ptr(out), _ptr(devs), devs.size))
+        return out
+    if devices is not None and device is None:
+        device = devices[0]
     dev = default_device() if device is None else device
     check(lib().pdc_aov_scan(_ptr(t), _ptr(x), t.size, _ptr(periods), periods.size, int(n_bins),
                              _ptr(out), dev))
     return out
 
 
-def cond_entropy_scan(t, mag_bin, periods, n_phase, n_mag, device=None):
+def cond_entropy_scan(t, mag_bin, periods, n_phase, n_mag, device=None, devices=None):
     """Conditional entropy at every trial period (``pdc_cond_entropy_scan``); ``mag_bin`` holds the
-    magnitude bin (0 .. n_mag-1) of every sample."""
+    magnitude bin (0 .. n_mag-1) of every sample; ``devices`` as in :func:`pdm_scan`."""
     t, mag_bin, periods = _f64(t, "t"), _f64(mag_bin, "mag_bin"), _f64(periods, "periods")
     if mag_bin.size != t.size:
         raise ValueError("Input arrays have incompatible lengths.")
     if mag_bin.size and not (np.all(mag_bin >= 0) and np.all(mag_bin < n_mag)):
         raise ValueError("magnitude bins must lie in 0 .. n_mag-1")
     out = np.empty(periods.size, dtype=np.float64)
+    if devices is not None and len(devices) > 1:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        check(lib().pdc_cond_entropy_scan_multi(_ptr(t), _ptr(mag_bin), t.size, _ptr(periods), periods.size,
+                                                int(n_phase), int(n_mag), _ptr(out), _ptr(devs), devs.size))
+        return out
+    if devices is not None and device is None:
+        device = devices[0]
     dev = default_device() if device is None else device
     check(lib().pdc_cond_entropy_scan(_ptr(t), _ptr(mag_bin), t.size, _ptr(periods), periods.size,
                                       int(n_phase), int(n_mag), _ptr(out), dev))
@@ -444,6 +509,59 @@ def stringlength_scan(t, m, periods, device=None, devices=None):
     check(lib().pdc_stringlength_scan(_ptr(t), _ptr(m), t.size, _ptr(periods), periods.size,
                                       _ptr(out), dev))
     return out
+
+
+PHASE_KINDS = {"pdm": 0, "aov": 1, "cond_entropy": 2, "stringlength": 3}
+
+
+class PhasePlan:
+    """A persistent fan-out of the phase scans over device slots (``pdc_phase_plan_*``): streams, buffers
+    and page-locked staging are created once; ``upload`` replicates the samples, ``scan`` only enqueues one
+    slab of the period grid per slot, ``download`` waits and returns the whole grid."""
+
+    def __init__(self, devices, n_max=0, n_periods_max=0):
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        self.devices = [int(d) for d in devs]
+        self._plan = C.c_void_p()
+        check(lib().pdc_phase_plan_create(_ptr(devs), devs.size, int(n_max), int(n_periods_max),
+                                          C.byref(self._plan)))
+        self.n_periods = 0
+
+    def upload(self, t, v):
+        t, v = _f64(t, "t"), _f64(v, "v")
+        if v.size != t.size:
+            raise ValueError("Input arrays have incompatible lengths.")
+        check(lib().pdc_phase_plan_upload(self._plan, _ptr(t), _ptr(v), t.size))
+
+    def scan(self, kind, periods, nb=1, nc=1, sigma=1.0):
+        periods = _f64(periods, "periods")
+        check(lib().pdc_phase_plan_scan(self._plan, PHASE_KINDS[kind], _ptr(periods), periods.size, int(nb),
+                                        int(nc), float(sigma)))
+        self.n_periods = periods.size
+
+    def wait(self):
+        check(lib().pdc_phase_plan_wait(self._plan))
+
+    def download(self):
+        out = np.empty(self.n_periods, dtype=np.float64)
+        check(lib().pdc_phase_plan_download(self._plan, _ptr(out), self.n_periods))
+        return out
+
+    def kernel_ms(self):
+        ms = C.c_float()
+        check(lib().pdc_phase_plan_kernel_ms(self._plan, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._plan:
+            check(lib().pdc_phase_plan_destroy(self._plan))
+            self._plan = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- device-resident helpers (bench.py, tests) ----------------------------------------------------

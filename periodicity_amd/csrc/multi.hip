@@ -1,12 +1,23 @@
-// One periodogram sharded over the GPUs of a node: every trial frequency is independent given
-// the (small, replicated) sample set, so the grid is cut into contiguous equal slabs, one per
-// device, and the only exchange is one RCCL all-gather of the power array over xGMI
-// (SURVEY.md §8e).  One process drives all devices (hipSetDevice + one stream per device,
-// ncclCommInitAll + grouped calls); the reference's multiprocessing.Pool fan-out
+// Scans sharded over the GPUs of a node.  Every trial frequency / trial period / light curve is
+// independent given the (small, replicated) sample set, so a grid is cut into contiguous equal
+// slabs, one per device slot; one process drives all devices (hipSetDevice + streams
+// per slot); the reference's multiprocessing.Pool fan-out
 // (/root/reference/src/periodicity/phase.py:69-70,185-186) is not reproduced.
+//
+//   GlsPlan    one periodogram, frequency slabs, ONE exchange: an all-gather of the power array - RCCL
+//              over xGMI (ncclCommInitAll + grouped in-place ncclAllGather), or, for "loopback" plans
+//              (several logical slots on one physical device: how the N > 1 logic runs on a 1-GPU box)
+//              and with PDC_PLAN_EXCHANGE=copy, the equivalent device-to-device copies;
+//   PhasePlan  PDM / AoV / conditional entropy / StringLength, period slabs, no exchange at all;
+//   batches    curves dealt to the slots in contiguous groups (pdc_gls_scan_batch_multi), no exchange.
+//
+// Everything with a fixed cost - per-slot buffers (grow-only), streams, events, pinned staging, the
+// communicators - is created once and kept: by the caller's plan handle, or, for the one-shot `_multi`
+// entry points, in a small cache keyed by the device list.
 #include <rccl/rccl.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -25,22 +36,86 @@ using namespace pdc;
 
 namespace {
 
-// A multi-GPU GLS plan: everything with a fixed cost (per-device buffers, two streams and the events
-// per device, the RCCL communicators) is created once and reused by every scan (SURVEY.md §8e
-// "create the communicator once and cache it").  Outputs are double-buffered: the all-gather of scan
-// i runs on the communication streams while the compute streams already scan i+1.
+// ---- grow-only buffers ---------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    int64_t cap = 0;
+};
+
+// (on the current device) hipFree synchronises it, so no kernel still uses the old block
+int ensure(DevBuf &b, int64_t bytes) {
+    if (bytes < 256) bytes = 256;
+    if (b.cap >= bytes) return PDC_OK;
+    if (b.p) PDC_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const int64_t want = bytes + bytes / 8;
+    PDC_TRY(device_alloc(&b.p, want));
+    b.cap = want;
+    return PDC_OK;
+}
+
+struct PinBuf {   // page-locked host staging: copies from/to it are truly asynchronous
+    void *p = nullptr;
+    int64_t cap = 0;
+};
+
+int ensure(PinBuf &b, int64_t bytes) {
+    if (bytes < 256) bytes = 256;
+    if (b.cap >= bytes) return PDC_OK;
+    if (b.p) PDC_HIP(hipHostFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    const int64_t want = bytes + bytes / 8;
+    PDC_TRY(pinned_alloc(&b.p, want));
+    b.cap = want;
+    return PDC_OK;
+}
+
+int check_devices(const char *who, const int *devices, int n_devices, bool distinct) {
+    PDC_REQUIRE(devices, "%s: NULL device list", who);
+    PDC_REQUIRE(n_devices >= 1 && n_devices <= 64, "%s: between 1 and 64 device slots", who);
+    int count = 0;
+    PDC_TRY(pdc_device_count(&count));
+    for (int a = 0; a < n_devices; ++a) {
+        PDC_REQUIRE(devices[a] >= 0 && devices[a] < count, "%s: device %d is not one of the %d visible", who,
+                    devices[a], count);
+        for (int b = a + 1; distinct && b < n_devices; ++b)
+            PDC_REQUIRE(devices[a] != devices[b], "%s: device %d listed twice", who, devices[a]);
+    }
+    return PDC_OK;
+}
+
+// contiguous equal slabs: slot i owns [i*per, min((i+1)*per, total)); trailing slots may own nothing
+struct Slab {
+    int64_t begin, count;
+};
+Slab slab_of(int64_t total, int n_slots, int i) {
+    const int64_t per = (total + n_slots - 1) / n_slots;
+    const int64_t b = (int64_t)i * per;
+    return {b, b >= total ? 0 : (total - b < per ? total - b : per)};
+}
+
+// ======================================================================================================
+// GlsPlan
+// ======================================================================================================
+enum Exchange { EX_NONE = 0, EX_RCCL = 1, EX_COPY = 2 };
+
 struct PlanDev {
     int device = -1;
     void *t = nullptr, *y = nullptr, *dy = nullptr, *work = nullptr;
     void *pow[2] = {nullptr, nullptr};
     hipStream_t compute = nullptr, comm = nullptr;
     hipEvent_t scanned[2] = {nullptr, nullptr}, gathered[2] = {nullptr, nullptr};
-    hipEvent_t k0 = nullptr, k1 = nullptr;
+    hipEvent_t k0 = nullptr, k1 = nullptr, uploaded = nullptr;
 };
 
 struct GlsPlan {
     std::vector<PlanDev> dev;
     std::vector<ncclComm_t> comms;
+    Exchange exchange = EX_NONE;
+    bool loopback = false;
+    PinBuf stage;        // (t, y, dy) staged once, then copied to every device asynchronously
     int64_t n_cap = 0, slab_cap = 0, work_cap = 0;
     int64_t n = 0, nf = 0, slab = 0;
     bool has_dy = false, timed = false;
@@ -55,6 +130,11 @@ bool force_rccl() {
     return f;
 }
 
+bool exchange_by_copy() {
+    static const bool f = [] { const char *e = getenv("PDC_PLAN_EXCHANGE"); return e && !strcmp(e, "copy"); }();
+    return f;
+}
+
 void plan_free(GlsPlan *p) {
     for (PlanDev &d : p->dev) {   // drain every stream before the communicators go
         if (d.device < 0 || hipSetDevice(d.device) != hipSuccess) continue;
@@ -65,20 +145,22 @@ void plan_free(GlsPlan *p) {
         if (c) ncclCommDestroy(c);
     for (PlanDev &d : p->dev) {
         if (d.device < 0 || hipSetDevice(d.device) != hipSuccess) continue;
-        for (hipEvent_t e : {d.scanned[0], d.scanned[1], d.gathered[0], d.gathered[1], d.k0, d.k1})
+        for (hipEvent_t e : {d.scanned[0], d.scanned[1], d.gathered[0], d.gathered[1], d.k0, d.k1, d.uploaded})
             if (e) (void)hipEventDestroy(e);
         if (d.compute) (void)hipStreamDestroy(d.compute);
         if (d.comm) (void)hipStreamDestroy(d.comm);
         for (void *q : {d.t, d.y, d.dy, d.work, d.pow[0], d.pow[1]})
             if (q) (void)hipFree(q);
     }
+    if (p->stage.p) (void)hipHostFree(p->stage.p);
     delete p;
 }
 
-int plan_build(GlsPlan *p, const int *devices, int n_devices, int64_t n_max, int64_t nf_max) {
+int plan_build(GlsPlan *p, const int *devices, int n_devices, int64_t n_max, int64_t nf_max, bool loopback) {
     p->n_cap = n_max;
     p->slab_cap = (nf_max + n_devices - 1) / n_devices;
     p->work_cap = pdc_gls_work_bytes(n_max, 1, p->slab_cap);
+    p->loopback = loopback;
     p->dev.resize(n_devices);
     for (int i = 0; i < n_devices; ++i) {
         PlanDev &d = p->dev[i];
@@ -89,18 +171,23 @@ int plan_build(GlsPlan *p, const int *devices, int n_devices, int64_t n_max, int
         for (int g = 0; g < 2; ++g) {
             PDC_HIP(hipEventCreateWithFlags(&d.scanned[g], hipEventDisableTiming));
             PDC_HIP(hipEventCreateWithFlags(&d.gathered[g], hipEventDisableTiming));
-            PDC_HIP(hipMalloc(&d.pow[g], (size_t)(p->slab_cap * n_devices * 8 + 8)));
+            PDC_TRY(device_alloc(&d.pow[g], p->slab_cap * n_devices * 8 + 8));
         }
         PDC_HIP(hipEventCreate(&d.k0));
         PDC_HIP(hipEventCreate(&d.k1));
-        PDC_HIP(hipMalloc(&d.t, (size_t)(n_max * 8 + 8)));
-        PDC_HIP(hipMalloc(&d.y, (size_t)(n_max * 8 + 8)));
-        PDC_HIP(hipMalloc(&d.dy, (size_t)(n_max * 8 + 8)));
-        PDC_HIP(hipMalloc(&d.work, (size_t)p->work_cap));
+        PDC_HIP(hipEventCreateWithFlags(&d.uploaded, hipEventDisableTiming));
+        PDC_TRY(device_alloc(&d.t, n_max * 8 + 8));
+        PDC_TRY(device_alloc(&d.y, n_max * 8 + 8));
+        PDC_TRY(device_alloc(&d.dy, n_max * 8 + 8));
+        PDC_TRY(device_alloc(&d.work, p->work_cap));
     }
-    if (n_devices > 1 || force_rccl()) {
+    PDC_TRY(ensure(p->stage, 3 * n_max * 8));
+    if (loopback || (n_devices > 1 && exchange_by_copy())) {
+        p->exchange = n_devices > 1 ? EX_COPY : EX_NONE;
+    } else if (n_devices > 1 || force_rccl()) {
         p->comms.assign(n_devices, nullptr);
         PDC_NCCL(ncclCommInitAll(p->comms.data(), n_devices, devices));
+        p->exchange = EX_RCCL;
     }
     return PDC_OK;
 }
@@ -109,20 +196,73 @@ int plan_upload(GlsPlan *p, const double *t, const double *y, const double *dy, 
     PDC_REQUIRE(t && y, "gls_plan_upload: t and y must not be NULL");
     PDC_REQUIRE(n >= 0 && n <= p->n_cap, "gls_plan_upload: %lld samples exceed the plan's %lld",
                 (long long)n, (long long)p->n_cap);
+    // The staging block is free again once the previous upload's copies have run (a scan of the old
+    // samples may still be in flight; it reads device memory only).
     for (PlanDev &d : p->dev) {
         PDC_TRY(use_device(d.device));
-        PDC_HIP(hipMemcpyAsync(d.t, t, n * 8, hipMemcpyHostToDevice, d.compute));
-        PDC_HIP(hipMemcpyAsync(d.y, y, n * 8, hipMemcpyHostToDevice, d.compute));
-        if (dy) PDC_HIP(hipMemcpyAsync(d.dy, dy, n * 8, hipMemcpyHostToDevice, d.compute));
+        PDC_HIP(hipEventSynchronize(d.uploaded));
+    }
+    // one pass over the caller's (pageable) arrays, then every device is fed from page-locked memory at
+    // the same time instead of one blocking pageable copy per device
+    double *s = static_cast<double *>(p->stage.p);
+    memcpy(s, t, (size_t)n * 8);
+    memcpy(s + n, y, (size_t)n * 8);
+    if (dy) memcpy(s + 2 * n, dy, (size_t)n * 8);
+    for (PlanDev &d : p->dev) {
+        PDC_TRY(use_device(d.device));
+        PDC_HIP(hipMemcpyAsync(d.t, s, n * 8, hipMemcpyHostToDevice, d.compute));
+        PDC_HIP(hipMemcpyAsync(d.y, s + n, n * 8, hipMemcpyHostToDevice, d.compute));
+        if (dy) PDC_HIP(hipMemcpyAsync(d.dy, s + 2 * n, n * 8, hipMemcpyHostToDevice, d.compute));
+        PDC_HIP(hipEventRecord(d.uploaded, d.compute));
     }
     p->n = n;
     p->has_dy = dy != nullptr;
     return PDC_OK;
 }
 
+// The all-gather of generation g as RCCL runs it: grouped, in place, on the communication streams.
+// A failing call inside the group still closes the group before the error is returned.
+int exchange_rccl(GlsPlan *p, int g, int64_t slab) {
+    const int nd = (int)p->dev.size();
+    PDC_NCCL(ncclGroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int i = 0; i < nd && bad == ncclSuccess; ++i) {
+        double *buf = (double *)p->dev[i].pow[g];
+        bad = ncclAllGather(buf + (int64_t)i * slab, buf, (size_t)slab, ncclDouble, p->comms[i], p->dev[i].comm);
+    }
+    const ncclResult_t end = ncclGroupEnd();
+    if (bad != ncclSuccess || end != ncclSuccess) {
+        set_error("ncclAllGather failed: %s", ncclGetErrorString(bad != ncclSuccess ? bad : end));
+        return PDC_ERR_RCCL;
+    }
+    return PDC_OK;
+}
+
+// The same data movement as device-to-device copies: slot i pulls slab j from slot j's buffer, for every
+// j, on ITS communication stream, once slot j's scan of this generation has been recorded.
+int exchange_copy(GlsPlan *p, int g, int64_t slab) {
+    const int nd = (int)p->dev.size();
+    for (int i = 0; i < nd; ++i) {
+        PlanDev &di = p->dev[i];
+        PDC_TRY(use_device(di.device));
+        for (int j = 0; j < nd; ++j) {
+            if (j == i) continue;
+            PlanDev &dj = p->dev[j];
+            PDC_HIP(hipStreamWaitEvent(di.comm, dj.scanned[g], 0));
+            double *dst = (double *)di.pow[g] + (int64_t)j * slab;
+            const double *src = (const double *)dj.pow[g] + (int64_t)j * slab;
+            if (di.device == dj.device)
+                PDC_HIP(hipMemcpyAsync(dst, src, (size_t)slab * 8, hipMemcpyDeviceToDevice, di.comm));
+            else
+                PDC_HIP(hipMemcpyPeerAsync(dst, di.device, src, dj.device, (size_t)slab * 8, di.comm));
+        }
+    }
+    return PDC_OK;
+}
+
 int plan_scan(GlsPlan *p, double f0, double delta, int64_t nf, int fit_mean, int psd) {
     const int nd = (int)p->dev.size();
-    const int64_t slab = (nf + nd - 1) / nd;   // equal counts; the tail of the last slab is padding
+    const int64_t slab = (nf + nd - 1) / nd;   // equal counts; the tail of the last slab(s) is padding
     PDC_REQUIRE(nf >= 0 && slab <= p->slab_cap, "gls_plan_scan: %lld frequencies exceed the plan",
                 (long long)nf);
     if (nf == 0) return PDC_OK;
@@ -130,33 +270,31 @@ int plan_scan(GlsPlan *p, double f0, double delta, int64_t nf, int fit_mean, int
     for (int i = 0; i < nd; ++i) {
         PlanDev &d = p->dev[i];
         PDC_TRY(use_device(d.device));
-        // generation g is free again once its previous gather (if any) has completed
-        if (p->used[g] && !p->comms.empty()) PDC_HIP(hipStreamWaitEvent(d.compute, d.gathered[g], 0));
-        const int64_t j0 = (int64_t)i * slab;
-        const int64_t cnt = j0 >= nf ? 0 : (nf - j0 < slab ? nf - j0 : slab);
-        double *out = (double *)d.pow[g] + j0;
-        if (cnt < slab)
-            PDC_HIP(hipMemsetAsync(out + cnt, 0, (size_t)((slab - cnt) * 8), d.compute));
+        // generation g is free again once its previous gather (if any) has completed: with RCCL the
+        // collective's completion on this device's stream covers it; with copies every OTHER slot's
+        // pull of this slot's slab has to be through as well
+        if (p->used[g] && p->exchange == EX_RCCL) PDC_HIP(hipStreamWaitEvent(d.compute, d.gathered[g], 0));
+        if (p->used[g] && p->exchange == EX_COPY)
+            for (int j = 0; j < nd; ++j) PDC_HIP(hipStreamWaitEvent(d.compute, p->dev[j].gathered[g], 0));
+        const Slab s = slab_of(nf, nd, i);
+        double *out = (double *)d.pow[g] + (int64_t)i * slab;
+        if (s.count < slab)
+            PDC_HIP(hipMemsetAsync(out + s.count, 0, (size_t)((slab - s.count) * 8), d.compute));
         if (i == 0) PDC_HIP(hipEventRecord(d.k0, d.compute));
-        if (cnt > 0)
+        if (s.count > 0)
             PDC_TRY(pdc_gls_scan_dev(d.device, d.compute, (double *)d.t, (double *)d.y,
                                      p->has_dy ? (double *)d.dy : nullptr, nullptr, p->n, 1, 0, f0,
-                                     delta, j0, cnt, fit_mean, psd, out, nullptr, nullptr, d.work,
+                                     delta, s.begin, s.count, fit_mean, psd, out, nullptr, nullptr, d.work,
                                      p->work_cap));
         if (i == 0) PDC_HIP(hipEventRecord(d.k1, d.compute));
-        if (!p->comms.empty()) {
+        if (p->exchange != EX_NONE) {
             PDC_HIP(hipEventRecord(d.scanned[g], d.compute));
             PDC_HIP(hipStreamWaitEvent(d.comm, d.scanned[g], 0));
         }
     }
-    if (!p->comms.empty()) {
-        PDC_NCCL(ncclGroupStart());
-        for (int i = 0; i < nd; ++i) {
-            double *buf = (double *)p->dev[i].pow[g];
-            PDC_NCCL(ncclAllGather(buf + (int64_t)i * slab, buf, (size_t)slab, ncclDouble, p->comms[i],
-                                   p->dev[i].comm));
-        }
-        PDC_NCCL(ncclGroupEnd());
+    if (p->exchange == EX_RCCL) PDC_TRY(exchange_rccl(p, g, slab));
+    if (p->exchange == EX_COPY) PDC_TRY(exchange_copy(p, g, slab));
+    if (p->exchange != EX_NONE) {
         for (int i = 0; i < nd; ++i) {
             PDC_TRY(use_device(p->dev[i].device));
             PDC_HIP(hipEventRecord(p->dev[i].gathered[g], p->dev[i].comm));
@@ -180,6 +318,20 @@ int plan_wait(GlsPlan *p) {
     return PDC_OK;
 }
 
+int plan_create(const int *devices, int n_devices, int64_t n_max, int64_t nf_max, bool loopback, void **plan) {
+    PDC_REQUIRE(plan, "gls_plan_create: NULL argument");
+    PDC_REQUIRE(n_max >= 0 && nf_max >= 0, "gls_plan_create: bad size");
+    PDC_TRY(check_devices("gls_plan_create", devices, n_devices, !loopback));
+    GlsPlan *p = new GlsPlan();
+    const int rc = plan_build(p, devices, n_devices, n_max, nf_max, loopback);
+    if (rc != PDC_OK) {
+        plan_free(p);
+        return rc;
+    }
+    *plan = p;
+    return PDC_OK;
+}
+
 // the one-shot host entry point keeps its plan between calls
 std::mutex g_oneshot_mutex;
 GlsPlan *g_oneshot = nullptr;
@@ -190,23 +342,25 @@ std::vector<int> g_oneshot_devices;
 extern "C" {
 
 int pdc_gls_plan_create(const int *devices, int n_devices, int64_t n_max, int64_t nf_max, void **plan) {
-    PDC_REQUIRE(devices && plan, "gls_plan_create: NULL argument");
-    PDC_REQUIRE(n_devices >= 1 && n_devices <= 64 && n_max >= 0 && nf_max >= 0, "gls_plan_create: bad size");
-    int count = 0;
-    PDC_TRY(pdc_device_count(&count));
-    for (int a = 0; a < n_devices; ++a) {
-        PDC_REQUIRE(devices[a] >= 0 && devices[a] < count, "gls_plan_create: device %d is not one of the %d visible",
-                    devices[a], count);
-        for (int b = a + 1; b < n_devices; ++b)
-            PDC_REQUIRE(devices[a] != devices[b], "gls_plan_create: device %d listed twice", devices[a]);
+    return plan_create(devices, n_devices, n_max, nf_max, false, plan);
+}
+
+int pdc_gls_plan_create_loopback(int device, int n_slots, int64_t n_max, int64_t nf_max, void **plan) {
+    PDC_REQUIRE(n_slots >= 1 && n_slots <= 64, "gls_plan_create_loopback: between 1 and 64 slots");
+    const std::vector<int> devices((size_t)n_slots, device);
+    return plan_create(devices.data(), n_slots, n_max, nf_max, true, plan);
+}
+
+int pdc_gls_plan_info(void *plan, int *n_slots, int *rccl_ranks, int *exchange) {
+    PDC_REQUIRE(plan, "gls_plan_info: NULL plan");
+    GlsPlan *p = static_cast<GlsPlan *>(plan);
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (n_slots) *n_slots = (int)p->dev.size();
+    if (exchange) *exchange = (int)p->exchange;
+    if (rccl_ranks) {
+        *rccl_ranks = 0;
+        if (!p->comms.empty()) PDC_NCCL(ncclCommCount(p->comms[0], rccl_ranks));
     }
-    GlsPlan *p = new GlsPlan();
-    const int rc = plan_build(p, devices, n_devices, n_max, nf_max);
-    if (rc != PDC_OK) {
-        plan_free(p);
-        return rc;
-    }
-    *plan = p;
     return PDC_OK;
 }
 
@@ -238,7 +392,6 @@ int pdc_gls_plan_download(void *plan, double *power_out, int64_t nf, int which) 
     PDC_REQUIRE(p->last >= 0 && nf == p->nf, "gls_plan_download: no scan of %lld frequencies is pending",
                 (long long)nf);
     PDC_REQUIRE(which >= 0 && which < (int)p->dev.size(), "gls_plan_download: bad device slot %d", which);
-    PDC_REQUIRE(which == 0 || !p->comms.empty() || p->dev.size() == 1, "gls_plan_download: bad slot");
     PDC_TRY(plan_wait(p));
     PlanDev &d = p->dev[which];
     PDC_TRY(use_device(d.device));
@@ -286,86 +439,187 @@ int pdc_gls_scan_multi(const double *t, const double *y, const double *dy, int64
     PDC_TRY(plan_wait(g_oneshot));
     PlanDev &d0 = g_oneshot->dev[0];
     PDC_TRY(use_device(d0.device));
-    if (g_oneshot->comms.empty() && n_devices > 1) return PDC_ERR_RCCL;  // (cannot happen: comms exist for n > 1)
     PDC_HIP(hipMemcpy(power_out, d0.pow[g_oneshot->last], (size_t)(nf * 8), hipMemcpyDeviceToHost));
     return PDC_OK;
 }
 
 }  // extern "C"
 
-// Frees the plan pdc_gls_scan_multi keeps between calls (pdc_release()).
-void pdc::release_multi() {
-    std::lock_guard<std::mutex> lk(g_oneshot_mutex);
-    if (g_oneshot) plan_free(g_oneshot);
-    g_oneshot = nullptr;
-    g_oneshot_devices.clear();
-}
-
-// ---- phase scans over several GPUs ------------------------------------------------------------------
-// The trial-period grid is cut into contiguous slabs, one per listed device (a device may be listed
-// more than once: its slabs then run on separate streams); samples are replicated, every slab comes
-// back with its own D2H copy, and there is no exchange step at all.
+// ======================================================================================================
+// PhasePlan: PDM / AoV / conditional entropy / StringLength over period slabs; batches over curve groups
+// ======================================================================================================
 namespace {
 
-struct PhaseSlot {
-    void *t = nullptr, *v = nullptr, *periods = nullptr, *out = nullptr, *work = nullptr;
+enum { B_T = 0, B_V, B_PER, B_OUT, B_WORK, B_DY, B_OFF, B_POW, B_AMAX, B_ARG, B_COUNT };
+
+struct DevSlot {
+    int device = -1;
     hipStream_t stream = nullptr;
+    hipEvent_t k0 = nullptr, k1 = nullptr;
+    DevBuf b[B_COUNT];
+    bool timed = false;
 };
 
-void free_slots(std::vector<PhaseSlot> &slots, const int *devices) {
-    for (size_t d = 0; d < slots.size(); ++d) {
-        if (hipSetDevice(devices[d]) != hipSuccess) continue;
-        if (slots[d].stream) (void)hipStreamDestroy(slots[d].stream);
-        for (void *p : {slots[d].t, slots[d].v, slots[d].periods, slots[d].out, slots[d].work})
-            if (p) (void)hipFree(p);
+struct PhasePlan {
+    std::vector<int> devices;
+    std::vector<DevSlot> slot;
+    PinBuf pin_in, pin_per, pin_out;   // samples (t, v) / trial periods / results
+    int64_t n = 0, n_periods = 0;
+    bool scanned = false;
+    std::mutex mu;
+};
+
+void phase_free(PhasePlan *p) {
+    for (DevSlot &s : p->slot) {
+        if (s.device < 0 || hipSetDevice(s.device) != hipSuccess) continue;
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        for (hipEvent_t e : {s.k0, s.k1})
+            if (e) (void)hipEventDestroy(e);
+        if (s.stream) {
+            (void)drop_stream_scratch(s.device, s.stream);
+            (void)hipStreamDestroy(s.stream);
+        }
+        for (DevBuf &b : s.b)
+            if (b.p) (void)hipFree(b.p);
     }
+    for (PinBuf *b : {&p->pin_in, &p->pin_per, &p->pin_out})
+        if (b->p) (void)hipHostFree(b->p);
+    delete p;
 }
 
-// kind 0 = PDM (v = x), 1 = StringLength (v = m)
-int phase_multi(int kind, const double *t, const double *v, int64_t n, const double *periods,
-                int64_t n_periods, int nb, int nc, double sigma, double *out, const int *devices,
-                int n_devices, std::vector<PhaseSlot> &slots) {
-    const int64_t slab = (n_periods + n_devices - 1) / n_devices;
-    for (int d = 0; d < n_devices; ++d) {
-        const int64_t p0 = (int64_t)d * slab;
-        const int64_t cnt = p0 >= n_periods ? 0 : (n_periods - p0 < slab ? n_periods - p0 : slab);
-        if (cnt == 0) continue;
-        PDC_TRY(use_device(devices[d]));
-        PhaseSlot &s = slots[d];
+int phase_build(PhasePlan *p, const int *devices, int n_devices, int64_t n_max, int64_t n_periods_max) {
+    p->devices.assign(devices, devices + n_devices);
+    p->slot.resize(n_devices);
+    const int64_t slab = (n_periods_max + n_devices - 1) / n_devices;
+    for (int i = 0; i < n_devices; ++i) {
+        DevSlot &s = p->slot[i];
+        PDC_TRY(use_device(devices[i]));
+        s.device = devices[i];
         PDC_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        PDC_HIP(hipMalloc(&s.t, (size_t)(n * 8 + 8)));
-        PDC_HIP(hipMalloc(&s.v, (size_t)(n * 8 + 8)));
-        PDC_HIP(hipMalloc(&s.periods, (size_t)(cnt * 8)));
-        PDC_HIP(hipMalloc(&s.out, (size_t)(cnt * 8)));
-        PDC_HIP(hipMemcpyAsync(s.t, t, n * 8, hipMemcpyHostToDevice, s.stream));
-        PDC_HIP(hipMemcpyAsync(s.v, v, n * 8, hipMemcpyHostToDevice, s.stream));
-        PDC_HIP(hipMemcpyAsync(s.periods, periods + p0, cnt * 8, hipMemcpyHostToDevice, s.stream));
-        if (kind == 0) {
-            PDC_TRY(pdc_pdm_scan_dev(devices[d], s.stream, (double *)s.t, (double *)s.v, n,
-                                     (double *)s.periods, cnt, nb, nc, sigma, (double *)s.out));
-        } else {
-            const int64_t wb = pdc_stringlength_work_bytes(n, cnt);
-            PDC_REQUIRE(wb >= 0, "stringlength_multi: bad size");
-            PDC_HIP(hipMalloc(&s.work, (size_t)(wb + 8)));
-            PDC_TRY(pdc_stringlength_scan_dev(devices[d], s.stream, (double *)s.t, (double *)s.v, n,
-                                              (double *)s.periods, cnt, (double *)s.out, s.work, wb));
+        PDC_HIP(hipEventCreate(&s.k0));
+        PDC_HIP(hipEventCreate(&s.k1));
+        if (n_max > 0) {
+            PDC_TRY(ensure(s.b[B_T], n_max * 8));
+            PDC_TRY(ensure(s.b[B_V], n_max * 8));
+        }
+        if (slab > 0) {
+            PDC_TRY(ensure(s.b[B_PER], slab * 8));
+            PDC_TRY(ensure(s.b[B_OUT], slab * 8));
         }
     }
-    // Results come back only after EVERY slab has been launched: a copy into the caller's pageable
-    // buffer blocks the host until that slab's scan has finished, and issued inside the loop above it
-    // would run the devices one after another.
-    for (int d = 0; d < n_devices; ++d) {
-        if (!slots[d].stream) continue;
-        const int64_t p0 = (int64_t)d * slab;
-        const int64_t cnt = n_periods - p0 < slab ? n_periods - p0 : slab;
-        PDC_TRY(use_device(devices[d]));
-        PDC_HIP(hipMemcpyAsync(out + p0, slots[d].out, cnt * 8, hipMemcpyDeviceToHost, slots[d].stream));
+    if (n_max > 0) PDC_TRY(ensure(p->pin_in, 2 * n_max * 8));
+    if (n_periods_max > 0) {
+        PDC_TRY(ensure(p->pin_per, n_periods_max * 8));
+        PDC_TRY(ensure(p->pin_out, n_periods_max * 8));
     }
-    for (int d = 0; d < n_devices; ++d) {
-        if (!slots[d].stream) continue;
-        PDC_TRY(use_device(devices[d]));
-        PDC_HIP(hipStreamSynchronize(slots[d].stream));
+    return PDC_OK;
+}
+
+int phase_wait(PhasePlan *p) {
+    for (DevSlot &s : p->slot) {
+        PDC_TRY(use_device(s.device));
+        PDC_HIP(hipStreamSynchronize(s.stream));
     }
+    return PDC_OK;
+}
+
+int phase_upload(PhasePlan *p, const double *t, const double *v, int64_t n) {
+    PDC_REQUIRE(t && v, "phase_plan_upload: t and v must not be NULL");
+    PDC_REQUIRE(n >= 0, "phase_plan_upload: negative size");
+    PDC_TRY(phase_wait(p));   // the staging block and the device copies may still be in use
+    PDC_TRY(ensure(p->pin_in, 2 * n * 8));
+    double *s = static_cast<double *>(p->pin_in.p);
+    memcpy(s, t, (size_t)n * 8);
+    memcpy(s + n, v, (size_t)n * 8);
+    for (DevSlot &sl : p->slot) {
+        PDC_TRY(use_device(sl.device));
+        PDC_TRY(ensure(sl.b[B_T], n * 8));
+        PDC_TRY(ensure(sl.b[B_V], n * 8));
+        PDC_HIP(hipMemcpyAsync(sl.b[B_T].p, s, n * 8, hipMemcpyHostToDevice, sl.stream));
+        PDC_HIP(hipMemcpyAsync(sl.b[B_V].p, s + n, n * 8, hipMemcpyHostToDevice, sl.stream));
+    }
+    p->n = n;
+    return PDC_OK;
+}
+
+// kind 0 = PDM (v = x), 1 = AoV (v = x; nb phase bins), 2 = conditional entropy (v = magnitude bins; nb x nc
+// cells), 3 = StringLength (v = m).  Enqueues on every slot: its slab of the trial periods H2D, the scan,
+// the slab of results D2H into the page-locked result block - and returns.
+int phase_scan(PhasePlan *p, int kind, const double *periods, int64_t n_periods, int nb, int nc, double sigma) {
+    PDC_REQUIRE(kind >= 0 && kind <= 3, "phase_plan_scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional "
+                                        "entropy) or 3 (StringLength)");
+    PDC_REQUIRE((periods || n_periods == 0) && n_periods >= 0, "phase_plan_scan: bad period grid");
+    const int nd = (int)p->slot.size();
+    PDC_TRY(phase_wait(p));   // the period / result staging blocks of the previous scan are free after this
+    p->n_periods = n_periods;
+    p->scanned = true;
+    for (DevSlot &s : p->slot) s.timed = false;
+    if (n_periods == 0) return PDC_OK;
+    PDC_TRY(ensure(p->pin_per, n_periods * 8));
+    PDC_TRY(ensure(p->pin_out, n_periods * 8));
+    memcpy(p->pin_per.p, periods, (size_t)n_periods * 8);
+    const double *pp = static_cast<const double *>(p->pin_per.p);
+    double *po = static_cast<double *>(p->pin_out.p);
+    for (int i = 0; i < nd; ++i) {
+        const Slab sb = slab_of(n_periods, nd, i);
+        if (sb.count == 0) continue;
+        DevSlot &s = p->slot[i];
+        PDC_TRY(use_device(s.device));
+        PDC_REQUIRE(s.b[B_T].p && s.b[B_V].p, "phase_plan_scan: no samples have been uploaded");
+        PDC_TRY(ensure(s.b[B_PER], sb.count * 8));
+        PDC_TRY(ensure(s.b[B_OUT], sb.count * 8));
+        const int64_t wb = pdc_phase_work_bytes(kind, p->n, sb.count, nb, nc);
+        PDC_REQUIRE(wb >= 0, "phase_plan_scan: bad size");
+        PDC_TRY(ensure(s.b[B_WORK], wb + 8));
+        PDC_HIP(hipMemcpyAsync(s.b[B_PER].p, pp + sb.begin, sb.count * 8, hipMemcpyHostToDevice, s.stream));
+        PDC_HIP(hipEventRecord(s.k0, s.stream));
+        PDC_TRY(pdc_phase_scan_dev(kind, s.device, s.stream, (double *)s.b[B_T].p, (double *)s.b[B_V].p, p->n,
+                                   (double *)s.b[B_PER].p, sb.count, nb, nc, sigma, (double *)s.b[B_OUT].p,
+                                   s.b[B_WORK].p, s.b[B_WORK].cap));
+        PDC_HIP(hipEventRecord(s.k1, s.stream));
+        s.timed = true;
+        PDC_HIP(hipMemcpyAsync(po + sb.begin, s.b[B_OUT].p, sb.count * 8, hipMemcpyDeviceToHost, s.stream));
+    }
+    return PDC_OK;
+}
+
+int phase_download(PhasePlan *p, double *out, int64_t n_periods) {
+    PDC_REQUIRE(p->scanned && n_periods == p->n_periods, "phase_plan_download: no scan of %lld periods is pending",
+                (long long)n_periods);
+    PDC_REQUIRE(out || n_periods == 0, "phase_plan_download: NULL argument");
+    PDC_TRY(phase_wait(p));
+    if (n_periods) memcpy(out, p->pin_out.p, (size_t)n_periods * 8);
+    return PDC_OK;
+}
+
+// one-shot callers: a few plans cached by device list, most recently used last
+std::mutex g_phase_mutex;
+std::vector<PhasePlan *> g_phase_cache;
+constexpr size_t kPhaseCache = 4;
+
+int cached_phase_plan(const char *who, const int *devices, int n_devices, PhasePlan **out) {
+    PDC_TRY(check_devices(who, devices, n_devices, false));
+    const std::vector<int> want(devices, devices + n_devices);
+    for (size_t i = 0; i < g_phase_cache.size(); ++i)
+        if (g_phase_cache[i]->devices == want) {
+            PhasePlan *p = g_phase_cache[i];
+            g_phase_cache.erase(g_phase_cache.begin() + (long)i);
+            g_phase_cache.push_back(p);
+            *out = p;
+            return PDC_OK;
+        }
+    while (g_phase_cache.size() >= kPhaseCache) {
+        phase_free(g_phase_cache.front());
+        g_phase_cache.erase(g_phase_cache.begin());
+    }
+    PhasePlan *p = new PhasePlan();
+    const int rc = phase_build(p, devices, n_devices, 0, 0);
+    if (rc != PDC_OK) {
+        phase_free(p);
+        return rc;
+    }
+    g_phase_cache.push_back(p);
+    *out = p;
     return PDC_OK;
 }
 
@@ -375,26 +629,200 @@ int phase_multi_entry(int kind, const char *who, const double *t, const double *
     PDC_REQUIRE(t && v && devices && (periods || n_periods == 0) && (out || n_periods == 0),
                 "%s: NULL argument", who);
     PDC_REQUIRE(n >= 0 && n_periods >= 0 && n_devices >= 1 && n_devices <= 64, "%s: bad size", who);
+    if (kind == 2)
+        for (int64_t i = 0; i < n; ++i)
+            PDC_REQUIRE(v[i] >= 0.0 && v[i] < (double)nc, "%s: mag_bin[%lld] = %g is not a bin index in 0 .. %d",
+                        who, (long long)i, v[i], nc - 1);
     if (n_periods == 0) return PDC_OK;
-    std::vector<PhaseSlot> slots(n_devices);
-    const int rc = phase_multi(kind, t, v, n, periods, n_periods, nb, nc, sigma, out, devices,
-                               n_devices, slots);
-    free_slots(slots, devices);
-    return rc;
+    std::lock_guard<std::mutex> lk(g_phase_mutex);
+    PhasePlan *p = nullptr;
+    PDC_TRY(cached_phase_plan(who, devices, n_devices, &p));
+    PDC_TRY(phase_upload(p, t, v, n));
+    PDC_TRY(phase_scan(p, kind, periods, n_periods, nb, nc, sigma));
+    return phase_download(p, out, n_periods);
 }
 
 }  // namespace
 
-extern "C" int pdc_pdm_scan_multi(const double *t, const double *x, int64_t n, const double *periods,
-                                  int64_t n_periods, int nb, int nc, double sigma, double *theta_out,
-                                  const int *devices, int n_devices) {
+extern "C" {
+
+int pdc_phase_plan_create(const int *devices, int n_devices, int64_t n_max, int64_t n_periods_max, void **plan) {
+    PDC_REQUIRE(plan && n_max >= 0 && n_periods_max >= 0, "phase_plan_create: bad argument");
+    PDC_TRY(check_devices("phase_plan_create", devices, n_devices, false));
+    PhasePlan *p = new PhasePlan();
+    const int rc = phase_build(p, devices, n_devices, n_max, n_periods_max);
+    if (rc != PDC_OK) {
+        phase_free(p);
+        return rc;
+    }
+    *plan = p;
+    return PDC_OK;
+}
+
+int pdc_phase_plan_upload(void *plan, const double *t, const double *v, int64_t n) {
+    PDC_REQUIRE(plan, "phase_plan_upload: NULL plan");
+    PhasePlan *p = static_cast<PhasePlan *>(plan);
+    std::lock_guard<std::mutex> lk(p->mu);
+    return phase_upload(p, t, v, n);
+}
+
+int pdc_phase_plan_scan(void *plan, int kind, const double *periods, int64_t n_periods, int nb, int nc,
+                        double sigma) {
+    PDC_REQUIRE(plan, "phase_plan_scan: NULL plan");
+    PhasePlan *p = static_cast<PhasePlan *>(plan);
+    std::lock_guard<std::mutex> lk(p->mu);
+    return phase_scan(p, kind, periods, n_periods, nb, nc, sigma);
+}
+
+int pdc_phase_plan_wait(void *plan) {
+    PDC_REQUIRE(plan, "phase_plan_wait: NULL plan");
+    PhasePlan *p = static_cast<PhasePlan *>(plan);
+    std::lock_guard<std::mutex> lk(p->mu);
+    return phase_wait(p);
+}
+
+int pdc_phase_plan_download(void *plan, double *out, int64_t n_periods) {
+    PDC_REQUIRE(plan, "phase_plan_download: NULL plan");
+    PhasePlan *p = static_cast<PhasePlan *>(plan);
+    std::lock_guard<std::mutex> lk(p->mu);
+    return phase_download(p, out, n_periods);
+}
+
+int pdc_phase_plan_kernel_ms(void *plan, float *ms) {
+    PDC_REQUIRE(plan && ms, "phase_plan_kernel_ms: NULL argument");
+    PhasePlan *p = static_cast<PhasePlan *>(plan);
+    std::lock_guard<std::mutex> lk(p->mu);
+    float worst = -1.0f;
+    for (DevSlot &s : p->slot) {
+        if (!s.timed) continue;
+        PDC_TRY(use_device(s.device));
+        PDC_HIP(hipEventSynchronize(s.k1));
+        float one = 0.0f;
+        PDC_HIP(hipEventElapsedTime(&one, s.k0, s.k1));
+        worst = one > worst ? one : worst;
+    }
+    PDC_REQUIRE(worst >= 0.0f, "phase_plan_kernel_ms: no scan has been enqueued");
+    *ms = worst;
+    return PDC_OK;
+}
+
+int pdc_phase_plan_destroy(void *plan) {
+    if (plan) phase_free(static_cast<PhasePlan *>(plan));
+    return PDC_OK;
+}
+
+int pdc_pdm_scan_multi(const double *t, const double *x, int64_t n, const double *periods,
+                       int64_t n_periods, int nb, int nc, double sigma, double *theta_out,
+                       const int *devices, int n_devices) {
     return phase_multi_entry(0, "pdm_multi", t, x, n, periods, n_periods, nb, nc, sigma, theta_out,
                              devices, n_devices);
 }
 
-extern "C" int pdc_stringlength_scan_multi(const double *t, const double *m, int64_t n,
-                                           const double *periods, int64_t n_periods, double *ell_out,
-                                           const int *devices, int n_devices) {
-    return phase_multi_entry(1, "stringlength_multi", t, m, n, periods, n_periods, 0, 0, 0.0, ell_out,
+int pdc_aov_scan_multi(const double *t, const double *x, int64_t n, const double *periods, int64_t n_periods,
+                       int n_bins, double *theta_out, const int *devices, int n_devices) {
+    return phase_multi_entry(1, "aov_multi", t, x, n, periods, n_periods, n_bins, 1, 1.0, theta_out, devices,
+                             n_devices);
+}
+
+int pdc_cond_entropy_scan_multi(const double *t, const double *mag_bin, int64_t n, const double *periods,
+                                int64_t n_periods, int n_phase, int n_mag, double *entropy_out,
+                                const int *devices, int n_devices) {
+    return phase_multi_entry(2, "cond_entropy_multi", t, mag_bin, n, periods, n_periods, n_phase, n_mag, 1.0,
+                             entropy_out, devices, n_devices);
+}
+
+int pdc_stringlength_scan_multi(const double *t, const double *m, int64_t n,
+                                const double *periods, int64_t n_periods, double *ell_out,
+                                const int *devices, int n_devices) {
+    return phase_multi_entry(3, "stringlength_multi", t, m, n, periods, n_periods, 1, 1, 0.0, ell_out,
                              devices, n_devices);
+}
+
+// Batch of light curves dealt to the device slots in contiguous groups of ceil(B / slots) curves (SURVEY.md
+// §8e: "Batched C3 can alternatively shard over curves (no exchange at all)"); the shape of GLS.bootstrap
+// over several GPUs when shared_t != 0 (/root/reference/src/periodicity/spectral.py:140-152).
+int pdc_gls_scan_batch_multi(const double *t, const double *y, const double *dy, const int64_t *offsets,
+                             int64_t n_curves, int shared_t, double f0, double delta, int64_t nf, int fit_mean,
+                             int psd, double *power_out, double *amax_out, int64_t *argmax_out,
+                             const int *devices, int n_devices) {
+    PDC_REQUIRE(t && y && offsets && devices, "gls_batch_multi: NULL argument");
+    PDC_REQUIRE(n_curves >= 1 && nf >= 0, "gls_batch_multi: negative size");
+    PDC_REQUIRE(power_out || amax_out || argmax_out, "gls_batch_multi: no output requested");
+    PDC_REQUIRE(offsets[0] == 0, "gls_batch_multi: offsets[0] must be 0");
+    for (int64_t b = 0; b < n_curves; ++b) {
+        PDC_REQUIRE(offsets[b + 1] >= offsets[b], "gls_batch_multi: offsets must be non-decreasing");
+        PDC_REQUIRE(!shared_t || offsets[b + 1] - offsets[b] == offsets[1] - offsets[0],
+                    "gls_batch_multi: with a shared time axis every curve must have the same length");
+    }
+    std::lock_guard<std::mutex> lk(g_phase_mutex);
+    PhasePlan *p = nullptr;
+    PDC_TRY(cached_phase_plan("gls_batch_multi", devices, n_devices, &p));
+    PDC_TRY(phase_wait(p));
+    if (nf == 0) return PDC_OK;
+    const int nd = n_devices;
+    std::vector<std::vector<int64_t>> rebased_of((size_t)nd);   // alive until the final wait
+    // launches first, on every slot; the results come back afterwards (a copy into the caller's pageable
+    // arrays blocks the host until that slot is done, and issued inside this loop it would run the
+    // devices one after another)
+    for (int i = 0; i < nd; ++i) {
+        const Slab sb = slab_of(n_curves, nd, i);
+        if (sb.count == 0) continue;
+        DevSlot &s = p->slot[i];
+        PDC_TRY(use_device(s.device));
+        const int64_t s0 = offsets[sb.begin], s1 = offsets[sb.begin + sb.count];
+        const int64_t n_total = s1 - s0;
+        const int64_t n_t = shared_t ? offsets[1] : n_total;
+        const int64_t wb = pdc_gls_work_bytes(n_total, sb.count, nf);
+        PDC_REQUIRE(wb >= 0, "gls_batch_multi: bad size");
+        PDC_TRY(ensure(s.b[B_T], n_t * 8));
+        PDC_TRY(ensure(s.b[B_V], n_total * 8));
+        if (dy) PDC_TRY(ensure(s.b[B_DY], n_total * 8));
+        PDC_TRY(ensure(s.b[B_OFF], (sb.count + 1) * 8));
+        if (power_out) PDC_TRY(ensure(s.b[B_POW], sb.count * nf * 8));
+        if (amax_out) PDC_TRY(ensure(s.b[B_AMAX], sb.count * 8));
+        if (argmax_out) PDC_TRY(ensure(s.b[B_ARG], sb.count * 8));
+        PDC_TRY(ensure(s.b[B_WORK], wb));
+        std::vector<int64_t> &rebased = rebased_of[(size_t)i];
+        rebased.resize((size_t)sb.count + 1);
+        for (int64_t b = 0; b <= sb.count; ++b) rebased[(size_t)b] = offsets[sb.begin + b] - s0;
+        PDC_HIP(hipMemcpyAsync(s.b[B_T].p, shared_t ? t : t + s0, n_t * 8, hipMemcpyHostToDevice, s.stream));
+        PDC_HIP(hipMemcpyAsync(s.b[B_V].p, y + s0, n_total * 8, hipMemcpyHostToDevice, s.stream));
+        if (dy) PDC_HIP(hipMemcpyAsync(s.b[B_DY].p, dy + s0, n_total * 8, hipMemcpyHostToDevice, s.stream));
+        PDC_HIP(hipMemcpyAsync(s.b[B_OFF].p, rebased.data(), (sb.count + 1) * 8, hipMemcpyHostToDevice, s.stream));
+        PDC_TRY(pdc_gls_scan_dev(s.device, s.stream, (double *)s.b[B_T].p, (double *)s.b[B_V].p,
+                                 dy ? (double *)s.b[B_DY].p : nullptr, (int64_t *)s.b[B_OFF].p, n_total, sb.count,
+                                 shared_t, f0, delta, 0, nf, fit_mean, psd,
+                                 power_out ? (double *)s.b[B_POW].p : nullptr,
+                                 amax_out ? (double *)s.b[B_AMAX].p : nullptr,
+                                 argmax_out ? (int64_t *)s.b[B_ARG].p : nullptr, s.b[B_WORK].p, s.b[B_WORK].cap));
+    }
+    for (int i = 0; i < nd; ++i) {
+        const Slab sb = slab_of(n_curves, nd, i);
+        if (sb.count == 0) continue;
+        DevSlot &s = p->slot[i];
+        PDC_TRY(use_device(s.device));
+        if (power_out)
+            PDC_HIP(hipMemcpyAsync(power_out + sb.begin * nf, s.b[B_POW].p, sb.count * nf * 8, hipMemcpyDeviceToHost,
+                                   s.stream));
+        if (amax_out)
+            PDC_HIP(hipMemcpyAsync(amax_out + sb.begin, s.b[B_AMAX].p, sb.count * 8, hipMemcpyDeviceToHost, s.stream));
+        if (argmax_out)
+            PDC_HIP(hipMemcpyAsync(argmax_out + sb.begin, s.b[B_ARG].p, sb.count * 8, hipMemcpyDeviceToHost, s.stream));
+    }
+    return phase_wait(p);
+}
+
+}  // extern "C"
+
+// Frees the plans the one-shot `_multi` entry points keep between calls (pdc_release()).
+void pdc::release_multi() {
+    {
+        std::lock_guard<std::mutex> lk(g_oneshot_mutex);
+        if (g_oneshot) plan_free(g_oneshot);
+        g_oneshot = nullptr;
+        g_oneshot_devices.clear();
+    }
+    std::lock_guard<std::mutex> lk(g_phase_mutex);
+    for (PhasePlan *p : g_phase_cache) phase_free(p);
+    g_phase_cache.clear();
 }

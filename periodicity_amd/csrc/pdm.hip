@@ -297,7 +297,11 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         };
         auto add = [&](const int k, const double val, const unsigned inc) {
             if (CE) {   // val = the sample's magnitude bin; a NaN phase (inc == 0) counts nowhere
-                atomicAdd(&hcnt[(k * mag + (int)val) * BLOCK + tid], inc);
+                // the bin is the caller's double: anything outside 0 .. mag-1 (NaN included) counts nowhere
+                // instead of indexing LDS with it (the host entry rejects such input; `_dev` callers get this)
+                const bool in_range = val >= 0.0 && val < (double)mag;
+                const int j = in_range ? (int)val : 0;
+                atomicAdd(&hcnt[(k * mag + j) * BLOCK + tid], in_range ? inc : 0u);
             } else {
                 atomicAdd(&hsum[k * BLOCK + tid], val);
                 atomicAdd(&hcnt[k * BLOCK + tid], inc);
@@ -412,9 +416,57 @@ int allow_lds(Kernel kernel) {
     return allow_dynamic_lds((const void *)kernel, 150 * 1024);
 }
 
-// kind 0: PDM theta; 1: AoV over nb phase bins; 2: conditional entropy over nb x nc cells
-int phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, const double *d_x, int64_t n,
-                   const double *d_periods, int64_t n_periods, int nb, int nc, double sigma, double *d_out) {
+// Split mode (few trial periods, many samples; see phase_stat_dev): how the samples are cut and how
+// much scratch the partial histograms take.  n_z == 1: not split.
+struct SplitShape {
+    int64_t n_z = 1, z_len = 0, p_pad = 0, bytes = 0;
+    int n_stat = 0;
+    size_t stat_b = 0, psum_b = 0, pq_b = 0, pcnt_b = 0;
+};
+
+SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
+    static const int env_split = [] { const char *e = getenv("PDC_PDM_SPLIT"); return e ? atoi(e) : -1; }();
+    SplitShape sh;
+    if (kind == 1) nc = 1;
+    const int m0 = kind == 2 ? nb : nb * nc;
+    const int last = kind == 2 ? (nb + 1) * nc - 1 : m0;
+    const int nbins = last + 1;
+    const int64_t groups0 = (n_periods + 63) / 64;
+    // (four workgroups of four waves fit a CU: below ~3000 waves the period grid alone leaves SIMD slots empty)
+    if (kind == 2 || env_split == 0 || n_periods == 0 || groups0 * 4 >= 3072 || n < 32 * kChunk ||
+        lds_bytes(last, 256) > 150 * 1024 || (size_t)nbins * 64 * 16 > 150 * 1024)
+        return sh;
+    int64_t n_z = (4096 + groups0 * 4 - 1) / (groups0 * 4);
+    const int64_t max_z = n / (8 * kChunk);
+    n_z = n_z < max_z ? n_z : max_z;
+    const int64_t z_len = ((n + n_z - 1) / n_z + kChunk - 1) / kChunk * kChunk;
+    n_z = (n + z_len - 1) / z_len;
+    if (n_z <= 1) return sh;
+    sh.n_z = n_z;
+    sh.z_len = z_len;
+    sh.p_pad = groups0 * 64;
+    sh.n_stat = (int)((n + 1023) / 1024 < kStatParts ? (n + 1023) / 1024 : kStatParts);
+    sh.stat_b = (size_t)3 * kStatParts * 8;
+    sh.psum_b = (size_t)n_z * nbins * sh.p_pad * 8;
+    sh.pq_b = (size_t)n_z * 2 * sh.p_pad * 8;
+    sh.pcnt_b = (size_t)n_z * nbins * sh.p_pad * 4;
+    sh.bytes = (int64_t)(sh.stat_b + sh.psum_b + sh.pq_b + sh.pcnt_b);
+    return sh;
+}
+
+}  // namespace
+
+int64_t pdc::phase_stat_work_bytes(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
+    if (kind < 0 || kind > 2 || n < 0 || n_periods < 0 || nb < 1 || nc < 1) return -1;
+    return split_shape(kind, n, n_periods, nb, nc).bytes;
+}
+
+// kind 0: PDM theta; 1: AoV over nb phase bins; 2: conditional entropy over nb x nc cells.
+// `work`: scratch of at least phase_stat_work_bytes() bytes for the split mode's partial histograms;
+// NULL = take it from the per-(device, stream) cache (the `_dev` entry points without a workspace).
+int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, const double *d_x, int64_t n,
+                        const double *d_periods, int64_t n_periods, int nb, int nc, double sigma, double *d_out,
+                        void *work, int64_t work_bytes) {
     PDC_REQUIRE(d_t && d_x && (d_periods || n_periods == 0) && (d_out || n_periods == 0),
                 "phase scan: NULL argument");
     PDC_REQUIRE(n >= 0 && n_periods >= 0, "phase scan: negative size");
@@ -431,47 +483,39 @@ int phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, cons
     // periods, so the period grid alone would leave most of the chip idle.  Split the SAMPLES over
     // blockIdx.y as well: statistics once (two short grid-wide launches), partial histograms per
     // slice, one finishing launch that adds them in slice order.  PDC_PDM_SPLIT=0 disables it.
-    static const int env_split = [] { const char *e = getenv("PDC_PDM_SPLIT"); return e ? atoi(e) : -1; }();
     const int64_t groups0 = (n_periods + 63) / 64;
     const int nbins = last + 1;
-    // (four workgroups of four waves fit a CU: below ~3000 waves the period grid alone leaves SIMD slots empty)
-    if (kind != 2 && env_split != 0 && groups0 * 4 < 3072 && n >= 32 * kChunk && lds_bytes(last, 256) <= 150 * 1024 &&
-        (size_t)nbins * 64 * 16 <= 150 * 1024) {
-        int64_t n_z = (4096 + groups0 * 4 - 1) / (groups0 * 4);
-        const int64_t max_z = n / (8 * kChunk);
-        n_z = n_z < max_z ? n_z : max_z;
-        const int64_t z_len = ((n + n_z - 1) / n_z + kChunk - 1) / kChunk * kChunk;
-        n_z = (n + z_len - 1) / z_len;
-        if (n_z > 1) {
-            a.p_pad = groups0 * 64;
-            a.n_z = (int)n_z;
-            a.z_len = z_len;
-            a.n_stat = (int)((n + 1023) / 1024 < kStatParts ? (n + 1023) / 1024 : kStatParts);
-            const size_t stat_b = (size_t)3 * kStatParts * 8;
-            const size_t psum_b = (size_t)n_z * nbins * a.p_pad * 8;
-            const size_t pq_b = (size_t)n_z * 2 * a.p_pad * 8;
-            const size_t pcnt_b = (size_t)n_z * nbins * a.p_pad * 4;
-            PDC_TRY(allow_lds(pdm_scan_kernel<256, 4, true>));
-            PDC_TRY(allow_lds(pdm_finish_kernel));
-            void *spv = nullptr;   // cached per (device, stream): see pdc_internal.h on why not hipMallocAsync
-            PDC_TRY(stream_scratch(device, st, (int64_t)(stat_b + psum_b + pq_b + pcnt_b), &spv));
-            char *const sp = static_cast<char *>(spv);
-            // PDC_PDM_POISON=1 fills the scratch with a NaN pattern first (debugging aid: every word the kernels
-            // read must have been written by them)
-            static const bool poison = [] { const char *e = getenv("PDC_PDM_POISON"); return e && e[0] == '1'; }();
-            if (poison) PDC_HIP(hipMemsetAsync(sp, 0x7f, stat_b + psum_b + pq_b + pcnt_b, st));
-            a.stat = reinterpret_cast<double *>(sp);
-            a.psum = reinterpret_cast<double *>(sp + stat_b);
-            a.pq = reinterpret_cast<double *>(sp + stat_b + psum_b);
-            a.pcnt = reinterpret_cast<unsigned *>(sp + stat_b + psum_b + pq_b);
-            hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 0);
-            hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 1);
-            hipLaunchKernelGGL((pdm_scan_kernel<256, 4, true>), dim3((unsigned)groups0, (unsigned)n_z), dim3(256),
-                               lds_bytes(last, 256), st, a);
-            hipLaunchKernelGGL(pdm_finish_kernel, dim3((unsigned)groups0), dim3(64), (size_t)nbins * 64 * 16, st, a);
-            PDC_HIP(hipGetLastError());
-            return PDC_OK;
+    const SplitShape sh = split_shape(kind, n, n_periods, nb, nc);
+    if (sh.n_z > 1) {
+        a.p_pad = sh.p_pad;
+        a.n_z = (int)sh.n_z;
+        a.z_len = sh.z_len;
+        a.n_stat = sh.n_stat;
+        PDC_TRY(allow_lds(pdm_scan_kernel<256, 4, true>));
+        PDC_TRY(allow_lds(pdm_finish_kernel));
+        void *spv = work;
+        if (work) {
+            PDC_REQUIRE(work_bytes >= sh.bytes, "phase scan: workspace too small (%lld < %lld bytes)",
+                        (long long)work_bytes, (long long)sh.bytes);
+        } else {   // cached per (device, stream): see pdc_internal.h on why not hipMallocAsync
+            PDC_TRY(stream_scratch(device, st, sh.bytes, &spv));
         }
+        char *const sp = static_cast<char *>(spv);
+        // PDC_PDM_POISON=1 fills the scratch with a NaN pattern first (debugging aid: every word the kernels
+        // read must have been written by them)
+        static const bool poison = [] { const char *e = getenv("PDC_PDM_POISON"); return e && e[0] == '1'; }();
+        if (poison) PDC_HIP(hipMemsetAsync(sp, 0x7f, (size_t)sh.bytes, st));
+        a.stat = reinterpret_cast<double *>(sp);
+        a.psum = reinterpret_cast<double *>(sp + sh.stat_b);
+        a.pq = reinterpret_cast<double *>(sp + sh.stat_b + sh.psum_b);
+        a.pcnt = reinterpret_cast<unsigned *>(sp + sh.stat_b + sh.psum_b + sh.pq_b);
+        hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 0);
+        hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 1);
+        hipLaunchKernelGGL((pdm_scan_kernel<256, 4, true>), dim3((unsigned)groups0, (unsigned)sh.n_z), dim3(256),
+                           lds_bytes(last, 256), st, a);
+        hipLaunchKernelGGL(pdm_finish_kernel, dim3((unsigned)groups0), dim3(64), (size_t)nbins * 64 * 16, st, a);
+        PDC_HIP(hipGetLastError());
+        return PDC_OK;
     }
     const int bpb = kind == 2 ? 4 : 12;
     if (lds_bytes(last, 256, bpb) <= 150 * 1024) {
@@ -511,28 +555,47 @@ int phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, cons
     return PDC_OK;
 }
 
-}  // namespace
-
 extern "C" {
+
+int64_t pdc_phase_work_bytes(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
+    if (kind == 3) return pdc_stringlength_work_bytes(n, n_periods);
+    return phase_stat_work_bytes(kind, n, n_periods, nb, nc);
+}
+
+int pdc_phase_scan_dev(int kind, int device, void *stream, const double *d_t, const double *d_v, int64_t n,
+                       const double *d_periods, int64_t n_periods, int nb, int nc, double sigma, double *d_out,
+                       void *work, int64_t work_bytes) {
+    PDC_REQUIRE(kind >= 0 && kind <= 3, "phase scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional entropy) or 3 "
+                                        "(StringLength)");
+    if (kind == 3)
+        return pdc_stringlength_scan_dev(device, stream, d_t, d_v, n, d_periods, n_periods, d_out, work, work_bytes);
+    const int64_t need = phase_stat_work_bytes(kind, n, n_periods, nb, nc);
+    PDC_REQUIRE(need >= 0, "phase scan: bad size");
+    PDC_REQUIRE(need == 0 || (work && work_bytes >= need), "phase scan: workspace too small (%lld < %lld bytes)",
+                (long long)work_bytes, (long long)need);
+    static char dummy;   // (a non-NULL workspace keeps phase_stat_dev away from the per-stream cache)
+    return phase_stat_dev(kind, device, (hipStream_t)stream, d_t, d_v, n, d_periods, n_periods, nb, nc, sigma, d_out,
+                          work ? work : &dummy, work ? work_bytes : 0);
+}
 
 int pdc_pdm_scan_dev(int device, void *stream, const double *d_t, const double *d_x, int64_t n,
                      const double *d_periods, int64_t n_periods, int nb, int nc, double sigma,
                      double *d_theta) {
     return phase_stat_dev(0, device, (hipStream_t)stream, d_t, d_x, n, d_periods, n_periods, nb, nc, sigma,
-                          d_theta);
+                          d_theta, nullptr, 0);
 }
 
 int pdc_aov_scan_dev(int device, void *stream, const double *d_t, const double *d_x, int64_t n,
                      const double *d_periods, int64_t n_periods, int n_bins, double *d_theta) {
     return phase_stat_dev(1, device, (hipStream_t)stream, d_t, d_x, n, d_periods, n_periods, n_bins, 1, 1.0,
-                          d_theta);
+                          d_theta, nullptr, 0);
 }
 
 int pdc_cond_entropy_scan_dev(int device, void *stream, const double *d_t, const double *d_mag_bin, int64_t n,
                               const double *d_periods, int64_t n_periods, int n_phase, int n_mag,
                               double *d_entropy) {
     return phase_stat_dev(2, device, (hipStream_t)stream, d_t, d_mag_bin, n, d_periods, n_periods, n_phase,
-                          n_mag, 1.0, d_entropy);
+                          n_mag, 1.0, d_entropy, nullptr, 0);
 }
 
 namespace {
@@ -541,9 +604,15 @@ int phase_stat_host(int kind, const double *t, const double *x, int64_t n, const
                     int64_t n_periods, int nb, int nc, double sigma, double *out, int device) {
     PDC_REQUIRE(t && x && (periods || n_periods == 0) && (out || n_periods == 0), "phase scan: NULL argument");
     PDC_REQUIRE(n >= 0 && n_periods >= 0, "phase scan: negative size");
+    if (kind == 2)   // the magnitude bins index the cell histogram: reject what is not one of 0 .. n_mag-1
+        for (int64_t i = 0; i < n; ++i)
+            PDC_REQUIRE(x[i] >= 0.0 && x[i] < (double)nc,
+                        "cond_entropy: mag_bin[%lld] = %g is not a bin index in 0 .. %d", (long long)i, x[i], nc - 1);
     PDC_TRY(use_device(device));
     DeviceLock lock(device);
-    void *d_t, *d_x, *d_p, *d_th;
+    void *d_t, *d_x, *d_p, *d_th, *d_work;
+    const int64_t wb = phase_stat_work_bytes(kind, n, n_periods, nb < 1 ? 1 : nb, nc < 1 ? 1 : nc);
+    PDC_TRY(cached(device, SLOT_WORK, wb > 0 ? wb : 0, &d_work));
     PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
     PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_x));
     PDC_TRY(cached(device, SLOT_IN2, n_periods * 8, &d_p));
@@ -553,7 +622,7 @@ int phase_stat_host(int kind, const double *t, const double *x, int64_t n, const
     PDC_HIP(hipMemcpyAsync(d_x, x, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_p, periods, n_periods * 8, hipMemcpyHostToDevice, st));
     PDC_TRY(phase_stat_dev(kind, device, st, (double *)d_t, (double *)d_x, n, (double *)d_p, n_periods, nb, nc,
-                           sigma, (double *)d_th));
+                           sigma, (double *)d_th, d_work, wb > 0 ? wb : 0));
     PDC_HIP(hipMemcpyAsync(out, d_th, n_periods * 8, hipMemcpyDeviceToHost, st));
     PDC_HIP(hipStreamSynchronize(st));
     return PDC_OK;

@@ -1,5 +1,6 @@
 // Runtime side of the C ABI: errors, device selection, cached workspaces, memory/stream/event
 // wrappers.  Nothing here is on the hot path.
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -58,6 +59,20 @@ int use_device(int device) {
     return PDC_OK;
 }
 
+static std::atomic<int64_t> g_device_allocs{0}, g_pinned_allocs{0};
+
+int device_alloc(void **dptr, int64_t bytes) {
+    PDC_HIP(hipMalloc(dptr, (size_t)(bytes > 0 ? bytes : 1)));
+    g_device_allocs.fetch_add(1);
+    return PDC_OK;
+}
+
+int pinned_alloc(void **hptr, int64_t bytes) {
+    PDC_HIP(hipHostMalloc(hptr, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault));
+    g_pinned_allocs.fetch_add(1);
+    return PDC_OK;
+}
+
 int cached(int device, Slot slot, int64_t bytes, void **dptr) {
     DeviceState *st = g_devices[device];
     if (bytes < 256) bytes = 256;
@@ -68,11 +83,10 @@ int cached(int device, Slot slot, int64_t bytes, void **dptr) {
             st->cap[slot] = 0;
         }
         int64_t want = bytes + bytes / 8;  // head-room so a slowly growing caller does not thrash
-        hipError_t e = hipMalloc(&st->buf[slot], (size_t)want);
-        if (e != hipSuccess) {
+        if (device_alloc(&st->buf[slot], want) != PDC_OK) {
             (void)hipGetLastError();
             want = bytes;
-            PDC_HIP(hipMalloc(&st->buf[slot], (size_t)want));
+            PDC_TRY(device_alloc(&st->buf[slot], want));
         }
         st->cap[slot] = want;
     }
@@ -87,27 +101,53 @@ struct StreamScratch {
     int64_t cap;
 };
 static std::mutex g_scratch_mutex;
-static std::vector<StreamScratch> g_scratch;
+static std::vector<StreamScratch> g_scratch;   // oldest entry first
+constexpr size_t kScratchEntries = 16;
+
+// (the caller holds g_scratch_mutex) hipFree synchronises the device: no kernel still uses the block
+static int free_scratch_entry(size_t i) {
+    StreamScratch s = g_scratch[i];
+    g_scratch.erase(g_scratch.begin() + (long)i);
+    if (s.buf) {
+        int now = -1;
+        PDC_HIP(hipGetDevice(&now));
+        PDC_HIP(hipSetDevice(s.device));
+        PDC_HIP(hipFree(s.buf));
+        PDC_HIP(hipSetDevice(now));
+    }
+    return PDC_OK;
+}
 
 int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
     std::lock_guard<std::mutex> lk(g_scratch_mutex);
     if (bytes < 256) bytes = 256;
-    StreamScratch *e = nullptr;
-    for (StreamScratch &s : g_scratch)
-        if (s.device == device && s.stream == stream) e = &s;
-    if (!e) {
+    size_t at = g_scratch.size();
+    for (size_t i = 0; i < g_scratch.size(); ++i)
+        if (g_scratch[i].device == device && g_scratch[i].stream == stream) at = i;
+    if (at == g_scratch.size()) {
+        // a stream handle this table has not seen: the caller may be cycling through transient streams
+        // (and HIP may never hand the same address out again), so the table is bounded - oldest goes
+        while (g_scratch.size() >= kScratchEntries) PDC_TRY(free_scratch_entry(0));
         g_scratch.push_back({device, stream, nullptr, 0});
-        e = &g_scratch.back();
+        at = g_scratch.size() - 1;
     }
+    StreamScratch *e = &g_scratch[at];
     if (e->cap < bytes) {
         if (e->buf) PDC_HIP(hipFree(e->buf));   // (synchronises the device: no kernel still uses it)
         e->buf = nullptr;
         e->cap = 0;
         const int64_t want = bytes + bytes / 4;
-        PDC_HIP(hipMalloc(&e->buf, (size_t)want));
+        PDC_TRY(device_alloc(&e->buf, want));
         e->cap = want;
     }
     *dptr = e->buf;
+    return PDC_OK;
+}
+
+int drop_stream_scratch(int device, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_scratch_mutex);
+    for (size_t i = 0; i < g_scratch.size(); ++i)
+        if (g_scratch[i].device == device && g_scratch[i].stream == stream) return free_scratch_entry(i);
     return PDC_OK;
 }
 
@@ -209,11 +249,16 @@ int pdc_release(void) {
     return PDC_OK;
 }
 
+int pdc_alloc_counts(int64_t *device_allocs, int64_t *pinned_allocs) {
+    if (device_allocs) *device_allocs = g_device_allocs.load();
+    if (pinned_allocs) *pinned_allocs = g_pinned_allocs.load();
+    return PDC_OK;
+}
+
 int pdc_malloc(int device, int64_t bytes, void **dptr) {
     PDC_REQUIRE(dptr != nullptr && bytes >= 0, "pdc_malloc: bad arguments");
     PDC_TRY(use_device(device));
-    PDC_HIP(hipMalloc(dptr, (size_t)(bytes > 0 ? bytes : 1)));
-    return PDC_OK;
+    return device_alloc(dptr, bytes);
 }
 
 int pdc_free(int device, void *dptr) {
@@ -254,7 +299,10 @@ int pdc_stream_create(int device, void **stream) {
 
 int pdc_stream_destroy(int device, void *stream) {
     PDC_TRY(use_device(device));
-    if (stream) PDC_HIP(hipStreamDestroy((hipStream_t)stream));
+    if (stream) {
+        PDC_TRY(drop_stream_scratch(device, (hipStream_t)stream));   // its split-mode scratch goes with it
+        PDC_HIP(hipStreamDestroy((hipStream_t)stream));
+    }
     return PDC_OK;
 }
 

@@ -191,16 +191,19 @@ class AOV(object):
         The trial-period grid, exactly as for :class:`PDM` (``phase.py:167-180``).
     device: int, keyword-only
         GPU ordinal.
+    devices: sequence of int, keyword-only
+        Several GPUs of this node, one contiguous slab of the period grid each.
     """
 
     def __init__(self, n_bins=10, p_min=None, p_max=None, n_periods=1000, oversample=1, cores=None,
-                 *, device=None):
+                 *, device=None, devices=None):
         self.n_bins = n_bins
         self.p_min, self.p_max = p_min, p_max
         self.n_periods = n_periods
         self.oversample = oversample
         self.cores = cores
         self.device = device
+        self.devices = None if devices is None else tuple(devices)
 
     def __call__(self, signal):
         signal = _coerce(signal)
@@ -209,7 +212,8 @@ class AOV(object):
         self.x = np.asarray(signal.values, dtype=float)
         self.periods, _, _ = _pdm_periods(signal, self.p_min, self.p_max, self.n_periods,
                                           self.oversample)
-        theta = _cabi.aov_scan(self.t, self.x, self.periods, self.n_bins, device=self.device)
+        theta = _cabi.aov_scan(self.t, self.x, self.periods, self.n_bins, device=self.device,
+                               devices=self.devices)
         self.periodogram = FSeries(1 / self.periods, theta)
         return self.periodogram
 
@@ -227,16 +231,19 @@ class ConditionalEntropy(object):
         The trial-period grid, exactly as for :class:`PDM`.
     device: int, keyword-only
         GPU ordinal.
+    devices: sequence of int, keyword-only
+        Several GPUs of this node, one contiguous slab of the period grid each.
     """
 
     def __init__(self, n_phase=10, n_mag=5, p_min=None, p_max=None, n_periods=1000, oversample=1,
-                 cores=None, *, device=None):
+                 cores=None, *, device=None, devices=None):
         self.n_phase, self.n_mag = n_phase, n_mag
         self.p_min, self.p_max = p_min, p_max
         self.n_periods = n_periods
         self.oversample = oversample
         self.cores = cores
         self.device = device
+        self.devices = None if devices is None else tuple(devices)
 
     def __call__(self, signal):
         signal = _coerce(signal)
@@ -249,6 +256,6 @@ class ConditionalEntropy(object):
         self.periods, _, _ = _pdm_periods(signal, self.p_min, self.p_max, self.n_periods,
                                           self.oversample)
         entropy = _cabi.cond_entropy_scan(self.t, self.mag_bin, self.periods, self.n_phase, self.n_mag,
-                                          device=self.device)
+                                          device=self.device, devices=self.devices)
         self.periodogram = FSeries(1 / self.periods, entropy)
         return self.periodogram

@@ -120,7 +120,8 @@ class GLS(object):
         on the unchanged time axis (``spectral.py:140-152``).  The draws come from
         ``default_rng(seed).integers(0, n, n)`` once per replicate, in order, exactly as
         upstream; the replicates then run as ONE batched launch that shares the time axis and
-        returns only the NaN-aware maximum of each spectrum."""
+        returns only the NaN-aware maximum of each spectrum (with ``devices=(...)``: one contiguous
+        group of replicates per GPU, no exchange)."""
         rng = np.random.default_rng(random_seed)
         ndata = len(self.signal)
         values = np.asarray(self.signal.values, dtype=float)
@@ -145,7 +146,8 @@ class GLS(object):
         elif n_bootstraps:
             _, amax, _ = _cabi.gls_scan_batch(
                 t, values[picks].ravel(), resampled_err, offsets, f0, delta, nf, True,
-                self.psd, shared_t=True, want_power=False, want_peaks=True, device=self.device)
+                self.psd, shared_t=True, want_power=False, want_peaks=True, device=self.device,
+                devices=self.devices)
             bs_replicates[:] = amax
         self.bs_replicates = bs_replicates
         return self.bs_replicates

@@ -86,7 +86,7 @@ def oracle_backend(monkeypatch):
         return so.gls_power(t, y, dy, freq, delta, f0, fit_mean, psd, sums="exact")
 
     def gls_scan_batch(t, y, dy, offsets, f0, delta, nf, fit_mean=True, psd=False, shared_t=False,
-                       want_power=True, want_peaks=False, j_begin=0, device=None):
+                       want_power=True, want_peaks=False, j_begin=0, device=None, devices=None):
         rows = [gls_scan(t, y[a:b], dy[a:b], f0, delta, nf, fit_mean, psd)
                 for a, b in zip(offsets[:-1], offsets[1:])]
         return None, np.array([np.nanmax(r) for r in rows]), None
@@ -98,9 +98,9 @@ def oracle_backend(monkeypatch):
     monkeypatch.setattr(_cabi, "stringlength_scan",
                         lambda t, m, p, device=None, devices=None: so.stringlength_scan(t, m, np.asarray(p)))
     monkeypatch.setattr(_cabi, "aov_scan",
-                        lambda t, x, p, n_bins, device=None: so.aov_scan(t, x, np.asarray(p), n_bins))
+                        lambda t, x, p, n_bins, device=None, devices=None: so.aov_scan(t, x, np.asarray(p), n_bins))
     monkeypatch.setattr(_cabi, "cond_entropy_scan",
-                        lambda t, mb, p, n_phase, n_mag, device=None: so.cond_entropy_scan(t, mb, np.asarray(p), n_phase, n_mag))
+                        lambda t, mb, p, n_phase, n_mag, device=None, devices=None: so.cond_entropy_scan(t, mb, np.asarray(p), n_phase, n_mag))
 
 
 def curve(n=400, seed=2):

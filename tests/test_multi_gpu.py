@@ -1,0 +1,325 @@
+"""The N > 1 logic on ONE GPU, through the C ABI.
+
+* ``pdc_gls_plan_create_loopback``: N logical slots on one physical device, each with its own buffers,
+  streams and events; the all-gather runs as device-to-device copies on the communication streams.  The
+  slab arithmetic, padded tails (``nf % N != 0``, ``nf < N``, slots that own nothing), the generation
+  reuse of the double-buffered outputs and the event ordering are those of the N-GPU plan; every scan
+  must come back bit-identical to what slab-wise single-device calls give, from EVERY slot.
+* the phase scans / batches over a device list that repeats device 0: bit-identical to one launch, and
+  the second call of a given size makes no device or pinned allocation at all.
+
+The fan-out these replace: ``multiprocessing.Pool.map`` over trial periods,
+``/root/reference/src/periodicity/phase.py:69-70,185-186``."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import scan_oracle as so
+from periodicity_amd import _cabi
+from periodicity_amd.core import TSeries
+from periodicity_amd.phase import AOV, PDM, ConditionalEntropy, StringLength
+from periodicity_amd.spectral import GLS
+
+pytestmark = pytest.mark.gpu
+
+
+def synth(n, seed, period=37.3):
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(0, float(n), n))
+    dy = rng.uniform(0.05, 0.2, n)
+    y = 1.0 + 0.5 * np.sin(2 * np.pi * t / period) + dy * rng.standard_normal(n)
+    return t, y, dy
+
+
+def slabwise(t, y, dy, f0, delta, nf, n_slots, **kw):
+    """What an N-slot plan must produce: slot i scans [i*per, min((i+1)*per, nf)) starting its recurrences
+    at its own first frequency."""
+    per = -(-nf // n_slots)
+    parts = [_cabi.gls_scan(t, y, dy, f0, delta, min(per, nf - b), j_begin=b, **kw)
+             for b in range(0, nf, per)]
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("n_slots", [2, 3, 8])
+def test_loopback_plan_matches_slabwise_scans_on_every_slot(n_slots):
+    t, y, dy = synth(3000, 11 + n_slots)
+    plan = _cabi.GlsPlan([0], n_max=4000, nf_max=6000, loopback_slots=n_slots)
+    info = plan.info()
+    assert info == {"n_slots": n_slots, "rccl_ranks": 0, "exchange": "copy"}
+    plan.upload(t, y, dy)
+    # grids: divisible, not divisible, shorter than the slot count (trailing slots own nothing), one bin
+    for nf in (4096 - 4096 % n_slots, 5003, n_slots - 1, 1, 2 * n_slots + 1):
+        f0, delta = 0.0013, 0.00017
+        plan.scan(f0, delta, nf)
+        want = slabwise(t, y, dy, f0, delta, nf, n_slots)
+        for which in range(n_slots):
+            assert np.array_equal(plan.download(which), want), (nf, which)
+    # generation reuse: four back-to-back enqueues without a wait in between (two generations, each
+    # written twice); the last one must win on every slot, and an earlier grid must not leak into it
+    grids = [(0.002, 0.0003, 2999), (0.001, 0.0002, 5999), (0.004, 0.0001, 1001), (0.0015, 0.00025, 4000)]
+    for f0, delta, nf in grids:
+        plan.scan(f0, delta, nf)
+    f0, delta, nf = grids[-1]
+    want = slabwise(t, y, dy, f0, delta, nf, n_slots)
+    for which in (0, n_slots - 1):
+        assert np.array_equal(plan.download(which), want)
+    # a new light curve through the same plan, other flags
+    plan.upload(t[:1000], y[:1000], None)
+    plan.scan(0.003, 0.0004, 777, fit_mean=False, psd=True)
+    want = slabwise(t[:1000], y[:1000], None, 0.003, 0.0004, 777, n_slots, fit_mean=False, psd=True)
+    assert np.array_equal(plan.download(n_slots - 1), want)
+    assert plan.kernel_ms() > 0
+    with pytest.raises(ValueError):
+        plan.scan(0.1, 0.1, 10 ** 6)
+    plan.close()
+
+
+def test_loopback_plan_many_scans_stay_consistent_under_load():
+    """Long enough scans that the copies of generation g really overlap the scan of generation g^1."""
+    t, y, dy = synth(20_000, 3)
+    plan = _cabi.GlsPlan([0], n_max=t.size, nf_max=40_000, loopback_slots=4)
+    plan.upload(t, y, dy)
+    f0, delta = 0.0005, 0.00001
+    wants = {nf: slabwise(t, y, dy, f0, delta, nf, 4) for nf in (40_000, 39_999)}
+    for i in range(6):
+        nf = 40_000 - (i & 1)
+        plan.scan(f0, delta, nf)
+        if i in (2, 5):
+            for which in range(4):
+                assert np.array_equal(plan.download(which), wants[nf])
+    plan.close()
+
+
+def test_single_slot_loopback_and_validation():
+    t, y, dy = synth(500, 5)
+    plan = _cabi.GlsPlan([0], 600, 1000, loopback_slots=1)
+    assert plan.info()["exchange"] == "none"
+    plan.upload(t, y, dy)
+    plan.scan(0.01, 0.001, 400)
+    assert np.array_equal(plan.download(), _cabi.gls_scan(t, y, dy, 0.01, 0.001, 400))
+    plan.close()
+    with pytest.raises(ValueError):
+        _cabi.GlsPlan([0], 10, 10, loopback_slots=0)
+    with pytest.raises(ValueError):
+        _cabi.GlsPlan([_cabi.device_count()], 10, 10, loopback_slots=2)
+
+
+# ---- phase scans ----------------------------------------------------------------------------------------
+def phase_inputs(n=1500, seed=8):
+    rng = np.random.default_rng(seed)
+    t = np.sort(rng.uniform(0, 60.0, n))
+    x = np.sin(2 * np.pi * t / 4.4) + 0.2 * rng.standard_normal(n)
+    return t, x, so.stringlength_scale(x)
+
+
+def test_phase_plan_all_kinds_and_slot_counts():
+    t, x, m = phase_inputs()
+    mag = so.magnitude_bins(x, 5)
+    sigma = float(np.var(x, ddof=1))
+    for devices in ((0,), (0, 0), (0, 0, 0, 0, 0)):
+        plan = _cabi.PhasePlan(devices)
+        for n_periods in (1000, 7, 3, 1):
+            periods = np.linspace(0.7, 30.0, n_periods)
+            plan.upload(t, x)
+            plan.scan("pdm", periods, 5, 2, sigma)
+            got = plan.download()
+            np.testing.assert_allclose(got, _cabi.pdm_scan(t, x, periods, 5, 2, sigma), rtol=1e-12)
+            assert plan.kernel_ms() > 0
+            plan.scan("aov", periods, 10)
+            np.testing.assert_allclose(plan.download(), _cabi.aov_scan(t, x, periods, 10), rtol=1e-12)
+            plan.upload(t, mag)
+            plan.scan("cond_entropy", periods, 10, 5)
+            assert np.array_equal(plan.download(), _cabi.cond_entropy_scan(t, mag, periods, 10, 5))
+            plan.upload(t, m)
+            plan.scan("stringlength", periods)
+            assert np.array_equal(plan.download(), _cabi.stringlength_scan(t, m, periods))
+        plan.scan("pdm", np.empty(0), 5, 2, sigma)
+        assert plan.download().size == 0
+        plan.close()
+    with pytest.raises(ValueError):
+        _cabi.PhasePlan((0, _cabi.device_count()))
+    plan = _cabi.PhasePlan((0, 0))
+    with pytest.raises(ValueError):
+        plan.scan("pdm", [1.0, 2.0], 5, 2, 1.0)       # nothing uploaded yet
+    plan.close()
+
+
+def test_cached_fan_out_allocates_nothing_on_the_second_call():
+    """the per-call hipStreamCreate + hipMalloc of the phase fan-out.  Now: buffers, streams
+    and pinned staging live in a cache keyed by the device list."""
+    t, x, m = phase_inputs(30_000, 9)
+    sigma = float(np.var(x, ddof=1))
+    devices = (0, 0, 0)
+    calls = {
+        "pdm long grid": lambda: _cabi.pdm_scan(t, x, np.linspace(0.7, 30.0, 60_000), 5, 2, sigma, devices=devices),
+        "pdm short grid (sample split, scratch)": lambda: _cabi.pdm_scan(t, x, np.linspace(0.7, 30.0, 300), 5, 2, sigma,
+                                                                         devices=devices),
+        "stringlength": lambda: _cabi.stringlength_scan(t, m, np.linspace(0.7, 30.0, 600), devices=devices),
+        "aov": lambda: _cabi.aov_scan(t, x, np.linspace(0.7, 30.0, 500), 10, devices=devices),
+    }
+    for name, call in calls.items():
+        first = call()
+        before = _cabi.alloc_counts()
+        for _ in range(3):
+            assert np.array_equal(call(), first), name
+        assert _cabi.alloc_counts() == before, f"{name}: allocations on a repeated call"
+    # all four interleaved once everything has reached its high-water mark
+    for call in calls.values():
+        call()
+    before = _cabi.alloc_counts()
+    for call in calls.values():
+        call()
+    assert _cabi.alloc_counts() == before
+    # classes route there
+    sig = TSeries(t, x)
+    # (a shorter slab may split the samples over more workgroups: same bins and counts, other summation order)
+    np.testing.assert_allclose(PDM(p_min=0.7, p_max=30.0, n_periods=300, devices=(0, 0))(sig).values,
+                               PDM(p_min=0.7, p_max=30.0, n_periods=300)(sig).values, rtol=1e-12)
+    np.testing.assert_allclose(AOV(p_min=0.7, p_max=30.0, n_periods=300, devices=(0, 0))(sig).values,
+                               AOV(p_min=0.7, p_max=30.0, n_periods=300)(sig).values, rtol=1e-12)
+    assert np.array_equal(ConditionalEntropy(p_min=0.7, p_max=30.0, n_periods=300, devices=(0, 0))(sig).values,
+                          ConditionalEntropy(p_min=0.7, p_max=30.0, n_periods=300)(sig).values)
+    assert np.array_equal(StringLength(n_periods=300, devices=(0, 0))(sig).values,
+                          StringLength(n_periods=300)(sig).values)
+
+
+def test_transient_streams_do_not_grow_the_scratch_table():
+    """the split-mode scratch of the `_dev` entry is cached per (device, stream); a caller
+    cycling through streams must not leak one block per stream.  pdc_stream_destroy drops the entry; the
+    table is capped for raw HIP streams."""
+    lib = _cabi.lib()
+    t, x, _ = phase_inputs(40_000, 3)
+    periods = np.linspace(0.7, 30.0, 64)                     # few periods x many samples: split mode
+    bufs = [_cabi.DeviceBuffer.from_array(a) for a in (t, x, periods)]
+    out = _cabi.DeviceBuffer(periods.size * 8)
+    sigma = float(np.var(x, ddof=1))
+    want = _cabi.pdm_scan(t, x, periods, 5, 2, sigma)
+
+    def one_stream():
+        s = C.c_void_p()
+        _cabi.check(lib.pdc_stream_create(0, C.byref(s)))
+        _cabi.check(lib.pdc_pdm_scan_dev(0, s, bufs[0].ptr, bufs[1].ptr, t.size, bufs[2].ptr, periods.size, 5, 2,
+                                         sigma, out.ptr))
+        _cabi.check(lib.pdc_stream_sync(0, s))
+        got = out.to_array(np.float64, periods.size)
+        _cabi.check(lib.pdc_stream_destroy(0, s))
+        return got
+    assert np.array_equal(one_stream(), want)
+    # explicit workspace: nothing is cached at all
+    wb = lib.pdc_phase_work_bytes(0, t.size, periods.size, 5, 2)
+    assert wb > 0
+    work = _cabi.DeviceBuffer(wb)
+    before = _cabi.alloc_counts()
+    for _ in range(3):
+        _cabi.check(lib.pdc_phase_scan_dev(0, 0, None, bufs[0].ptr, bufs[1].ptr, t.size, bufs[2].ptr, periods.size,
+                                           5, 2, sigma, out.ptr, work.ptr, wb))
+        _cabi.check(lib.pdc_device_sync(0))
+        assert np.array_equal(out.to_array(np.float64, periods.size), want)
+    assert _cabi.alloc_counts() == before
+    with pytest.raises(ValueError):
+        _cabi.check(lib.pdc_phase_scan_dev(0, 0, None, bufs[0].ptr, bufs[1].ptr, t.size, bufs[2].ptr, periods.size,
+                                           5, 2, sigma, out.ptr, work.ptr, wb - 1))
+    for b in bufs + [out, work]:
+        b.free()
+
+
+def test_cond_entropy_dev_entry_ignores_out_of_range_bins():
+    """the kernel used the caller's double as an LDS index unchecked.  Through the `_dev` entry
+    a NaN / negative / too large magnitude bin now counts nowhere (as if the sample were absent); the host
+    entries reject such input."""
+    lib = _cabi.lib()
+    t, x, _ = phase_inputs(3000, 4)
+    mag = so.magnitude_bins(x, 5)
+    periods = np.linspace(0.7, 30.0, 200)
+    bad = mag.copy()
+    holes = np.array([3, 500, 1234, 2999])
+    bad[holes] = [np.nan, -1.0, 5.0, 1e300]
+    keep = np.ones(t.size, bool)
+    keep[holes] = False
+    want = _cabi.cond_entropy_scan(t[keep], mag[keep], periods, 10, 5)
+    bufs = [_cabi.DeviceBuffer.from_array(a) for a in (t, bad, periods)]
+    out = _cabi.DeviceBuffer(periods.size * 8)
+    _cabi.check(lib.pdc_cond_entropy_scan_dev(0, None, bufs[0].ptr, bufs[1].ptr, t.size, bufs[2].ptr, periods.size,
+                                              10, 5, out.ptr))
+    _cabi.check(lib.pdc_device_sync(0))
+    np.testing.assert_allclose(out.to_array(np.float64, periods.size), want, rtol=1e-12)
+    for b in bufs + [out]:
+        b.free()
+    out = np.empty(periods.size)
+    for entry, extra in ((lib.pdc_cond_entropy_scan, (0,)),
+                         (lib.pdc_cond_entropy_scan_multi, (_cabi._ptr(np.zeros(2, np.int32)), 2))):
+        status = entry(_cabi._ptr(t), _cabi._ptr(bad), t.size, _cabi._ptr(periods), periods.size, 10, 5,
+                       _cabi._ptr(out), *extra)
+        assert status == -1 and b"mag_bin" in lib.pdc_last_error()
+
+
+# ---- batches ---------------------------------------------------------------------------------------------
+def test_batch_sharded_over_curves_equals_one_launch():
+    rng = np.random.default_rng(12)
+    lens = rng.integers(150, 400, 37)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    t = np.concatenate([np.sort(rng.uniform(0, 300.0, k)) for k in lens])
+    dy = rng.uniform(0.05, 0.2, t.size)
+    y = np.sin(2 * np.pi * t / 9.0) + dy * rng.standard_normal(t.size)
+    f0, delta, nf = 0.001, 0.0007, 1500
+    one = _cabi.gls_scan_batch(t, y, dy, offsets, f0, delta, nf, want_peaks=True)
+    for devices in ((0, 0), (0, 0, 0, 0, 0), (0,) * 40):       # more slots than curves: some own nothing
+        many = _cabi.gls_scan_batch(t, y, dy, offsets, f0, delta, nf, want_peaks=True, devices=devices)
+        for a, b in zip(one, many):
+            assert np.array_equal(a, b)
+    peaks_only = _cabi.gls_scan_batch(t, y, None, offsets, f0, delta, nf, want_power=False, want_peaks=True,
+                                      fit_mean=False, psd=True, devices=(0, 0, 0))
+    ref = _cabi.gls_scan_batch(t, y, None, offsets, f0, delta, nf, want_power=False, want_peaks=True,
+                               fit_mean=False, psd=True)
+    assert peaks_only[0] is None and np.array_equal(peaks_only[1], ref[1]) and np.array_equal(peaks_only[2], ref[2])
+    _cabi.gls_scan_batch(t, y, dy, offsets, f0, delta, nf, want_peaks=True, devices=(0, 0, 0))
+    before = _cabi.alloc_counts()
+    again = _cabi.gls_scan_batch(t, y, dy, offsets, f0, delta, nf, want_peaks=True, devices=(0, 0, 0))
+    assert _cabi.alloc_counts() == before and np.array_equal(again[0], one[0])
+
+
+def test_bootstrap_sharded_over_device_slots(golden_dir):
+    """GLS.bootstrap (spectral.py:140-152) with the replicates dealt to device slots: same draws, same
+    maxima as the one-device batch and as golden G6."""
+    import os
+    g = np.load(os.path.join(golden_dir, "g6_bootstrap.npz"))
+    one = GLS()
+    one(TSeries(g["t"], g["y"]), err=g["dy"])
+    many = GLS(devices=(0, 0, 0))
+    many(TSeries(g["t"], g["y"]), err=g["dy"])
+    a = one.bootstrap(20, random_seed=42)
+    b = many.bootstrap(20, random_seed=42)
+    np.testing.assert_allclose(b, a, rtol=1e-12)      # (a smaller group may take the per-curve kernel)
+    np.testing.assert_allclose(b, g["replicates_exact"], rtol=1e-6)
+    t = g["t"]
+    big = GLS(devices=(0, 0))
+    big(TSeries(t, g["y"]))                              # equal weights, enough replicates for the shared kernel
+    ref = GLS()
+    ref(TSeries(t, g["y"]))
+    np.testing.assert_allclose(big.bootstrap(400, random_seed=1), ref.bootstrap(400, random_seed=1), rtol=1e-12)
+
+
+def test_pdm_split_mode_writes_every_scratch_word_it_reads(tmp_path):
+    """the split mode's scratch is a cached block that is as stale between calls as the pool
+    memory it replaced.  With PDC_PDM_POISON=1 the block is filled with a NaN pattern before every call: a
+    word read without having been written in the same call would surface as NaN / garbage.  Shapes change
+    between back-to-back calls (n_periods and n up and down); results must equal the unsplit kernel's
+    (PDC_PDM_SPLIT=0) to summation order and the oracle's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "pdm_poison_check.py")
+    outs = {}
+    for tag, env in (("poison", {"PDC_PDM_POISON": "1"}), ("unsplit", {"PDC_PDM_SPLIT": "0"})):
+        path = str(tmp_path / f"{tag}.npz")
+        run = subprocess.run([sys.executable, script, path], env=dict(os.environ, **env), cwd=root,
+                             capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        outs[tag] = np.load(path)
+    assert sorted(outs["poison"].files) == sorted(outs["unsplit"].files) and len(outs["poison"].files) >= 12
+    for key in outs["poison"].files:
+        a, b = outs["poison"][key], outs["unsplit"][key]
+        assert np.all(np.isfinite(a)), key
+        np.testing.assert_allclose(a, b, rtol=1e-11, err_msg=key)
