@@ -4,6 +4,7 @@ frequencies per GPU (BASELINE.json configs[1]); prints ONE JSON line on rank 0.
     python bench.py [--gpus N --steps K --warmup W]                  # one process, N devices
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W      # one rank per GPU
+    python bench.py --loopback N                                     # N logical slots on ONE device (testing)
 
 A step = one pass of the hot path over resident inputs: the weights prologue + direct-sum scan + fused
 epilogue (``pdc_gls_scan_dev``) writing power[nf] in HBM.  With N > 1 each GPU scans its own
@@ -17,22 +18,30 @@ Two ways to drive N GPUs, same kernels, same collective:
     ncclAllGather) - no torch anywhere;
   * under ``torch.distributed.run`` (WORLD_SIZE > 1 in the environment): one rank per GPU, torch is
     used for rendezvous, the barrier and the RCCL all-gather only.
+With N > 1 the line also carries ``extras``: the other configs sharded the way they shard - C5's period
+grid in N slabs (PDM, StringLength), C3's curves in N groups - kernel-only and end to end.
 
 The product path is the C ABI (libperiodicity_hip.so).  ``oracle/`` is touched only by the
-``cpu_baseline`` leg, after the clock has stopped.
+``cpu_baseline`` legs, after the clock has stopped.
 
-``roofline.frac`` is the EXECUTED fp64 vector-issue fraction: VALU wave-instructions per launch
-(rocprofv3 SQ_INSTS_VALU, from profiles/r02_pmc_summary.json, which tools/pmc_summary.py wrote for
-the kernel sources whose hash it records - a summary of other sources is refused) x 4 cycles / 1024
-SIMDs / 2.4 GHz / the HIP-event time of this run.  The 50-flop-per-pair figure of SURVEY.md 8d is
-reported beside it as ``algorithmic`` (it exceeds the direct-evaluation roofline because the kernel
-advances sin/cos by rotation recurrences instead of evaluating them per pair).
+Every roofline figure in the line means one of two things, and says which:
+  * ``executed_issue_frac``: VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, read from
+    profiles/r03_pmc_summary.json, which tools/pmc_summary.py wrote for the kernel sources whose hash it
+    records - a summary of other sources is refused) x 4 cycles / 1024 SIMDs / 2.4 GHz / the HIP-event
+    time of this run: the fraction of the fp64 vector issue slots the kernel filled (an upper bound
+    where the mix holds 32-bit instructions, which issue in fewer cycles);
+  * ``algorithmic_frac``: SURVEY.md 8d's per-unit work (50 flop per GLS pair, 40 per PDM pair, one
+    gathered record per StringLength pair, 8 B per spectrum bin) x units / time / the peak it is priced
+    against.  It may exceed 1 where the kernel does less work than the unit assumes (rotation
+    recurrences instead of a sincos per pair).
+The headline ``roofline.frac`` is the executed-issue fraction.
 """
 import argparse
 import ctypes as C
 import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -46,11 +55,11 @@ PEAK_FP64_VECTOR_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz (MI35
 SIMDS, CLOCK_HZ, FP64_ISSUE_CYCLES = 1024, 2.4e9, 4
 PDM_FLOP_PER_PAIR = 40.0
 SL_MODEL_BYTES_PER_PAIR = 48.0  # HBM bucket-pass model
-L2_GATHER_PER_S = 2.7e11        # tools/ubench/gather_rate.hip (profiles/r02_ubench_gather_rate.txt)
 HBM_PEAK_TBS = 8.0
 N_SAMPLES = 100_000
 NF_PER_GPU = 1_000_000
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+GATHER_UBENCH = os.path.join(ROOT, "profiles", "r03_ubench_gather_rate.json")
 
 
 def synth_curve(n, k=2, period=37.3):
@@ -72,6 +81,32 @@ def throughput_grid(t, nf):
     raise AssertionError((freq.size, nf))
 
 
+def c3_batch():
+    """BASELINE configs[2]: 4096 curves x 2000 samples, each its own seeded (t, y, dy), one shared grid."""
+    B, n, nf = 4096, 2000, 50_000
+    rng = np.random.default_rng(20241008 + 3)
+    tt = np.sort(rng.uniform(0, float(n), (B, n)), axis=1)
+    dd = rng.uniform(0.05, 0.2, (B, n))
+    pp = (5.0 + 0.01 * np.arange(B))[:, None]
+    yy = 1.0 + 0.5 * np.sin(2 * np.pi * tt / pp) + dd * rng.standard_normal((B, n))
+    df = 1.0 / n / 5
+    f = np.arange(0.5 * df, 0.5 * df + (nf - 1.5) * df + df, df)
+    assert f.size == nf
+    return tt, yy, dd, f
+
+
+def c5_inputs():
+    """BASELINE configs[4]: N=5e4 samples x 1e5 trial periods for PDM and StringLength."""
+    n, n_per = 50_000, 100_000
+    t5, y5, _ = synth_curve(n, 5, period=13.7)
+    periods = np.linspace(1.0, 100.0, n_per)
+    vmax, vmin = y5.max(), y5.min()
+    m = (y5 - vmax) / (2 * (vmax - vmin)) + 0.25
+    dfp = 0.1 / (t5[-1] - t5[0])
+    sl_periods = 1 / np.linspace(n_per * dfp, dfp, n_per)
+    return t5, y5, m, periods, sl_periods
+
+
 # which sources a profiled kernel was built from: a PMC summary entry is refused once any of them changed
 KERNEL_SOURCES = {
     "gls_": ("gls.hip", "gls_epilogue.h", "pdc_device.h"),
@@ -83,10 +118,14 @@ KERNEL_SOURCES = {
 }
 
 
+def file_sha(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
 def source_hashes():
     """sha256 (first 16 hex digits) of every kernel source; tools/pmc_summary.py stores the same."""
     src = os.path.join(ROOT, "periodicity_amd", "csrc")
-    return {name: hashlib.sha256(open(os.path.join(src, name), "rb").read()).hexdigest()[:16]
+    return {name: file_sha(os.path.join(src, name))
             for name in sorted(os.listdir(src)) if name.endswith((".hip", ".h"))}
 
 
@@ -101,8 +140,9 @@ def pmc_for(kernel_substr, measured_ms):
     """Counters of the profiled kernel whose name contains `kernel_substr` and whose profiled duration
     is closest to this run's; (None, reason) when the summary is absent or was collected for other
     sources of that kernel."""
+    rel = os.path.relpath(PMC_SUMMARY, ROOT)
     if not os.path.isfile(PMC_SUMMARY):
-        return None, "profiles/r02_pmc_summary.json is missing"
+        return None, f"{rel} is missing"
     summ = json.load(open(PMC_SUMMARY))
     now, then = source_hashes(), summ.get("src_sha", {})
     best = None
@@ -115,8 +155,7 @@ def pmc_for(kernel_substr, measured_ms):
         return None, f"no profiled '{kernel_substr}' launch within 25% of {measured_ms:.3f} ms"
     changed = [f for f in sources_of(best[1]) if now.get(f) != then.get(f)]
     if changed:
-        return None, (f"profiles/r02_pmc_summary.json was collected before {', '.join(changed)} changed: "
-                      "refused as stale")
+        return None, f"{rel} was collected before {', '.join(changed)} changed: refused as stale"
     return dict(best[2], name=best[1]), None
 
 
@@ -127,10 +166,7 @@ def valu_issue_block(kernel_substr, kernel_ms):
     busy_s = k["SQ_INSTS_VALU"] * FP64_ISSUE_CYCLES / SIMDS / CLOCK_HZ
     out = {"kernel": k["name"], "valu_wave_instr_per_launch": k["SQ_INSTS_VALU"],
            "frac": round(busy_s / (kernel_ms * 1e-3), 4),
-           "profiled_ms": k["ms"], "source": "profiles/r02_pmc_summary.json",
-           "note": "frac prices every VALU wave-instruction at the fp64 rate (4 cycles per wave64): exact for "
-                   "the fp64-fma streams of the GLS kernels, an upper bound where the mix holds 32-bit "
-                   "instructions (PDM, StringLength)"}
+           "profiled_ms": k["ms"], "source": os.path.relpath(PMC_SUMMARY, ROOT)}
     for key in ("hbm_bytes", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_LDS_BANK_CONFLICT",
                 "SQ_LDS_IDX_ACTIVE", "TCP_TCC_READ_REQ_sum"):
         if key in k:
@@ -138,22 +174,62 @@ def valu_issue_block(kernel_substr, kernel_ms):
     return out, None
 
 
+def two_fracs(kernel_substr, ms, algorithmic_frac, unit):
+    """The two roofline fields every entry of the line carries (module docstring)."""
+    blk, why = valu_issue_block(kernel_substr, ms)
+    out = {"executed_issue_frac": blk["frac"] if blk else None,
+           "algorithmic_frac": None if algorithmic_frac is None else round(algorithmic_frac, 4),
+           "algorithmic_unit": unit}
+    if blk:
+        out["executed_issue"] = {k: blk[k] for k in ("kernel", "valu_wave_instr_per_launch", "profiled_ms", "source")}
+    else:
+        out["executed_issue_note"] = why
+    return out, blk
+
+
+def gls_algorithmic_frac(pairs, ms):
+    return pairs * FLOP_PER_PAIR / (ms * 1e-3) / 1e12 / PEAK_FP64_VECTOR_TFLOPS
+
+
+def pdm_algorithmic_frac(pairs, ms):
+    return pairs * PDM_FLOP_PER_PAIR / (ms * 1e-3) / 1e12 / PEAK_FP64_VECTOR_TFLOPS
+
+
+def l2_gather_ceiling():
+    """Random 16-byte gathers per second the chip serves from an L2-resident table, as measured by
+    tools/ubench/gather_rate.hip and summarised (with the sha256 of that source) by tools/ubench_summary.py;
+    (None, reason) when the summary is absent or belongs to another version of the micro-benchmark."""
+    rel = os.path.relpath(GATHER_UBENCH, ROOT)
+    if not os.path.isfile(GATHER_UBENCH):
+        return None, f"{rel} is missing"
+    u = json.load(open(GATHER_UBENCH))
+    src = os.path.join(ROOT, "tools", "ubench", "gather_rate.hip")
+    if u.get("src_sha") != file_sha(src):
+        return None, f"{rel} was measured with another tools/ubench/gather_rate.hip: refused as stale"
+    return float(u["gather_16B_per_s"]), None
+
+
+def host_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
 def cpu_baseline(t, y, dy, freq, df, fmin):
     """The reference's own CPU algorithm (FFT/extirpolation, single-threaded numpy as upstream),
-    restated in oracle/scan_oracle.py, on the full N=1e5 x nf=1e6 workload; plus the exact
-    direct sum (the arithmetic the GPU kernel does) on a bounded sample, all host cores."""
+    restated in oracle/scan_oracle.py, on the full N=1e5 x nf=1e6 workload and at C1 / C4 (SURVEY.md
+    8d (i)); plus the exact direct sum (the arithmetic the GPU kernel does) on a bounded sample, all
+    host cores (8d (ii))."""
     from oracle import c_oracle as co
     from oracle import scan_oracle as so
     t0 = time.perf_counter()
     p_fft = so.gls_power(t, y, dy, freq, df, fmin, True, False, sums="fft")
     dt_fft = time.perf_counter() - t0
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    cores = host_cores()
     co.set_threads(cores)
     n_s, nf_s = 10_000, 8 * cores
     t0 = time.perf_counter()
     co.trig_sums_exact(t[:n_s], dy[:n_s], freq[:nf_s])      # calibration pass (also warms OpenMP)
     probe = max(time.perf_counter() - t0, 1e-3)
-    nf_s = int(min(freq.size, max(nf_s, nf_s * 10.0 / probe)))  # aim at ~10 s of CPU work
+    nf_s = int(min(freq.size, max(nf_s, nf_s * 6.0 / probe)))  # aim at ~6 s of CPU work
     t0 = time.perf_counter()
     co.trig_sums_exact(t[:n_s], dy[:n_s], freq[:nf_s])
     dt_direct = time.perf_counter() - t0
@@ -167,7 +243,38 @@ def cpu_baseline(t, y, dy, freq, df, fmin):
                        "sample": f"long-double direct sums, N={n_s} x nf={nf_s} "
                                  f"(one trig-sum pair), OpenMP: {dt_direct:.2f} s"},
     }
+    # the same single-threaded FFT-path restatement at C1 (1k x 1k) and C4 (1e6 x 1e7: three 1-GiB grids)
+    other = {}
+    for key, n_c, nf_c, k in (("c1", 1000, 1000, 1), ("c4", 1_000_000, 10_000_000, 4)):
+        tc, yc, dyc = synth_curve(n_c, k)
+        fc, dfc, fminc = throughput_grid(tc, nf_c)
+        reps = 20 if key == "c1" else 1
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pc = so.gls_power(tc, yc, dyc, fc, dfc, fminc, True, False, sums="fft")
+        dt = (time.perf_counter() - t0) / reps
+        other[key] = {"seconds": round(dt, 5), "effective_Gpair_per_s": round(n_c * nf_c / dt / 1e9, 2),
+                      "cores": 1, "kind": "port", "peak_bin": int(np.nanargmax(pc)),
+                      "sample": f"full workload N={n_c} x nf={nf_c}, FFT-extirpolation path in numpy"}
+        del pc, fc
+    base["fft_path_other_configs"] = other
     return base, p_fft
+
+
+def cpu_pool_baseline(cores):
+    """the phase scans under multiprocessing.Pool(all cores) as upstream runs them, in
+    a child process that never touches the GPU (tools/cpu_pool_baseline.py)."""
+    sub = max(2000, 16 * cores)
+    try:
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_pool_baseline.py"), str(sub), str(cores)],
+                             capture_output=True, text=True, timeout=600, cwd=ROOT)
+        res = json.loads(run.stdout.strip().splitlines()[-1])
+    except Exception as exc:                                  # the baseline is informational: never fail the bench
+        return {"error": f"{type(exc).__name__}: {exc}"}
+    res["kind"] = "port"
+    res["sample"] = (f"{sub} of 100000 trial periods of C5 (N=5e4), numpy restatement of _pdm / _stringlength under "
+                     f"multiprocessing.Pool({cores}).map as phase.py:69-70,185-186; map time scaled linearly")
+    return res
 
 
 class EventTimer:
@@ -209,22 +316,19 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
     t1 = time.perf_counter()
     cabi.gls_scan(t2, y2, dy2, f0, delta, nf2, device=dev)
     t2_ = time.perf_counter()
-    out["c2_end_to_end"] = {"ms": round((t2_ - t1) * 1e3, 3), "first_call_ms": round((t1 - t0) * 1e3, 3),
-                            "Gpair_per_s": round(t2.size * nf2 / (t2_ - t1) / 1e9, 1),
+    e2e_ms = (t2_ - t1) * 1e3
+    fr, _ = two_fracs("gls_scan_kernel", e2e_ms, gls_algorithmic_frac(float(t2.size) * nf2, e2e_ms),
+                      "50 flop/pair vs 78.6 TFLOP/s")
+    out["c2_end_to_end"] = {"ms": round(e2e_ms, 3), "first_call_ms": round((t1 - t0) * 1e3, 3),
+                            "Gpair_per_s": round(t2.size * nf2 / (t2_ - t1) / 1e9, 1), **fr,
                             "note": "pdc_gls_scan on host buffers: H2D of (t, y, dy) + prologue + scan + "
-                                    "D2H of power[1e6], wall clock"}
+                                    "D2H of power[1e6], wall clock (both fractions priced on the wall time)"}
 
     # -- C3: 4096 light curves x 2000 samples, shared 5e4-frequency grid ---------------------------
-    B, n, nf = 4096, 2000, 50_000
-    rng = np.random.default_rng(20241008 + 3)
-    tt = np.sort(rng.uniform(0, float(n), (B, n)), axis=1)
-    dd = rng.uniform(0.05, 0.2, (B, n))
-    pp = (5.0 + 0.01 * np.arange(B))[:, None]
-    yy = 1.0 + 0.5 * np.sin(2 * np.pi * tt / pp) + dd * rng.standard_normal((B, n))
+    tt, yy, dd, f = c3_batch()
+    B, n = tt.shape
+    nf = f.size
     offsets = np.arange(B + 1, dtype=np.int64) * n
-    df = 1.0 / n / 5
-    f = np.arange(0.5 * df, 0.5 * df + (nf - 1.5) * df + df, df)
-    assert f.size == nf
     g0, gd, _ = cabi.grid_params(f)
     bt, by, bdy, boff = DB.from_array(tt, dev), DB.from_array(yy, dev), DB.from_array(dd, dev), DB.from_array(offsets, dev)
     bt0 = DB.from_array(tt[0], dev)
@@ -246,11 +350,8 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
                                      ("c3_peaks_only", False, True, "gls_scan_kernel"),
                                      ("c3_shared_t_peaks_only", True, True, "gls_shared_kernel")):
         ms = tm.ms(c3(shared, peaks), reps=3)
-        blk, why = valu_issue_block(kern, ms)
-        out[key] = {"ms": round(ms, 3), "Gpair_per_s": round(pairs / ms / 1e6, 1),
-                    "valu_issue": blk if blk else None}
-        if why:
-            out[key]["valu_issue_note"] = why
+        fr, _ = two_fracs(kern, ms, gls_algorithmic_frac(pairs, ms), "50 flop/(pair, curve) vs 78.6 TFLOP/s")
+        out[key] = {"ms": round(ms, 3), "Gpair_per_s": round(pairs / ms / 1e6, 1), **fr}
     # ranked peaks with prominences + half-maximum crossings of the 4096 resident spectra (f3)
     k = 4
     pk = DB(B * (1 + 5 * k) * 8, dev)
@@ -258,12 +359,14 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
     p_idx, p_lo, p_hi = p_cnt + B * 8, p_cnt + B * 8 * (1 + k), p_cnt + B * 8 * (1 + 2 * k)
     p_h, p_p = p_cnt + B * 8 * (1 + 3 * k), p_cnt + B * 8 * (1 + 4 * k)
     ms = tm.ms(lambda: cabi.check(lib.pdc_peaks_topk_dev(dev, stream, power.ptr, B, nf, k, 1, p_cnt, p_idx, p_h, p_p,
-                                                         p_lo, p_hi)), reps=3)
+                                                         p_lo, p_hi)), reps=5)
     ms_h = tm.ms(lambda: cabi.check(lib.pdc_peaks_topk_dev(dev, stream, power.ptr, B, nf, k, 0, p_cnt, p_idx, p_h, p_p,
-                                                           p_lo, p_hi)), reps=3)
+                                                           p_lo, p_hi)), reps=5)
     gbps = B * nf * 8 / ms / 1e6
+    fr, _ = two_fracs("peaks_topk_kernel", ms, gbps / (HBM_PEAK_TBS * 1000), "8 B per spectrum bin read once vs 8 TB/s HBM")
     out["c3_peaks_topk"] = {"ms": round(ms, 3), "k": k, "by": "prominence", "ms_by_height": round(ms_h, 3),
-                            "GBps_over_spectra": round(gbps, 1),
+                            "GBps_over_spectra": round(gbps, 1), **fr,
+                            "algorithmic_frac_by_height": round(B * nf * 8 / ms_h / 1e6 / (HBM_PEAK_TBS * 1000), 4),
                             "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_TBS * 1000,
                                          "unit": "GB/s", "frac": round(gbps / (HBM_PEAK_TBS * 1000), 4),
                                          "algorithmic_bytes": B * nf * 8,
@@ -281,60 +384,54 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
         b.free()
 
     # -- C5: PDM and StringLength, N=5e4 x 1e5 trial periods ----------------------------------------
-    n, n_per = 50_000, 100_000
-    t5, y5, _ = synth_curve(n, 5, period=13.7)
+    t5, y5, m, periods, sl_periods = c5_inputs()
+    n, n_per = t5.size, periods.size
     bt5 = DB.from_array(t5, dev)
     pairs = float(n) * n_per
-    periods = np.linspace(1.0, 100.0, n_per)
     bx, bp, bth = DB.from_array(y5, dev), DB.from_array(periods, dev), DB(n_per * 8, dev)
     sigma = float(np.var(y5, ddof=1))
     ms = tm.ms(lambda: cabi.check(lib.pdc_pdm_scan_dev(dev, stream, bt5.ptr, bx.ptr, n, bp.ptr, n_per, 5, 2,
                                                        sigma, bth.ptr)), reps=5)
-    blk, why = valu_issue_block("pdm_scan_kernel", ms)
+    fr, _ = two_fracs("pdm_scan_kernel<256, 4, false, 0>", ms, pdm_algorithmic_frac(pairs, ms), "40 flop/pair vs 78.6 TFLOP/s")
     ach = pairs * PDM_FLOP_PER_PAIR / ms / 1e9
-    out["c5_pdm"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1),
+    out["c5_pdm"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), **fr,
                      "roofline": {"bound": "valu", "achieved": round(ach, 2), "peak": PEAK_FP64_VECTOR_TFLOPS,
                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_FP64_VECTOR_TFLOPS, 4),
-                                  "note": "40 algorithmic fp64 flop per (sample, period) pair (SURVEY 8d)"},
-                     "valu_issue": blk}
-    if why:
-        out["c5_pdm"]["valu_issue_note"] = why
-    vmax, vmin = y5.max(), y5.min()
-    m = (y5 - vmax) / (2 * (vmax - vmin)) + 0.25
-    dfp = 0.1 / (t5[-1] - t5[0])
-    sl_periods = 1 / np.linspace(n_per * dfp, dfp, n_per)
+                                  "note": "40 algorithmic fp64 flop per (sample, period) pair (SURVEY 8d)"}}
     bm, bsp, be = DB.from_array(m, dev), DB.from_array(sl_periods, dev), DB(n_per * 8, dev)
     swb = lib.pdc_stringlength_work_bytes(n, n_per)
     swork = DB(swb, dev)
     ms = tm.ms(lambda: cabi.check(lib.pdc_stringlength_scan_dev(dev, stream, bt5.ptr, bm.ptr, n, bsp.ptr, n_per,
                                                                 be.ptr, swork.ptr, swb)), reps=5)
-    blk, why = valu_issue_block("sl_", ms)
-    floor_ms = pairs / L2_GATHER_PER_S * 1e3
+    ceiling, why_c = l2_gather_ceiling()
+    floor_ms = None if ceiling is None else pairs / ceiling * 1e3
+    fr, _ = two_fracs("sl_fast_kernel", ms, None if floor_ms is None else floor_ms / ms,
+                      "one gathered 16-byte (t, m) record per pair vs the measured L2 random-gather rate")
     out["c5_stringlength"] = {
-        "ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1),
-        "roofline": {"bound": "l2-gather", "achieved": round(pairs / ms / 1e6, 1), "peak": L2_GATHER_PER_S / 1e9,
-                     "unit": "G gathered records/s", "frac": round(floor_ms / ms, 4),
+        "ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), **fr,
+        "roofline": {"bound": "l2-gather", "achieved": round(pairs / ms / 1e6, 1),
+                     "peak": None if ceiling is None else round(ceiling / 1e9, 1),
+                     "unit": "G gathered records/s", "frac": None if floor_ms is None else round(floor_ms / ms, 4),
+                     "ceiling_source": os.path.relpath(GATHER_UBENCH, ROOT) if ceiling else why_c,
                      "note": "a sort by phase gathers one 16-byte (t, m) record per (sample, period) pair "
-                             "from an L2-resident table; random accesses are served at 2.7e11/s chip-wide "
-                             "whatever their width (tools/ubench/gather_rate.hip, "
-                             "profiles/r02_ubench_gather_rate.txt)"},
+                             "from an L2-resident table; random accesses are served at one rate chip-wide "
+                             "whatever their width (tools/ubench/gather_rate.hip)"},
         "survey_hbm_model": {"bytes_per_pair": SL_MODEL_BYTES_PER_PAIR,
                              "achieved_TBps": round(pairs * SL_MODEL_BYTES_PER_PAIR / ms / 1e9, 2),
                              "frac_of_8TBps": round(pairs * SL_MODEL_BYTES_PER_PAIR / ms / 1e9 / HBM_PEAK_TBS, 3),
                              "note": "SURVEY 8d's HBM bucket-pass model (48 B/pair); the kernel sorts in LDS "
-                                     "and moves none of these bytes through HBM, so this may exceed 1"},
-        "valu_issue": blk}
-    if why:
-        out["c5_stringlength"]["valu_issue_note"] = why
+                                     "and moves none of these bytes through HBM, so this may exceed 1"}}
     if with_cpu:
         # the reference's per-period work on the host (never inside a timed GPU region): numpy restatement
-        # of PDM._pdm / _stringlength on ONE core as upstream's Pool worker runs it, and the plain-C
-        # restatement under OpenMP on all cores, on a bounded subsample of the grid, scaled linearly
+        # of PDM._pdm / _stringlength on ONE core as upstream's Pool worker runs it, the same under
+        # multiprocessing.Pool(all cores) as upstream fans it out, and the plain-C restatement under OpenMP
+        # on all cores, on a bounded subsample of the grid, scaled linearly
         from oracle import c_oracle as co
         from oracle import scan_oracle as so
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+        cores = host_cores()
         co.set_threads(cores)
         sub = np.linspace(0, n_per - 1, 16 * max(8, cores // 8)).astype(int)
+        pool = cpu_pool_baseline(cores)
         for key, np_fn, c_fn, grid in (
                 ("c5_pdm", lambda p: so.pdm_scan(t5, y5, p, 5, 2), lambda p: co.pdm_scan(t5, y5, p, 5, 2), periods),
                 ("c5_stringlength", lambda p: so.stringlength_scan(t5, m, p), lambda p: co.stringlength_scan(t5, m, p),
@@ -346,20 +443,26 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
             t0 = time.perf_counter()
             c_fn(grid[sub])
             dt_c = time.perf_counter() - t0
+            pooled = {k_: v for k_, v in pool.items() if k_ in ("cores", "periods_sampled", "kind", "sample", "error",
+                                                                "start_method")}
+            pooled.update(pool.get(key[3:], {}))
             out[key]["cpu_baseline"] = {
                 "numpy_ms_per_period_one_core": round(dt_np * 1e3, 3),
                 "numpy_core_seconds_full_grid": round(dt_np * n_per, 1),
                 "c_openmp_seconds_full_grid": round(dt_c * n_per / sub.size, 2), "cores": cores, "kind": "port",
-                "sample": f"{sub.size} of {n_per} trial periods, scaled linearly"}
+                "sample": f"{sub.size} of {n_per} trial periods, scaled linearly",
+                "multiprocessing_pool": pooled}
     ms = tm.ms(lambda: cabi.check(lib.pdc_aov_scan_dev(dev, stream, bt5.ptr, bx.ptr, n, bp.ptr, n_per, 10, bth.ptr)),
                reps=3)
-    out["c5_aov"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), "n_bins": 10}
+    fr, _ = two_fracs("pdm_scan_kernel<256, 4, false, 1>", ms, pdm_algorithmic_frac(pairs, ms), "40 flop/pair vs 78.6 TFLOP/s")
+    out["c5_aov"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), "n_bins": 10, **fr}
     lo5, hi5 = y5.min(), y5.max()
     mag = np.minimum(np.floor((y5 - lo5) / (hi5 - lo5) * 5), 4).astype(np.float64)
     bmag = DB.from_array(mag, dev)
     ms = tm.ms(lambda: cabi.check(lib.pdc_cond_entropy_scan_dev(dev, stream, bt5.ptr, bmag.ptr, n, bp.ptr, n_per,
                                                                 10, 5, bth.ptr)), reps=3)
-    out["c5_cond_entropy"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), "cells": "10 x 5"}
+    fr, _ = two_fracs("pdm_scan_kernel<256, 4, false, 2>", ms, pdm_algorithmic_frac(pairs, ms), "40 flop/pair vs 78.6 TFLOP/s")
+    out["c5_cond_entropy"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), "cells": "10 x 5", **fr}
     for b in (bt5, bx, bp, bth, bm, bsp, be, swork, bmag):
         b.free()
 
@@ -373,10 +476,222 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
     ms = tm.ms(lambda: cabi.check(lib.pdc_gls_scan_dev(dev, stream, b4[0].ptr, b4[1].ptr, b4[2].ptr, None, n4, 1, 0,
                                                        0.5 * df4, df4, 3 * nf4, nf4, 1, 0, p4.ptr, None, None,
                                                        w4.ptr, wb4)), reps=2, warm=1)
-    out["c4_slab_of_8"] = {"ms": round(ms, 2), "Gpair_per_s": round(float(n4) * nf4 / ms / 1e6, 1),
+    fr, _ = two_fracs("gls_scan_kernel", ms, gls_algorithmic_frac(float(n4) * nf4, ms), "50 flop/pair vs 78.6 TFLOP/s")
+    out["c4_slab_of_8"] = {"ms": round(ms, 2), "Gpair_per_s": round(float(n4) * nf4 / ms / 1e6, 1), **fr,
                            "note": "BASELINE configs[3] (N=1e6 x nf=1e7 over 8 GPUs): the slab j in [3.75e6, 5e6) "
                                    "one GPU scans, resident; the 8-GPU run adds one 10 MB-per-rank all-gather"}
     for b in b4 + [w4, p4]:
+        b.free()
+    return out
+
+
+# ---- N > 1: the other configs, sharded the way they shard ------------------------------------------------
+def slab(total, n, i):
+    per = -(-total // n)
+    b = min(i * per, total)
+    return b, min(b + per, total)
+
+
+def sharded_extras_one_process(cabi, lib, devices):
+    """One process, the listed device slots (a repeated ordinal = loopback): C5's period grid in one slab
+    per slot through the persistent phase plan, C3's curves in one contiguous group per slot."""
+    n_slots = len(devices)
+    out = {"slots": n_slots}
+    t5, y5, m, periods, sl_periods = c5_inputs()
+    n, n_per = t5.size, periods.size
+    pairs = float(n) * n_per
+    sigma = float(np.var(y5, ddof=1))
+    plan = cabi.PhasePlan(devices, n, n_per)
+    for key, kind, v, grid, args, afrac in (
+            ("c5_pdm_sharded", "pdm", y5, periods, (5, 2, sigma), pdm_algorithmic_frac),
+            ("c5_stringlength_sharded", "stringlength", m, sl_periods, (), None)):
+        plan.upload(t5, v)
+        plan.scan(kind, grid, *args)
+        plan.wait()
+        k_ms = []
+        for _ in range(3):
+            plan.scan(kind, grid, *args)
+            plan.wait()
+            k_ms.append(plan.kernel_ms())
+        t0 = time.perf_counter()
+        plan.upload(t5, v)
+        plan.scan(kind, grid, *args)
+        got = plan.download()
+        e2e = time.perf_counter() - t0
+        ms = float(np.median(k_ms))
+        out[key] = {"kernel_ms_slowest_slot": round(ms, 4), "Gpair_per_s_kernel": round(pairs / ms / 1e6, 1),
+                    "end_to_end_ms": round(e2e * 1e3, 3), "Gpair_per_s_end_to_end": round(pairs / e2e / 1e9, 1),
+                    "argmin": int(np.nanargmin(got)),
+                    "algorithmic_frac_per_slot": None if afrac is None else round(afrac(pairs / n_slots, ms), 4),
+                    "note": f"period grid in {n_slots} contiguous slabs, samples replicated, no exchange; kernel = HIP "
+                            "events around each slot's scan, the slowest; end to end = upload through pinned staging + "
+                            "scans + results back, wall"}
+    plan.close()
+
+    # C3: curves dealt to the slots; resident per-slot buffers, one stream per slot, peaks only
+    tt, yy, dd, f = c3_batch()
+    B, ns = tt.shape
+    nf = f.size
+    g0, gd, _ = cabi.grid_params(f)
+    DB = cabi.DeviceBuffer
+    slots = []
+    for i, dev in enumerate(devices):
+        b0, b1 = slab(B, n_slots, i)
+        if b1 == b0:
+            continue
+        nb = b1 - b0
+        s = C.c_void_p()
+        cabi.check(lib.pdc_stream_create(dev, C.byref(s)))
+        wb = lib.pdc_gls_work_bytes(nb * ns, nb, nf)
+        ev = []
+        for _ in range(2):
+            e = C.c_void_p()
+            cabi.check(lib.pdc_event_create(dev, C.byref(e)))
+            ev.append(e.value)
+        slots.append({"dev": dev, "nb": nb, "stream": s.value, "ev": ev, "wb": wb,
+                      "t": DB.from_array(tt[b0:b1], dev), "y": DB.from_array(yy[b0:b1], dev),
+                      "dy": DB.from_array(dd[b0:b1], dev),
+                      "off": DB.from_array(np.arange(nb + 1, dtype=np.int64) * ns, dev),
+                      "work": DB(wb, dev), "amax": DB(nb * 8, dev), "arg": DB(nb * 8, dev)})
+
+    def launch_all():
+        for s in slots:
+            cabi.check(lib.pdc_event_record(s["dev"], s["ev"][0], s["stream"]))
+            cabi.check(lib.pdc_gls_scan_dev(s["dev"], s["stream"], s["t"].ptr, s["y"].ptr, s["dy"].ptr, s["off"].ptr,
+                                            s["nb"] * ns, s["nb"], 0, g0, gd, 0, nf, 1, 0, None, s["amax"].ptr,
+                                            s["arg"].ptr, s["work"].ptr, s["wb"]))
+            cabi.check(lib.pdc_event_record(s["dev"], s["ev"][1], s["stream"]))
+        for s in slots:
+            cabi.check(lib.pdc_stream_sync(s["dev"], s["stream"]))
+    launch_all()
+    walls, kmax = [], []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        launch_all()
+        walls.append(time.perf_counter() - t0)
+        worst = 0.0
+        for s in slots:
+            ms = C.c_float()
+            cabi.check(lib.pdc_event_elapsed_ms(s["dev"], s["ev"][0], s["ev"][1], C.byref(ms)))
+            worst = max(worst, ms.value)
+        kmax.append(worst)
+    for s in slots:
+        for b in ("t", "y", "dy", "off", "work", "amax", "arg"):
+            s[b].free()
+        cabi.check(lib.pdc_stream_destroy(s["dev"], s["stream"]))
+    pairs3 = float(B) * ns * nf
+    offsets = np.arange(B + 1, dtype=np.int64) * ns
+    cabi.gls_scan_batch(tt.ravel(), yy.ravel(), dd.ravel(), offsets, g0, gd, nf, want_power=False, want_peaks=True,
+                        devices=devices)                       # sizes the cached per-slot buffers
+    t0 = time.perf_counter()
+    _, amax, _ = cabi.gls_scan_batch(tt.ravel(), yy.ravel(), dd.ravel(), offsets, g0, gd, nf, want_power=False,
+                                     want_peaks=True, devices=devices)
+    e2e = time.perf_counter() - t0
+    ms = float(np.median(kmax))
+    wall = float(np.median(walls))
+    out["c3_sharded_by_curves"] = {
+        "kernel_ms_slowest_slot": round(ms, 3), "launch_to_sync_wall_ms": round(wall * 1e3, 3),
+        "Gpair_per_s_kernel": round(pairs3 / wall / 1e9, 1),
+        "end_to_end_ms": round(e2e * 1e3, 2), "Gpair_per_s_end_to_end": round(pairs3 / e2e / 1e9, 1),
+        "algorithmic_frac_per_slot": round(gls_algorithmic_frac(pairs3 / n_slots, ms), 4),
+        "max_of_amax": float(np.nanmax(amax)),
+        "note": f"4096 curves in {n_slots} contiguous groups, one per slot, peaks only, no exchange; kernel = resident "
+                "inputs, all slots launched then synchronised (wall) and each slot's HIP events (slowest); end to end = "
+                "pdc_gls_scan_batch_multi on host buffers (H2D of 197 MB of samples + scans + [B] maxima back)"}
+    return out
+
+
+def sharded_extras_dist(cabi, lib, torch, dist, dev, rank, world):
+    """One rank per GPU (torch.distributed): this rank takes slab `rank` of C5's period grid / group `rank`
+    of C3's curves; kernel time = HIP events on this rank, MAX over ranks; end to end = barrier-to-barrier
+    wall of host-buffer calls + the all-gather of the results, MAX over ranks."""
+    out = {"ranks": world}
+    DB = cabi.DeviceBuffer
+    s = C.c_void_p()
+    cabi.check(lib.pdc_stream_create(dev, C.byref(s)))
+    stream = s.value
+    tm = EventTimer(lib, cabi, dev, stream)
+
+    def max_over_ranks(x):
+        v = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v.item())
+
+    def end_to_end(fn):
+        fn()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        return max_over_ranks(time.perf_counter() - t0), got
+
+    from periodicity_amd import distributed as pdist
+    t5, y5, m, periods, sl_periods = c5_inputs()
+    n, n_per = t5.size, periods.size
+    pairs = float(n) * n_per
+    sigma = float(np.var(y5, ddof=1))
+    b0, b1 = slab(n_per, world, rank)
+    cnt = b1 - b0
+    bt5 = DB.from_array(t5, dev)
+    for key, kind, v, grid, nbnc, afrac, e2e_fn in (
+            ("c5_pdm_sharded", 0, y5, periods, (5, 2), pdm_algorithmic_frac,
+             lambda: pdist.sharded_pdm(t5, y5, periods, 5, 2, sigma, device=dev)),
+            ("c5_stringlength_sharded", 3, m, sl_periods, (1, 1), None,
+             lambda: pdist.sharded_stringlength(t5, m, sl_periods, device=dev))):
+        bv, bp, bo = DB.from_array(v, dev), DB.from_array(grid[b0:b1], dev), DB(max(cnt, 1) * 8, dev)
+        wb = lib.pdc_phase_work_bytes(kind, n, cnt, *nbnc)
+        bw = DB(wb + 8, dev)
+        ms = tm.ms(lambda: cabi.check(lib.pdc_phase_scan_dev(kind, dev, stream, bt5.ptr, bv.ptr, n, bp.ptr, cnt, nbnc[0],
+                                                             nbnc[1], sigma, bo.ptr, bw.ptr, wb + 8)), reps=3)
+        ms = max_over_ranks(ms)
+        e2e, got = end_to_end(e2e_fn)
+        out[key] = {"kernel_ms_slowest_rank": round(ms, 4), "Gpair_per_s_kernel": round(pairs / ms / 1e6, 1),
+                    "end_to_end_ms": round(e2e * 1e3, 3), "Gpair_per_s_end_to_end": round(pairs / e2e / 1e9, 1),
+                    "argmin": int(np.nanargmin(got)),
+                    "algorithmic_frac_per_rank": None if afrac is None else round(afrac(pairs / world, ms), 4),
+                    "note": f"period grid in {world} contiguous slabs, one per rank, samples replicated; kernel = HIP "
+                            "events, MAX over ranks; end to end = host buffers in, slab scan, all-gather of the "
+                            "results (periodicity_amd.distributed), barrier to barrier, MAX over ranks"}
+        for b in (bv, bp, bo, bw):
+            b.free()
+    bt5.free()
+
+    tt, yy, dd, f = c3_batch()
+    B, ns = tt.shape
+    nf = f.size
+    g0, gd, _ = cabi.grid_params(f)
+    b0, b1 = slab(B, world, rank)
+    nb = b1 - b0
+    bufs = [DB.from_array(a[b0:b1], dev) for a in (tt, yy, dd)] + [DB.from_array(np.arange(nb + 1, dtype=np.int64) * ns, dev)]
+    wb = lib.pdc_gls_work_bytes(nb * ns, nb, nf)
+    work, amax, arg = DB(wb, dev), DB(nb * 8, dev), DB(nb * 8, dev)
+    ms = tm.ms(lambda: cabi.check(lib.pdc_gls_scan_dev(dev, stream, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr,
+                                                       nb * ns, nb, 0, g0, gd, 0, nf, 1, 0, None, amax.ptr, arg.ptr,
+                                                       work.ptr, wb)), reps=3)
+    ms = max_over_ranks(ms)
+    per = -(-B // world)
+    off = np.arange(nb + 1, dtype=np.int64) * ns
+
+    def c3_host():
+        _, a, _ = cabi.gls_scan_batch(tt[b0:b1].ravel(), yy[b0:b1].ravel(), dd[b0:b1].ravel(), off, g0, gd, nf,
+                                      want_power=False, want_peaks=True, device=dev)
+        send = torch.zeros(per, dtype=torch.float64, device="cuda")
+        send[:nb] = torch.from_numpy(a).cuda()
+        full = torch.empty(per * world, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(full, send)
+        return full[:B].cpu().numpy()
+    e2e, got = end_to_end(c3_host)
+    pairs3 = float(B) * ns * nf
+    out["c3_sharded_by_curves"] = {
+        "kernel_ms_slowest_rank": round(ms, 3), "Gpair_per_s_kernel": round(pairs3 / ms / 1e6, 1),
+        "end_to_end_ms": round(e2e * 1e3, 2), "Gpair_per_s_end_to_end": round(pairs3 / e2e / 1e9, 1),
+        "algorithmic_frac_per_rank": round(gls_algorithmic_frac(pairs3 / world, ms), 4),
+        "max_of_amax": float(np.nanmax(got)),
+        "note": f"4096 curves in {world} contiguous groups, one per rank, peaks only; kernel = resident inputs, HIP "
+                "events, MAX over ranks; end to end = host buffers in, batched scan, all-gather of the [B] maxima"}
+    for b in bufs + [work, amax, arg]:
         b.free()
     return out
 
@@ -392,6 +707,9 @@ def main():
                     help="take the torch.distributed path even with one rank (testing)")
     ap.add_argument("--force-plan", action="store_true",
                     help="take the one-process multi-device plan path even with one GPU (testing)")
+    ap.add_argument("--loopback", type=int, default=0, metavar="N",
+                    help="N logical slots on ONE device through the plan path (testing the N > 1 code on a 1-GPU box); "
+                         "the all-gather runs as device-to-device copies; `value` is not a scaling figure")
     args = ap.parse_args()
 
     # ONE JSON line on stdout, nothing else: RCCL writes a version banner to the C-level stdout of every
@@ -407,8 +725,10 @@ def main():
     dist_mode = world > 1 or args.force_dist            # one rank per GPU (torchrun)
     if dist_mode and args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    plan_mode = not dist_mode and (args.gpus > 1 or args.force_plan)   # one process, N devices
+    loopback = args.loopback if not dist_mode else 0
+    plan_mode = not dist_mode and (args.gpus > 1 or args.force_plan or loopback > 0)   # one process, N devices
     n_gpus = world if dist_mode else args.gpus
+    n_slots = loopback if loopback else n_gpus          # slabs of the grid
 
     torch = dist = None
     if dist_mode:
@@ -432,17 +752,22 @@ def main():
 
     # ---- workload --------------------------------------------------------------------------
     n = N_SAMPLES
-    nf_total = NF_PER_GPU * n_gpus
+    nf_total = NF_PER_GPU * n_slots
     t, y, dy = synth_curve(n)
     freq, df, fmin = throughput_grid(t, nf_total)
     f0, delta, _ = _cabi.grid_params(freq)
-    slab = NF_PER_GPU
-    j_begin = rank * slab if dist_mode else 0
+    slab_nf = NF_PER_GPU
+    j_begin = rank * slab_nf if dist_mode else 0
     stream = None
     plan = None
+    plan_info = None
 
     if plan_mode:
-        plan = _cabi.GlsPlan(list(range(args.gpus)), n, nf_total)
+        if loopback:
+            plan = _cabi.GlsPlan([0], n, nf_total, loopback_slots=loopback)
+        else:
+            plan = _cabi.GlsPlan(list(range(args.gpus)), n, nf_total)
+        plan_info = plan.info()
         plan.upload(t, y, dy)
     elif dist_mode:
         tt = torch.from_numpy(np.stack([t, y, dy])).cuda()
@@ -450,10 +775,10 @@ def main():
         # two generations of the output buffers: the all-gather of step i (RCCL's own stream) overlaps
         # the scan of step i+1 (compute stream); a buffer is reused only after its gather was waited on
         powers = [torch.empty(nf_total, dtype=torch.float64, device="cuda") for _ in range(2)]
-        work_bytes = lib.pdc_gls_work_bytes(n, 1, slab)
+        work_bytes = lib.pdc_gls_work_bytes(n, 1, slab_nf)
         work = torch.empty(work_bytes, dtype=torch.uint8, device="cuda")
         d_work = work.data_ptr()
-        slabs = [torch.empty(slab, dtype=torch.float64, device="cuda") for _ in range(2)]
+        slabs = [torch.empty(slab_nf, dtype=torch.float64, device="cuda") for _ in range(2)]
         pending = [None, None]
         counter = [0]
         stream = torch.cuda.current_stream().cuda_stream
@@ -461,7 +786,7 @@ def main():
         bufs = [_cabi.DeviceBuffer.from_array(a, dev) for a in (t, y, dy)]
         d_t, d_y, d_dy = (b.ptr for b in bufs)
         power_buf = _cabi.DeviceBuffer(nf_total * 8, dev)
-        work_bytes = lib.pdc_gls_work_bytes(n, 1, slab)
+        work_bytes = lib.pdc_gls_work_bytes(n, 1, slab_nf)
         work_buf = _cabi.DeviceBuffer(work_bytes, dev)
         d_work, d_power_slab = work_buf.ptr, power_buf.ptr
         sp = C.c_void_p()
@@ -488,7 +813,7 @@ def main():
         if ev:
             _cabi.check(lib.pdc_event_record(dev, ev[0], stream))
         _cabi.check(lib.pdc_gls_scan_dev(dev, stream, d_t, d_y, d_dy, None, n, 1, 0, f0, delta,
-                                         j_begin, slab, 1, 0, out_ptr, None, None, d_work,
+                                         j_begin, slab_nf, 1, 0, out_ptr, None, None, d_work,
                                          work_bytes))
         if ev:
             _cabi.check(lib.pdc_event_record(dev, ev[1], stream))
@@ -539,7 +864,7 @@ def main():
             plan.scan(f0, delta, nf_total)
             plan.wait()
             plan_kernel_ms.append(plan.kernel_ms())
-        kernel_s = float(np.median(plan_kernel_ms)) / 1e3
+        kernel_all_ms = [round(v, 4) for v in plan_kernel_ms]
         # PCIe-inclusive figure of the sharded call (never `value`): replicate the samples, scan, gather,
         # bring the whole power array back to the host
         te = time.perf_counter()
@@ -548,18 +873,25 @@ def main():
         plan.download(0)
         end_to_end_s = time.perf_counter() - te
     else:
-        kernel_ms = []
+        kernel_all_ms = []
         for a, b in events:
             ms = C.c_float()
             _cabi.check(lib.pdc_event_elapsed_ms(dev, a, b, C.byref(ms)))
-            kernel_ms.append(ms.value)
-        kernel_s = float(np.mean(kernel_ms)) / 1e3
+            kernel_all_ms.append(round(ms.value, 4))
+    kernel_s = float(np.median(kernel_all_ms)) / 1e3
+
+    sharded = None
+    if n_slots > 1 and not args.no_extras:
+        if dist_mode:
+            sharded = sharded_extras_dist(_cabi, lib, torch, dist, dev, rank, world)
+        else:
+            sharded = sharded_extras_one_process(_cabi, lib, [0] * loopback if loopback else list(range(args.gpus)))
 
     if rank == 0:
         if plan_mode:
             got = plan.download(0)
-            if args.gpus > 1:      # every device must hold the same gathered array
-                other = plan.download(args.gpus - 1)
+            if n_slots > 1:      # every slot must hold the same gathered array
+                other = plan.download(n_slots - 1)
                 assert np.array_equal(got, other, equal_nan=True), "all-gather left the devices with different arrays"
         elif dist_mode:
             got = powers[(counter[0] - 1) % 2].cpu().numpy()
@@ -567,10 +899,13 @@ def main():
             got = power_buf.to_array(np.float64, nf_total)
         pairs_per_step = float(n) * float(nf_total)
         value = pairs_per_step * args.steps / elapsed / 1e9
-        launch_pairs = float(n) * float(slab)
+        launch_pairs = float(n) * float(slab_nf)
+        kernel_ms_now = kernel_s * 1e3
         algorithmic = launch_pairs * FLOP_PER_PAIR / kernel_s / 1e12
-        blk, why = valu_issue_block("gls_scan_kernel", kernel_s * 1e3)
-        algo_bytes = 24.0 * n + 8.0 * slab
+        fr, blk = two_fracs("gls_scan_kernel", kernel_ms_now, algorithmic / PEAK_FP64_VECTOR_TFLOPS,
+                            "50 flop/pair vs 78.6 TFLOP/s")
+        why = fr.get("executed_issue_note")
+        algo_bytes = 24.0 * n + 8.0 * slab_nf
         if blk:
             achieved = blk["valu_wave_instr_per_launch"] * 64 * 2 / kernel_s / 1e12
             frac = round(achieved / PEAK_FP64_VECTOR_TFLOPS, 4)
@@ -588,8 +923,11 @@ def main():
                                    "frequencies per GPU (BASELINE configs[1]); inputs resident in "
                                    "HBM, exact direct summation",
                        "n_samples": n, "n_freq_total": nf_total,
-                       "sharding": f"frequency grid in {n_gpus} contiguous slab(s)"
-                                   + (", RCCL all-gather of power" if n_gpus > 1 else ""),
+                       "sharding": f"frequency grid in {n_slots} contiguous slab(s)"
+                                   + (", RCCL all-gather of power" if n_gpus > 1 else "")
+                                   + (f"; LOOPBACK: {loopback} logical slots on one device, the all-gather as "
+                                      "device-to-device copies (a test of the N > 1 logic, not a scaling figure)"
+                                      if loopback else ""),
                        "launcher": "one process, N devices (pdc_gls_plan_*, ncclCommInitAll)" if plan_mode
                                    else ("one rank per GPU (torch.distributed over RCCL)" if dist_mode
                                          else "one process, one device")},
@@ -598,7 +936,10 @@ def main():
                          "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s", "frac": frac,
                          "traffic": traffic,
                          "kernel": "gls_scan_kernel (+ prologue kernels, <0.1%)",
-                         "kernel_ms": round(kernel_s * 1e3, 4),
+                         "kernel_ms": round(kernel_ms_now, 4),
+                         "kernel_ms_is": "median of the HIP-event times of the timed steps",
+                         "kernel_ms_all": kernel_all_ms,
+                         **fr,
                          "valu_issue": blk,
                          "algorithmic": {"flop_per_pair": FLOP_PER_PAIR,
                                          "achieved_TFLOPs": round(algorithmic, 3),
@@ -617,12 +958,19 @@ def main():
             "peak_bin": int(np.nanargmax(got)),
         }
         if plan_mode:
+            out["rccl"] = {"ranks_in_communicator": plan_info["rccl_ranks"], "exchange": plan_info["exchange"],
+                           "slots": plan_info["n_slots"]}
             out["end_to_end_sharded"] = {
                 "ms": round(end_to_end_s * 1e3, 3),
                 "Gpair_per_s": round(pairs_per_step / end_to_end_s / 1e9, 1),
-                "note": "H2D of (t, y, dy) to every device + slab scans + RCCL all-gather + D2H of power[nf] "
+                "note": "H2D of (t, y, dy) to every device + slab scans + all-gather + D2H of power[nf] "
                         "from device 0, wall clock (the shape of pdc_gls_scan_multi / GLS(devices=...))"}
-        if n_gpus == 1 and not dist_mode and not plan_mode:
+        if dist_mode:
+            out["rccl"] = {"ranks_in_communicator": dist.get_world_size(),
+                           "exchange": f"rccl (torch.distributed, backend {dist.get_backend()})", "slots": world}
+        if sharded is not None:
+            out["extras"] = sharded
+        if n_slots == 1 and not dist_mode and not plan_mode:
             # informational: the reference's own algorithm on the device (Tier F), same workload
             wb = lib.pdc_gls_fft_work_bytes(n, nf_total)
             fwork = _cabi.DeviceBuffer(wb, dev)
@@ -641,7 +989,7 @@ def main():
             if not args.no_extras:
                 out["extras"] = extra_configs(lib, _cabi, dev, stream, t, y, dy, f0, delta, nf_total,
                                                with_cpu=not args.no_cpu_baseline)
-        if not args.no_cpu_baseline and n_gpus == 1:
+        if not args.no_cpu_baseline and n_gpus == 1 and n_slots == 1:
             base, p_fft = cpu_baseline(t, y, dy, freq, df, fmin)
             out["cpu_baseline"] = base
             out["peak_bin_matches_cpu_reference_path"] = bool(
@@ -651,6 +999,7 @@ def main():
     if plan_mode:
         plan.close()
     if dist_mode:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -26,6 +26,7 @@
 #include "pdc_internal.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 using namespace pdc;
 
@@ -197,9 +198,12 @@ __device__ __forceinline__ double ce_from_bins(CntAt cnt_at, int m0, int mag) {
 // to hide latency).  Each thread keeps its own private histogram; the SPLIT partial histograms of
 // a period are summed in a fixed order at the end.
 // ZS: split mode (the samples are split over blockIdx.y as well, see PdmArgs).
-// CE: conditional-entropy cells (phase bin x magnitude bin, counts only) instead of phase bins.
-template <int BLOCK, int SPLIT, bool ZS = false, bool CE = false>
+// KIND: which statistic (PdmArgs::kind; a template parameter so that the three show up as three kernels
+// in a profile): 0 PDM theta, 1 AoV, 2 conditional entropy - cells (phase bin x magnitude bin, counts
+// only) instead of phase bins.
+template <int BLOCK, int SPLIT, bool ZS = false, int KIND = 0>
 __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
+    constexpr bool CE = KIND == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int mag = CE ? a.nc : 1;                 // magnitude bins per phase bin
     const int m0 = CE ? a.nb : a.nb * a.nc;        // phase bins
@@ -265,7 +269,15 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         __syncthreads();
         for (int i = tid; i < kChunk; i += BLOCK) {
             const int64_t g = base + i;
-            stage[i] = g < s_end ? make_double2(a.t[g], CE ? a.x[g] : a.x[g] - mean) : make_double2(0.0, 0.0);
+            double2 v = g < s_end ? make_double2(a.t[g], CE ? a.x[g] : a.x[g] - mean) : make_double2(0.0, 0.0);
+            if (CE && !(v.y >= 0.0 && v.y < (double)mag)) {
+                // the magnitude bin is the caller's double and indexes the cell histogram: anything outside
+                // 0 .. mag-1 (NaN included) is staged with a NaN time - its phase is NaN, so it takes the exact
+                // path and counts nowhere, exactly as if the sample were absent (the host entries reject such
+                // input; `_dev` callers get this).  Checked once per staged sample, not once per pair.
+                v = make_double2(__builtin_nan(""), 0.0);
+            }
+            stage[i] = v;
         }
         __syncthreads();
         const int cnt = (int)((s_end - base) < kChunk ? (s_end - base) : kChunk);
@@ -296,12 +308,8 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
             if (k == m0) q_over += tx.y * tx.y;
         };
         auto add = [&](const int k, const double val, const unsigned inc) {
-            if (CE) {   // val = the sample's magnitude bin; a NaN phase (inc == 0) counts nowhere
-                // the bin is the caller's double: anything outside 0 .. mag-1 (NaN included) counts nowhere
-                // instead of indexing LDS with it (the host entry rejects such input; `_dev` callers get this)
-                const bool in_range = val >= 0.0 && val < (double)mag;
-                const int j = in_range ? (int)val : 0;
-                atomicAdd(&hcnt[(k * mag + j) * BLOCK + tid], in_range ? inc : 0u);
+            if (CE) {   // val = the sample's magnitude bin (range-checked when staged); a NaN phase (inc == 0) counts nowhere
+                atomicAdd(&hcnt[(k * mag + (int)val) * BLOCK + tid], inc);
             } else {
                 atomicAdd(&hsum[k * BLOCK + tid], val);
                 atomicAdd(&hcnt[k * BLOCK + tid], inc);
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     auto sum_at = [&](int b) { return hsum[b * BLOCK + tid]; };
     auto cnt_at = [&](int b) { return (long long)hcnt[b * BLOCK + tid]; };
     if (CE) a.theta[pidx] = ce_from_bins(cnt_at, m0, mag);
-    else if (a.kind == 1) a.theta[pidx] = aov_from_bins(sum_at, cnt_at, m0, q_total - q_nan);
+    else if (KIND == 1) a.theta[pidx] = aov_from_bins(sum_at, cnt_at, m0, q_total - q_nan);
     else a.theta[pidx] = theta_from_bins(sum_at, cnt_at, m0, a.nc, q_total, q_nan, q_over, a.sigma);
 }
 
@@ -518,39 +526,24 @@ int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t,
         return PDC_OK;
     }
     const int bpb = kind == 2 ? 4 : 12;
-    if (lds_bytes(last, 256, bpb) <= 150 * 1024) {
-        const size_t lds = lds_bytes(last, 256, bpb);
+    auto launch = [&](auto kernel, int block, int periods_per_block) -> int {
+        PDC_TRY(allow_lds(kernel));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)((n_periods + periods_per_block - 1) / periods_per_block)),
+                           dim3((unsigned)block), lds_bytes(last, block, bpb), st, a);
+        return PDC_OK;
+    };
+    auto launch_kind = [&](auto kind_tag) -> int {
+        constexpr int K = decltype(kind_tag)::value;
+        if (lds_bytes(last, 256, bpb) > 150 * 1024) return launch(pdm_scan_kernel<64, 1, false, K>, 64, 64);
         // waves = ceil(P/64) * SPLIT; aim at >= 4 waves per SIMD (4096 on the chip)
         const int64_t groups = (n_periods + 63) / 64;
-        const int split = groups >= 4096 ? 1 : (groups >= 2048 ? 2 : 4);
-        auto launch = [&](auto kernel, int periods_per_block) -> int {
-            PDC_TRY(allow_lds(kernel));
-            hipLaunchKernelGGL(kernel, dim3((unsigned)((n_periods + periods_per_block - 1) / periods_per_block)),
-                               dim3(256), lds, st, a);
-            return PDC_OK;
-        };
-        if (kind == 2) {
-            if (split == 4) PDC_TRY(launch(pdm_scan_kernel<256, 4, false, true>, 64));
-            else if (split == 2) PDC_TRY(launch(pdm_scan_kernel<256, 2, false, true>, 128));
-            else PDC_TRY(launch(pdm_scan_kernel<256, 1, false, true>, 256));
-        } else if (split == 4) {
-            PDC_TRY(launch(pdm_scan_kernel<256, 4>, 64));
-        } else if (split == 2) {
-            PDC_TRY(launch(pdm_scan_kernel<256, 2>, 128));
-        } else {
-            PDC_TRY(launch(pdm_scan_kernel<256, 1>, 256));
-        }
-    } else {
-        const size_t lds = lds_bytes(last, 64, bpb);
-        if (kind == 2) {
-            PDC_TRY(allow_lds(pdm_scan_kernel<64, 1, false, true>));
-            hipLaunchKernelGGL((pdm_scan_kernel<64, 1, false, true>), dim3((unsigned)((n_periods + 63) / 64)), dim3(64),
-                               lds, st, a);
-        } else {
-            PDC_TRY(allow_lds(pdm_scan_kernel<64, 1>));
-            hipLaunchKernelGGL((pdm_scan_kernel<64, 1>), dim3((unsigned)((n_periods + 63) / 64)), dim3(64), lds, st, a);
-        }
-    }
+        if (groups >= 4096) return launch(pdm_scan_kernel<256, 1, false, K>, 256, 256);
+        if (groups >= 2048) return launch(pdm_scan_kernel<256, 2, false, K>, 256, 128);
+        return launch(pdm_scan_kernel<256, 4, false, K>, 256, 64);
+    };
+    if (kind == 2) PDC_TRY(launch_kind(std::integral_constant<int, 2>{}));
+    else if (kind == 1) PDC_TRY(launch_kind(std::integral_constant<int, 1>{}));
+    else PDC_TRY(launch_kind(std::integral_constant<int, 0>{}));
     PDC_HIP(hipGetLastError());
     return PDC_OK;
 }

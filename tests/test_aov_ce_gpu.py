@@ -29,6 +29,27 @@ def test_aov_matches_published_formula(n, n_periods, n_bins):
     assert np.argmax(got) == np.argmax(want)
 
 
+def test_aov_is_scipy_one_way_anova_over_the_phase_bins():
+    """An independent, third-party pin: Theta_AoV IS the one-way ANOVA F statistic of the samples grouped by
+    phase bin (Schwarzenberg-Czerny 1989 section 2) - scipy.stats.f_oneway over the groups numpy's own
+    ``(t / P) % 1`` and ``floor(phi * r)`` produce, for the kernel AND for the oracle's restatement."""
+    from scipy.stats import f_oneway
+    t, x = curve(4000, 321, t_shift=-77.25)
+    periods = np.concatenate([np.linspace(1.5, 50.0, 40), [13.7, 27.4, 6.85]])
+    for r in (4, 10, 16):
+        got = _cabi.aov_scan(t, x, periods, r)
+        mine = so.aov_scan(t, x, periods, r)
+        for i, period in enumerate(periods):
+            phi = (t / period) % 1
+            # bin membership by the doubles k / r exactly as phase.py:137 compares them
+            edges = np.arange(r + 1) / r
+            k = np.clip(np.searchsorted(edges, phi, side="right") - 1, 0, r - 1)
+            groups = [x[k == j] for j in range(r)]
+            assert all(g.size > 0 for g in groups)
+            f_stat = f_oneway(*groups).statistic
+            assert abs(got[i] / f_stat - 1) < 1e-9 and abs(mine[i] / f_stat - 1) < 1e-9
+
+
 def test_aov_agrees_with_the_reference_pinned_pdm_kernel():
     """Non-overlapping bins: Theta_AoV = ((N - 1) / theta_PDM - (N - r)) / (r - 1) - the AoV scan against the
     PDM scan whose parity is pinned by the reference's own goldens (G7)."""

@@ -381,11 +381,22 @@ def test_full_size_c2_properties():
     assert np.all(np.isfinite(power)) and power.min() >= -1e-12 and power.max() <= 1 + 1e-9
     peak = int(np.argmax(power))
     assert abs(1 / freq[peak] - 37.3) < 0.01
+    # >= 4096 bins against the long-double oracle, stratified over the kernel's tiles (2048 frequencies at
+    # this shape; other tile shapes divide it): the first and last frequency of EVERY tile - where a thread's
+    # recurrence starts and where it has run longest -, the last (partial) tile, and 7 random bins inside
+    # each tile
     rng = np.random.default_rng(0)
-    pick = np.unique(np.concatenate([rng.integers(0, nf, 96), [0, nf - 1, peak, peak + 1]]))
+    tile = 2048
+    starts = np.arange(0, nf, tile)
+    ends = np.minimum(starts + tile, nf) - 1
+    inside = (starts[:, None] + rng.integers(0, tile, (starts.size, 7))).ravel()
+    pick = np.unique(np.concatenate([starts, ends, inside[inside < nf], [0, nf - 1, peak, peak + 1],
+                                     np.arange(starts[-1], nf, 37)]))
+    assert pick.size >= 4096
     exact = co.gls_power_exact(t, y, dy, freq[pick])
     rel = np.abs(power[pick] - exact) / np.abs(exact)
     assert rel.max() <= RTOL, rel.max()
+    assert peak == pick[np.argmax(exact)]                 # the oracle's maximum over the sampled bins is the peak
     # normalised power is invariant under y -> a*y + b
     again = _cabi.gls_scan(t, 3.0 * y - 7.0, 3.0 * dy, f0, delta, nf)
     np.testing.assert_allclose(again, power, rtol=1e-7, atol=1e-14)
@@ -422,6 +433,17 @@ def test_full_size_c3_batch_peaks_only():
         # (a lone curve picks another tile shape than the 4096-curve batch: equal to rounding)
         assert argmax[b] == np.argmax(single) and abs(amax[b] / single.max() - 1) < 1e-12
         assert abs(val[b] / single[idx[b]] - 1) < 1e-12
+    # the full-size batch against the ORACLE: the spectra of 8 random curves (first and last included) at all
+    # 5e4 bins vs the long-double direct sums (1e8 pairs per curve), Tier E, and their argmax / amax
+    power, amax2, argmax2 = _cabi.gls_scan_batch(t.ravel(), y.ravel(), dy.ravel(), offsets, f0, delta, nf,
+                                                 want_power=True, want_peaks=True)
+    assert np.array_equal(argmax2, argmax) and np.array_equal(amax2, amax)    # peaks-only == with the spectra written
+    for b in np.unique(np.concatenate([[0, B - 1], rng.integers(0, B, 6)])):
+        exact = np.asarray(co.gls_power_exact(t[b], y[b], dy[b], freq))
+        assert_tier_e(power[b], exact)
+        assert argmax[b] == int(np.argmax(exact)) and abs(amax[b] / exact.max() - 1) < 1e-9
+        assert argmax[b] == int(np.nanargmax(so.gls_power(t[b], y[b], dy[b], freq, delta, f0, sums="fft")))   # Tier R
+    del power
     # the same batch reduced to its 4 highest / most prominent find_peaks() maxima with prominences and
     # half-maximum crossings (core.py:283-317, 944-978): 1.64 GB of spectra stay in HBM
     from scipy.signal import find_peaks
@@ -463,10 +485,16 @@ def test_full_size_c4_on_one_gpu_both_paths():
     assert peak == int(np.argmax(fft))                                   # tier R at the largest config
     assert abs(1 / (f0 + peak * delta) - 37.3) < 0.01
     assert np.median(np.abs(fft - power)) < 1e-6 and np.max(np.abs(fft - power)) < 1e-3
+    # >= 64 bins against the long-double oracle (1e6 pairs each): both edges of every slab (where the 8-GPU
+    # run starts / ends a device's recurrences), the peak, and random bins in every slab
     rng = np.random.default_rng(5)
-    pick = np.unique(np.concatenate([rng.integers(0, nf, 6), [peak]]))
+    edges = np.concatenate([[r * slab, (r + 1) * slab - 1] for r in range(world)])
+    inner = (np.arange(world)[:, None] * slab + rng.integers(1, slab - 1, (world, 6))).ravel()
+    pick = np.unique(np.concatenate([edges, inner, [peak]]))
+    assert pick.size >= 64
     exact = co.gls_power_exact(t, y, dy, f0 + delta * pick)
     assert np.max(np.abs(power[pick] - exact) / np.abs(exact)) <= RTOL
+    assert peak == pick[np.argmax(exact)]
 
 
 _SHAPE_CHECK = """

@@ -155,6 +155,24 @@ def test_aov_restatement_is_tied_to_the_reference_pdm():
         np.testing.assert_allclose(so.aov_scan(t, x, periods, r), ((n - 1) / theta - (n - r)) / (r - 1), rtol=1e-10)
 
 
+def test_aov_restatement_is_scipy_one_way_anova():
+    """An independent third-party pin of the AoV restatement: Theta_AoV is the one-way ANOVA F statistic of
+    the samples grouped by phase bin; scipy.stats.f_oneway over groups built with numpy alone."""
+    from scipy.stats import f_oneway
+    rng = np.random.default_rng(321)
+    n = 4000
+    t = np.sort(rng.uniform(0, float(n), n)) - 77.25
+    x = 1.0 + 0.5 * np.sin(2 * np.pi * t / 13.7) + rng.uniform(0.05, 0.2, n) * rng.standard_normal(n)
+    periods = np.concatenate([np.linspace(1.5, 50.0, 40), [13.7, 27.4, 6.85]])
+    for r in (4, 10, 16):
+        mine = so.aov_scan(t, x, periods, r)
+        for i, period in enumerate(periods):
+            phi = (t / period) % 1
+            k = np.clip(np.searchsorted(np.arange(r + 1) / r, phi, side="right") - 1, 0, r - 1)
+            f_stat = f_oneway(*[x[k == j] for j in range(r)]).statistic
+            assert abs(mine[i] / f_stat - 1) < 1e-10
+
+
 def test_conditional_entropy_restatement_equals_joint_minus_marginal_entropy():
     """H_c = H(m, phi) - H(phi), computed here with numpy's own 2-d histogram and scipy's entropy."""
     from scipy.stats import entropy

@@ -20,6 +20,9 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass l2    TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
 rocprofv3 --kernel-trace --stats -d "$out/stats" -o run --output-format csv -- python3 bench.py $args > "$out/stats.log" 2>&1
-# the headline workload alone, so that the average duration of gls_scan_kernel is the C2 launch's
-rocprofv3 --kernel-trace --stats -d "$out/stats_c2" -o run --output-format csv -- python3 bench.py $args --no-extras > "$out/stats_c2.log" 2>&1
+# the headline workload alone, 20 timed steps + 3 warm-up, so that the statistics of gls_scan_kernel are
+# the C2 launch's; the bench line of THIS run (same lease, same process) is kept beside the trace
+rocprofv3 --kernel-trace --stats -d "$out/stats_c2" -o run --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > "$out/stats_c2.log" 2>&1
+tail -1 "$out/stats_c2.log" > "$out/bench_under_kernel_trace.json"
+python3 tools/kernel_median.py "$out/stats_c2/run_kernel_trace.csv" "$out/bench_c2_kernel_median.json"
 python3 tools/pmc_summary.py "$out" --out "$out/pmc_summary.json" --command "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py $args"
