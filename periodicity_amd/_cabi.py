@@ -118,7 +118,12 @@ def lib():
                         "__graft_entry__ as g; g.build()'`). There is no CPU fallback.")
                 handle = C.CDLL(path)
                 for name, (res, args) in PROTOTYPES.items():
-                    fn = getattr(handle, name)
+                    try:
+                        fn = getattr(handle, name)
+                    except AttributeError:
+                        if os.environ.get("PDC_LIBRARY"):   # an older build under A/B comparison may lack newer entries
+                            continue
+                        raise
                     fn.restype, fn.argtypes = res, args
                 _lib = handle
     return _lib

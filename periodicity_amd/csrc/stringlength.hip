@@ -114,11 +114,12 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Exclusive prefix sum of a[0..NB) in place (NB / 1024 entries per thread).
-template <int NB>
-__device__ __forceinline__ void scan_buckets(unsigned *a, unsigned *wave_tot) {
+// Exclusive prefix sum of a[0..NB) in place (NB / BLOCK entries per thread); returns the total.
+template <int NB, int BLOCK = kBlock>
+__device__ __forceinline__ unsigned scan_buckets(unsigned *a, unsigned *wave_tot) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int per = NB / kBlock;
+    constexpr int per = NB / BLOCK;
+    static_assert(per * BLOCK == NB, "bucket count must be a multiple of the block size");
     unsigned local[per], sum = 0;
 #pragma unroll
     for (int e = 0; e < per; ++e) {
@@ -134,16 +135,19 @@ __device__ __forceinline__ void scan_buckets(unsigned *a, unsigned *wave_tot) {
     __syncthreads();
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
-    unsigned run = incl - sum;
+    unsigned run = incl - sum, all = 0u;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w)
+    for (int w = 0; w < BLOCK / 64; ++w) {
         if (w < wave) run += wave_tot[w];
+        all += wave_tot[w];
+    }
 #pragma unroll
     for (int e = 0; e < per; ++e) {
         a[tid * per + e] = run;
         run += local[e];
     }
     __syncthreads();
+    return all;
 }
 
 // Ascending bitonic sort of P (power of two) (key, index) pairs by (key, index), whole workgroup.
@@ -151,7 +155,7 @@ template <typename IdxT, typename KeyPtr, typename IdxPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr K, IdxPtr I, int P) {
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int c = threadIdx.x; c < (P >> 1); c += kBlock) {
+            for (int c = threadIdx.x; c < (P >> 1); c += (int)blockDim.x) {
                 const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
                 const int l = i | j;
                 const unsigned long long ka = K[i], kb = K[l];
@@ -175,7 +179,7 @@ template <typename KeyPtr, typename IdxPtr>
 __device__ __forceinline__ double segment_sum(KeyPtr K, IdxPtr I, int cnt, const double *m) {
     const int lane = threadIdx.x & 63;
     double total = 0.0;
-    for (int j0 = 0; j0 < cnt; j0 += kBlock) {
+    for (int j0 = 0; j0 < cnt; j0 += (int)blockDim.x) {
         const int j = j0 + threadIdx.x;
         const bool live = j < cnt;
         double phi = 0.0, mm = 0.0;
@@ -753,6 +757,8 @@ struct FastArgs {
     int64_t n_pad, nr_pad;
     unsigned *ghist;            // [grid][kNBLarge]  first sorted position of every coarse bucket (several slices)
     unsigned short *gbucket;    // [grid][2 n_pad]   coarse bucket of every sample, written by P1 (several slices)
+    int slice_cap;              // samples per LDS slice (several slices)
+    const unsigned char *todo;  // NULL, or [n_periods]: only periods with a non-zero entry are worked off
 };
 
 // RN(t / period) without the division: y = RN(1 / period); q0 = RN(t y) is within 1.5 ulp of the
@@ -923,6 +929,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
     static_assert(!MULTI || NB <= 65536, "bucket ids are kept as 16-bit numbers");
 
     for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
+        if (a.todo && !a.todo[p]) continue;   // (workgroup-uniform)
         const double period = a.periods[p];
         const double y = 1.0 / period;
         const bool safe = period_is_safe(period, t_safe);
@@ -1065,7 +1072,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 b0 = l;
             }
             const int first_cnt = end_of(b0) - consumed;
-            if (first_cnt > FL<IdxT>::capacity) {
+            if (first_cnt > a.slice_cap) {
                 // a single coarse bucket larger than a slice (clustered phases): sorted in global scratch
                 const int cnt = first_cnt;
                 int P = 2;
@@ -1106,7 +1113,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 int l = b0 + 1, h = NB;
                 while (l < h) {
                     const int mid = (l + h + 1) >> 1;
-                    if (end_of(mid - 1) - consumed <= FL<IdxT>::capacity) l = mid; else h = mid - 1;
+                    if (end_of(mid - 1) - consumed <= a.slice_cap) l = mid; else h = mid - 1;
                 }
                 b1 = l;
             }
@@ -1495,6 +1502,446 @@ __global__ __launch_bounds__(kBlock) void sl_prep_kernel(const double *t, const 
 
 }  // namespace fast
 
+
+// =====================================================================================================
+// Two workgroups per CU ("duo"), for N <= 26 048 samples: while a workgroup folds its samples and builds the
+// permutation (P1 + P2 + range table) the gather pipe of its CU idles, and the ranges (P3a) leave a third of
+// the VALU slots empty.  Here a workgroup is 512 threads and takes HALF of LDS, so two are resident per CU,
+// each on its own period (handed out by a global ticket counter): one's P1/P2 runs under the other's ranges,
+// and a short period no longer pays for 16 waves' worth of barriers.  Same algorithm, same arithmetic and
+// summation order per range as sl_fast_kernel.  Measured against it on one box (tools/sl_shapes.py):
+// N = 25 000 x 1e5 periods 15.07 -> 13.24 ms, 10 000 x 2e4 1.81 -> 1.25, 2000 x 1e5 3.99 -> 2.32, 500 x 1e5
+// 3.20 -> 1.80 ms.  Above one half-LDS permutation (C5's N = 5e4) the one-workgroup kernel stays: a period cut
+// into two phase halves, one per workgroup, was built and measured (31.2 against 27.3 ms) - each half has to
+// fold ALL samples to find its own, and the range phase is latency-bound per wave (16 waves per CU either
+// way), so the doubled P1 is not hidden.
+// A deferred range beyond the LDS sort (heavily clustered phases) marks the period in todo[], and the
+// one-workgroup kernel works off the marked periods afterwards.
+namespace duo {
+using namespace fast;
+
+constexpr int kB = 512;
+constexpr int kW = kB / 64;
+constexpr int kLdsWg = kLdsTotal / 2;   // two workgroups per CU
+constexpr int kWaveB = Lds<unsigned short>::wave_bytes;
+constexpr int kRangesD = 136;           // >= kCapD / kFWin + 2
+constexpr int kStaticD = 256;           // static __shared__ below, rounded up
+constexpr int kFixedD = kW * kWaveB + 2 * (kRangesD + 8) * 2 + 64;
+constexpr int kCapD = ((((kLdsWg - kFixedD - kStaticD) / 2) & ~7) - 64);   // samples per period (+ 64 dummy slots)
+static_assert(kCapD / kFWin + 2 <= kRangesD, "range table too small");
+static_assert(kW * kWaveB >= (kNB + 64) * 4 && kW * kWaveB >= kDCap * 10, "aliases must fit");
+static_assert(kRangesD <= 15 * 32, "deferred-range bits live in defer[0..14]");
+
+struct DuoArgs {
+    const double *t, *m, *periods;
+    const rec_t *rec;
+    const unsigned *flags;      // [0] != 0: every t is 0 or 1e-150 <= |t| <= 1e150
+    int n;
+    int64_t n_periods;
+    unsigned *ticket;           // next period (zeroed before the launch)
+    double *ell;
+    unsigned char *todo;        // [n_periods]: 1 = left to the one-workgroup kernel
+    double *rsum;               // [grid][nr_pad][4]
+    int *rcnt;                  // [grid][nr_pad]
+    double *rlen;               // [grid][nr_pad]
+    int64_t nr_pad;
+};
+
+template <int KMAX>
+__global__ __launch_bounds__(kB, 4) void sl_duo_kernel(DuoArgs a) {
+    constexpr int NBL = kNB;
+    typedef unsigned short IdxT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned char *wbuf = lds_raw;                                                  // P3a: per-wave scratch
+    unsigned *hist = reinterpret_cast<unsigned *>(lds_raw);                         // P1/P2 alias [NBL + 64]
+    unsigned long long *bkeys = reinterpret_cast<unsigned long long *>(lds_raw);    // P3b alias [kDCap]
+    IdxT *bidx = reinterpret_cast<IdxT *>(bkeys + kDCap);                           // P3b alias [kDCap]
+    unsigned short *bndb = reinterpret_cast<unsigned short *>(lds_raw + kW * kWaveB);
+    unsigned short *bnds = bndb + kRangesD + 8;
+    unsigned *defer = reinterpret_cast<unsigned *>(bnds + kRangesD + 8);            // [16]
+    IdxT *order = reinterpret_cast<IdxT *>(defer + 16);                             // [cap + 64]
+    __shared__ unsigned wave_tot[kW];
+    __shared__ double red[kW];
+    __shared__ unsigned s_item, s_bad;
+    const int tid0 = threadIdx.x, lane = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int n = a.n;
+    double *rsum = a.rsum + (int64_t)blockIdx.x * a.nr_pad * 4;
+    int *rcnt = a.rcnt + (int64_t)blockIdx.x * a.nr_pad;
+    double *rlen = a.rlen + (int64_t)blockIdx.x * a.nr_pad;
+    const bool t_safe = a.flags[0] != 0u;
+    const unsigned n_items = (unsigned)a.n_periods;
+
+    unsigned long long *keys_w = reinterpret_cast<unsigned long long *>(wbuf + wave * kWaveB);
+    unsigned *fine_w = reinterpret_cast<unsigned *>(wbuf + wave * kWaveB + kRCap * 8);
+    IdxT *idx_w = reinterpret_cast<IdxT *>(wbuf + wave * kWaveB + kRCap * 8 + (kWFine + 4) * 4);
+
+    for (;;) {
+        __syncthreads();   // the previous item is done with LDS
+        if (tid0 == 0) {
+            s_item = atomicAdd(a.ticket, 1u);
+            s_bad = 0u;
+        }
+        __syncthreads();
+        const unsigned item = s_item;
+        if (item >= n_items) break;
+        const int64_t p = (int64_t)item;
+        const double period = a.periods[p];
+        const double y = 1.0 / period;
+        const bool safe = period_is_safe(period, t_safe);
+        double total = 0.0;
+
+        // ---- P1: exact phases, coarse histogram; bucket ids in registers ------------------------------
+        // (as in sl_fast_kernel: opaque copy of the thread id, dummy buckets for samples past the end)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        for (int b = tid; b < NBL + 64; b += kB) hist[b] = 0u;
+        if (tid < 16) defer[tid] = tid == 15 ? (unsigned)kW : 0u;   // [15]: next range to hand out (P3a)
+        __syncthreads();
+        unsigned pk[(KMAX + 1) / 2];
+#pragma unroll
+        for (int k = 0; k < (KMAX + 1) / 2; ++k) pk[k] = 0u;
+        double tv[4], tn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = u * kB + tid;
+            tn[u] = a.t[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < KMAX; k0 += 4) {
+            if (k0 * kB < n) {   // workgroup-uniform
+#pragma unroll
+                for (int u = 0; u < 4; ++u) tv[u] = tn[u];
+                if (k0 + 4 < KMAX && (k0 + 4) * kB < n) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = (k0 + 4 + u) * kB + tid;
+                        tn[u] = a.t[i < n ? i : n - 1];
+                    }
+                }
+                double phi[4];
+                phases4(tv, period, y, safe, phi);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + u < KMAX) {
+                        const int i = (k0 + u) * kB + tid;
+                        const int b = i < n ? coarse_of<kNB>(phi[u]) : NBL + lane;
+                        atomicAdd(&hist[b], 1u);
+                        pk[(k0 + u) >> 1] |= (unsigned)b << (((k0 + u) & 1) * 16);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        scan_buckets<NBL, kB>(hist, wave_tot);   // hist[b] = first sorted position of bucket b
+        const int slice_n = n;
+
+        // ---- P2: the permutation, grouped by coarse bucket ----------------------------------------
+#pragma unroll
+        for (int k0 = 0; k0 < KMAX; k0 += 4) {
+            if (k0 * kB < n) {   // workgroup-uniform
+                unsigned pos[4], bb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + u < KMAX) {
+                        bb[u] = (pk[(k0 + u) >> 1] >> (((k0 + u) & 1) * 16)) & 0xFFFFu;
+                        pos[u] = atomicAdd(&hist[bb[u]], 1u);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (k0 + u < KMAX) {
+                        const int i = (k0 + u) * kB + tid;
+                        order[i < n ? pos[u] : (unsigned)(n + lane)] = (IdxT)i;
+                    }
+                }
+            }
+        }
+        const int nranges = (slice_n + kFWin - 1) / kFWin;
+        __syncthreads();   // hist[b] = END position of bucket b
+        // range r starts at the first bucket whose start position is >= r * kFWin
+        for (int r = tid; r <= nranges; r += kB) {
+            int b = 0, s0 = 0;
+            if (r > 0) {
+                const unsigned x = (unsigned)r * kFWin;
+                int l = 0, h = NBL;   // smallest j in [0, NBL) with end(j) >= x, NBL if none
+                while (l < h) {
+                    const int mid = (l + h) >> 1;
+                    if (hist[mid] >= x) h = mid; else l = mid + 1;
+                }
+                b = l < NBL ? l + 1 : NBL;
+                s0 = l < NBL ? (int)hist[l] : slice_n;
+            }
+            bndb[r] = (unsigned short)b;
+            bnds[r] = (unsigned short)s0;
+        }
+        __syncthreads();   // (the histogram is dead from here on: its LDS becomes wave scratch)
+
+        // ---- P3a: wave-autonomous ranges (sl_fast_kernel's, with this workgroup's 8 waves) ---------------
+        int n_cnt = 0, n_slo = 0, n_lob = 0, n_hib = 0;
+        unsigned n_idx[kRPer];
+        rec_t n_rec[kRPer];
+        auto request = [&](int r) {
+            n_lob = __builtin_amdgcn_readfirstlane((int)bndb[r]);
+            n_hib = __builtin_amdgcn_readfirstlane((int)bndb[r + 1]);
+            n_slo = __builtin_amdgcn_readfirstlane((int)bnds[r]);
+            n_cnt = __builtin_amdgcn_readfirstlane((int)bnds[r + 1]) - n_slo;
+            if (n_cnt > 0 && n_cnt <= kFCap) {
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) {
+                    const int sI = lane + e * 64;
+                    n_idx[e] = (unsigned)order[n_slo + (sI < n_cnt ? sI : 0)];
+                }
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) n_rec[e] = a.rec[n_idx[e]];
+            }
+        };
+        unsigned *fine32 = fine_w;
+        unsigned char *fine8 = reinterpret_cast<unsigned char *>(fine_w);
+        int r_next = nranges;
+        auto process = [&](const int r, auto rows3_tag) {
+            constexpr bool ROWS3 = decltype(rows3_tag)::value;
+            const int cnt = n_cnt, lo_b = n_lob, hi_b = n_hib;
+            unsigned ticket = 0u;
+            if (lane == 0) ticket = atomicAdd(&defer[15], 1u);
+            if (cnt <= 0 || cnt > kFCap) {
+                if (lane == 0) {
+                    if (cnt <= 0) rcnt[r] = 0;
+                    else atomicOr(&defer[r >> 5], 1u << (r & 31));
+                }
+                r_next = __builtin_amdgcn_readfirstlane((int)ticket);
+                if (r_next < nranges) request(r_next);
+                return;
+            }
+            const double fsc = (double)((float)(kFine - 1) * __builtin_amdgcn_rcpf((float)(hi_b - lo_b)));
+            const double fmul = (double)kNB * fsc, fadd = -(double)lo_b * fsc;
+            reinterpret_cast<uint4 *>(fine32)[lane] = make_uint4(0u, 0u, 0u, 0u);
+            if (lane < 4) fine32[kFine / 4 + lane] = 0u;
+            wave_sync();
+            double et[kRPer], em[kRPer], ephi[kRPer];
+            unsigned ei[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                et[e] = n_rec[e].x;
+                em[e] = n_rec[e].y;
+                ei[e] = n_idx[e];
+            }
+            phases4(et, period, y, safe, ephi);
+            unsigned er[kRPer];
+            int ef[kRPer];
+            bool live[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                live[e] = (ROWS3 && e < 3) ? true : lane + e * 64 < cnt;
+                const double phi = ephi[e];
+                int fb = (int)__builtin_fma(phi, fmul, fadd);
+                fb = fb < 0 ? 0 : (fb > kFine - 1 ? kFine - 1 : fb);
+                fb = phi == phi ? fb : kFine - 1;
+                ephi[e] = __longlong_as_double((long long)phase_key(phi));
+                ef[e] = fb;
+                const unsigned esh = ((unsigned)fb & 3u) * 8u;
+                const unsigned old = atomicAdd(&fine32[live[e] ? fb >> 2 : lane], live[e] ? 1u << esh : 0u);
+                er[e] = (old >> esh) & 0xFFu;
+            }
+#define EK(e) ((unsigned long long)__double_as_longlong(ephi[e]))
+            r_next = __builtin_amdgcn_readfirstlane((int)ticket);
+            if (r_next < nranges) request(r_next);
+            unsigned mx = 0;
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                const unsigned v = live[e] ? er[e] : 0u;
+                mx = v > mx ? v : mx;
+            }
+            const int mxu = (int)wave_max_u32(mx) + 1;
+            if (mxu > kWInsertMax) {
+                if (lane == 0) atomicOr(&defer[r >> 5], 1u << (r & 31));
+                return;
+            }
+            wave_sync();
+            {
+                const uint4 cv = reinterpret_cast<uint4 *>(fine32)[lane];
+                unsigned w[4] = {cv.x, cv.y, cv.z, cv.w}, x[4], tot[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x[q] = w[q] + (w[q] << 8);
+                    x[q] += x[q] << 16;
+                    tot[q] = x[q] >> 24;
+                }
+                const unsigned lane_tot = (tot[0] + tot[1]) + (tot[2] + tot[3]);
+                const unsigned incl = wave_scan_add(lane_tot);
+                unsigned base = incl - lane_tot;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x[q] = (x[q] - w[q]) + __builtin_amdgcn_perm(base, base, 0u);
+                    base += tot[q];
+                }
+                reinterpret_cast<uint4 *>(fine32)[lane] = make_uint4(x[0], x[1], x[2], x[3]);
+                if (lane == 63) fine32[kFine / 4] = incl;
+            }
+            wave_sync();
+            unsigned eb0[kRPer], ec[kRPer], park[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                eb0[e] = fine8[ef[e]];
+                ec[e] = fine8[ef[e] + 1];
+            }
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                ec[e] = live[e] ? ec[e] - eb0[e] : 0u;
+                park[e] = live[e] ? eb0[e] + er[e] : (unsigned)(lane + e * 64);
+                keys_w[park[e]] = EK(e);
+                idx_w[park[e]] = (IdxT)ei[e];
+            }
+            wave_sync();
+            unsigned before[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) before[e] = 0u;
+            for (int j = 1; j < mxu; ++j) {
+                unsigned long long ky[kRPer];
+                unsigned oth[kRPer];
+                bool tie = false;
+#pragma unroll
+                for (int e = 0; e < kRPer; ++e) {
+                    const bool in = (unsigned)j < ec[e];
+                    unsigned o = er[e] + (unsigned)j;
+                    o = o >= ec[e] ? o - ec[e] : o;
+                    oth[e] = in ? eb0[e] + o : park[e];
+                    ky[e] = keys_w[oth[e]];
+                    before[e] += (in && ky[e] < EK(e)) ? 1u : 0u;
+                    tie = tie || (in && ky[e] == EK(e));
+                }
+                if (__any(tie)) {
+#pragma unroll
+                    for (int e = 0; e < kRPer; ++e) {
+                        const bool in = (unsigned)j < ec[e];
+                        if (in && ky[e] == EK(e) && (unsigned)idx_w[oth[e]] < ei[e]) ++before[e];
+                    }
+                }
+            }
+            wave_sync();
+#undef EK
+            unsigned fs[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                fs[e] = live[e] ? eb0[e] + before[e] : (unsigned)(lane + e * 64);
+                keys_w[fs[e]] = (unsigned long long)__double_as_longlong(ephi[e]);
+            }
+            wave_sync();
+            double sphi[kRPer], sm[kRPer];
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) sphi[e] = __longlong_as_double((long long)keys_w[lane + e * 64]);
+            wave_sync();
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) keys_w[fs[e]] = (unsigned long long)__double_as_longlong(em[e]);
+            wave_sync();
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) sm[e] = __longlong_as_double((long long)keys_w[lane + e * 64]);
+            double carry_phi = 0.0, carry_m = 0.0, last_phi = 0.0, last_m = 0.0, inside = 0.0;
+#pragma unroll
+            for (int e = 0; e < kRPer; ++e) {
+                const int j = lane + e * 64;
+                const double phi = sphi[e], mm = sm[e];
+                const double pphi = lane_below(phi, carry_phi), pm = lane_below(mm, carry_m);
+                const double seg = short_hypot(mm - pm, phi - pphi);
+                inside += (live[e] && j > 0) ? seg : 0.0;
+                carry_phi = read_lane(phi, 63);
+                carry_m = read_lane(mm, 63);
+                if (e == ((cnt - 1) >> 6)) {
+                    last_phi = read_lane(phi, (cnt - 1) & 63);
+                    last_m = read_lane(mm, (cnt - 1) & 63);
+                }
+            }
+            inside = wave_sum_fixed(inside);
+            if (lane == 0) {
+                rsum[(int64_t)r * 4 + 0] = sphi[0];
+                rsum[(int64_t)r * 4 + 1] = sm[0];
+                rsum[(int64_t)r * 4 + 2] = last_phi;
+                rsum[(int64_t)r * 4 + 3] = last_m;
+                rcnt[r] = cnt;
+                rlen[r] = inside;
+            }
+            wave_sync();
+        };
+        if (wave < nranges) request(wave);
+        for (int r = wave; r < nranges; r = r_next) {
+            if (n_cnt > 192) process(r, std::true_type{});
+            else process(r, std::false_type{});
+        }
+        __syncthreads();
+
+        // ---- P3b: deferred ranges, whole workgroup (LDS sort; larger ones mark the period) ----------
+        for (int w32 = 0; w32 < (nranges + 31) / 32; ++w32) {
+            unsigned bits = defer[w32];
+            while (bits) {
+                const int r = w32 * 32 + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const int s_lo = bnds[r], cnt = (int)bnds[r + 1] - s_lo;
+                if (cnt > kDCap) {      // (workgroup-uniform)
+                    if (tid == 0) s_bad = 1u;
+                    continue;
+                }
+                int P = 2;
+                while (P < cnt) P <<= 1;
+                for (int sI = tid; sI < P; sI += kB) {
+                    if (sI < cnt) {
+                        const IdxT id = order[s_lo + sI];
+                        bkeys[sI] = phase_key(fast_phase(a.t[id], period, y, safe));
+                        bidx[sI] = id;
+                    } else {
+                        bkeys[sI] = ~0ull;
+                        bidx[sI] = (IdxT)~0u;
+                    }
+                }
+                __syncthreads();
+                bitonic_sort<IdxT>(bkeys, bidx, P);
+                total += segment_sum(bkeys, bidx, cnt, a.m);
+                if (tid == 0) {
+                    rsum[(int64_t)r * 4 + 0] = __longlong_as_double((long long)bkeys[0]);
+                    rsum[(int64_t)r * 4 + 1] = a.m[bidx[0]];
+                    rsum[(int64_t)r * 4 + 2] = __longlong_as_double((long long)bkeys[cnt - 1]);
+                    rsum[(int64_t)r * 4 + 3] = a.m[bidx[cnt - 1]];
+                    rcnt[r] = cnt;
+                    rlen[r] = 0.0;   // (its segments were added to `total` by the whole workgroup, in a fixed order)
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();  // every summary of this item (global, this workgroup's) is visible
+
+        // ---- P3c: links between consecutive non-empty ranges + the closing segment -----------------------
+        for (int r = tid; r < nranges; r += kB) {
+            if (rcnt[r] > 0) {
+                total += rlen[r];
+                int q = r - 1;
+                while (q >= 0 && rcnt[q] == 0) --q;
+                if (q >= 0)
+                    total += hypot(rsum[(int64_t)r * 4 + 1] - rsum[(int64_t)q * 4 + 3],
+                                   rsum[(int64_t)r * 4 + 0] - rsum[(int64_t)q * 4 + 2]);
+            }
+        }
+        if (tid == 0 && nranges > 0) {
+            int f0 = 0, l0 = nranges - 1;
+            while (f0 < nranges && rcnt[f0] == 0) ++f0;
+            while (l0 >= 0 && rcnt[l0] == 0) --l0;
+            // closing segment of np.roll(-1): first minus last, no phase wrap (phase.py:50)
+            if (f0 < nranges && l0 >= 0)
+                total += hypot(rsum[(int64_t)f0 * 4 + 1] - rsum[(int64_t)l0 * 4 + 3],
+                               rsum[(int64_t)f0 * 4 + 0] - rsum[(int64_t)l0 * 4 + 2]);
+        }
+        total = wave_sum(total);
+        if (lane == 0) red[wave] = total;
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0;
+            for (int w = 0; w < kW; ++w) sum += red[w];
+            a.todo[p] = s_bad ? 1 : 0;
+            if (!s_bad) a.ell[p] = sum;
+        }
+    }
+}
+
+}  // namespace duo
+
 int64_t pad_pow2(int64_t n) {
     int64_t p = 2;
     while (p < n) p <<= 1;
@@ -1516,9 +1963,32 @@ int64_t scratch_bytes(int64_t n, int64_t n_periods, int64_t partition) {
 // AoS (t, m) records + flags of the fast path, placed behind the general scratch
 int64_t fast_table_bytes(int64_t n) { return ((n * 16 + 255) & ~(int64_t)255) + 256; }
 
+// workspace of the two-workgroups-per-CU kernel, behind the (t, m) table: the marks for the one-workgroup
+// kernel and the ticket counter
+int64_t duo_bytes(int64_t n_periods) { return ((n_periods + 255) & ~(int64_t)255) + 256; }
+
+template <int KMAX>
+int launch_duo(const duo::DuoArgs &a, int64_t grid, hipStream_t st) {
+    const size_t lds = (size_t)duo::kFixedD + (size_t)((a.n + 64 + 7) & ~7) * 2;
+    PDC_TRY(allow_dynamic_lds((const void *)duo::sl_duo_kernel<KMAX>, duo::kLdsWg - duo::kStaticD));
+    hipLaunchKernelGGL((duo::sl_duo_kernel<KMAX>), dim3((unsigned)grid), dim3(duo::kB), lds, st, a);
+    return PDC_OK;
+}
+
+int cu_count(int device) {
+    static int cached[64] = {};
+    if (device < 0 || device >= 64) return 256;
+    if (cached[device] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 256;
+        cached[device] = v;
+    }
+    return cached[device];
+}
+
 template <int KMAX, typename IdxT = unsigned short, int NB = fast::kNB, bool MULTI = false>
 int launch_fast(const fast::FastArgs &a, int64_t grid, hipStream_t st) {
-    const int64_t slice = MULTI ? fast::FL<IdxT>::capacity : a.n;
+    const int64_t slice = MULTI ? a.slice_cap : a.n;
     const size_t lds = (size_t)fast::FL<IdxT>::fixed + (size_t)((slice + 64 + 7) & ~(int64_t)7) * sizeof(IdxT);
     PDC_TRY(allow_dynamic_lds((const void *)fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI>, fast::kLdsTotalDyn));
     hipLaunchKernelGGL((fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
@@ -1532,7 +2002,7 @@ extern "C" {
 int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) {
     if (n < 0 || n_periods < 0) return -1;
     const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
-    return scratch_bytes(n, n_periods, partition) + fast_table_bytes(n);
+    return scratch_bytes(n, n_periods, partition) + fast_table_bytes(n) + duo_bytes(n_periods);
 }
 
 int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
@@ -1593,6 +2063,38 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
         hipLaunchKernelGGL(fast::sl_prep_kernel, dim3(1), dim3(kBlock), 0, st, d_t, d_m, (int)n,
                            reinterpret_cast<fast::rec_t *>(table), const_cast<unsigned *>(f.flags));
         const int k = (int)((n + kBlock - 1) / kBlock);
+        f.slice_cap = fast::FL<unsigned>::capacity;
+        f.todo = nullptr;
+        // Two workgroups per CU (sl_duo_kernel) whenever a period's permutation fits half of LDS;
+        // PDC_SL_DUO=0 keeps the one-workgroup kernel (A/B, tests)
+        static const bool duo_on = [] { const char *e = getenv("PDC_SL_DUO"); return !(e && e[0] == '0'); }();
+        if (duo_on && n <= duo::kCapD) {
+            duo::DuoArgs d;
+            d.t = d_t;
+            d.m = d_m;
+            d.periods = d_periods;
+            d.rec = f.rec;
+            d.flags = f.flags;
+            d.n = (int)n;
+            d.n_periods = n_periods;
+            d.ell = d_ell;
+            char *area = table + fast_table_bytes(n);
+            unsigned char *todo = reinterpret_cast<unsigned char *>(area);
+            d.todo = todo;
+            d.ticket = reinterpret_cast<unsigned *>(area + ((n_periods + 255) & ~(int64_t)255));
+            d.rsum = a.rsum;
+            d.rcnt = a.rcnt;
+            d.rlen = rlen;
+            d.nr_pad = a.nr_pad;
+            int64_t dgrid = 2 * (int64_t)cu_count(device);
+            dgrid = dgrid < grid ? dgrid : grid;       // (the range scratch is laid out for `grid` workgroups)
+            PDC_HIP(hipMemsetAsync(d.ticket, 0, 4, st));
+            const int kd = (int)((n + duo::kB - 1) / duo::kB);
+            if (kd <= 16) PDC_TRY(launch_duo<16>(d, dgrid, st));
+            else if (kd <= 36) PDC_TRY(launch_duo<36>(d, dgrid, st));
+            else PDC_TRY(launch_duo<52>(d, dgrid, st));
+            f.todo = todo;   // the periods the duo kernel marked (clustered phases) go through the one-slice kernel
+        }
         if (n > fast::kCapacity) PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true>(f, grid, st)));
         else if (k <= 8) PDC_TRY(launch_fast<8>(f, grid, st));
         else if (k <= 20) PDC_TRY(launch_fast<20>(f, grid, st));

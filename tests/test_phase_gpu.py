@@ -135,6 +135,35 @@ def test_stringlength_clusters_take_the_scratch_path():
     np.testing.assert_allclose(got[:3], so.stringlength_scan(t, m, periods[:3]), rtol=RTOL)
 
 
+def test_stringlength_two_workgroups_per_cu_equal_the_one_workgroup_kernel(tmp_path):
+    """N <= 26 048 runs two 512-thread workgroups per CU (sl_duo_kernel); PDC_SL_DUO=0 keeps the 1024-thread
+    kernel.  Same ranges, same arithmetic per range; only the order in which the range sums are added
+    differs.  Shapes around the switch (26 048 / 26 049), clusters (deferred ranges, the marked-period
+    fallback), tied and NaN time stamps; each kernel bitwise reproducible."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("duo", {"PDC_SL_DUO": "1"}), ("one", {"PDC_SL_DUO": "0"})):
+        path = str(tmp_path / f"{tag}.npz")
+        run = subprocess.run([sys.executable, os.path.join(root, "tools", "sl_ab_check.py"), path],
+                             env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        res[tag] = np.load(path)
+    assert sorted(res["duo"].files) == sorted(res["one"].files)
+    for key in res["duo"].files:
+        a, b = res["duo"][key], res["one"][key]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), key
+        np.testing.assert_allclose(a, b, rtol=1e-12, err_msg=key)
+        if key.endswith("_again"):
+            assert np.array_equal(a, res["duo"][key[:-6]], equal_nan=True), key   # run-to-run bitwise
+    # and against the oracle where it is cheap
+    t = np.arange(20_000.0)
+    m = so.stringlength_scale(np.sin(2 * np.pi * t / 12.5) + 0.05 * np.cos(0.37 * t))
+    pe = np.array([1.0, 2.0, 2.5, 4.0, 12.5, 3.0000000000000004, 7.3, 20000.0, 1e-3, 0.3, 1 / 3, 100.0, 128.0])
+    np.testing.assert_allclose(res["duo"]["clustered"], co.stringlength_scan(t, m, pe), rtol=RTOL)
+
+
 def test_stringlength_large_n_runs_in_phase_slices():
     # more samples than one LDS slice holds (52112 with 16-bit indices): up to 16 slices of ~24k the fast
     # kernel reads every sample's bucket id back per slice and keeps that slice's; beyond, the general kernel groups

@@ -30,6 +30,7 @@ for n, n_per in SHAPES:
     w = DB(wb, 0)
     ms = tm.ms(lambda: _cabi.check(lib.pdc_stringlength_scan_dev(0, sp.value, bt.ptr, bm.ptr, n, bp.ptr, n_per, be.ptr,
                                                                  w.ptr, wb)), reps=3)
-    print(f"N={n:6d} periods={n_per:6d}: {ms:8.3f} ms  {n * n_per / ms / 1e6:7.1f} Gpair/s")
+    ell = be.to_array(np.float64, n_per)
+    print(f"N={n:6d} periods={n_per:6d}: {ms:8.3f} ms  {n * n_per / ms / 1e6:7.1f} Gpair/s   sum(ell)={ell.sum():.12e} min at {int(np.argmin(ell))}")
     for b in (bt, bm, bp, be, w):
         b.free()
