@@ -35,6 +35,7 @@ namespace {
 constexpr int kChunk = 128;
 
 constexpr int kStatParts = 512;  // partial sums of the sample statistics (split mode)
+constexpr int kSlots = 1024;     // resident workgroups of the scan kernel on an MI355X: 256 CUs x 4 (38 KB of LDS each)
 
 struct PdmArgs {
     const double *t, *x, *periods;
@@ -323,9 +324,32 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
             add(k, val, inc);
         };
         int i = part * (kChunk / SPLIT);
-        // the pair of the next trip is read before this trip's histogram atomics go out (the compiler
+        // the samples of the next trip are read before this trip's histogram atomics go out (the compiler
         // cannot move an LDS read above a possibly aliasing LDS atomic by itself); the staging area
-        // is followed by the histograms, so reading one pair past the chunk is harmless
+        // is followed by the histograms, so reading a few entries past the chunk is harmless
+        {   // four samples per trip: four independent read -> bin -> atomic chains in flight per wave (two per
+            // trip measured 3.5-8 % slower on one box); the next four are read before this trip's atomics go out
+            double2 n0 = stage[i], n1 = stage[i + 1], n2 = stage[i + 2], n3 = stage[i + 3];
+            for (; i + 3 < i_end; i += 4) {
+                const double2 t0 = n0, t1 = n1, t2 = n2, t3 = n3;
+                n0 = stage[i + 4];
+                n1 = stage[i + 5];
+                n2 = stage[i + 6];
+                n3 = stage[i + 7];
+                int k0, k1, k2, k3;
+                double v0 = t0.y, v1 = t1.y, v2 = t2.y, v3 = t3.y;
+                unsigned i0 = 1u, i1 = 1u, i2 = 1u, i3 = 1u;
+                const bool f0 = fast_bin(t0.x, k0), f1 = fast_bin(t1.x, k1), f2 = fast_bin(t2.x, k2), f3 = fast_bin(t3.x, k3);
+                if (!f0) exact_bin(t0, k0, v0, i0);
+                add(k0, v0, i0);
+                if (!f1) exact_bin(t1, k1, v1, i1);
+                add(k1, v1, i1);
+                if (!f2) exact_bin(t2, k2, v2, i2);
+                add(k2, v2, i2);
+                if (!f3) exact_bin(t3, k3, v3, i3);
+                add(k3, v3, i3);
+            }
+        }
         double2 na = stage[i], nb2 = stage[i + 1];
         for (; i + 1 < i_end; i += 2) {
             // both fast bins first: two independent dependency chains back to back
@@ -440,13 +464,36 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
     const int last = kind == 2 ? (nb + 1) * nc - 1 : m0;
     const int nbins = last + 1;
     const int64_t groups0 = (n_periods + 63) / 64;
-    // (four workgroups of four waves fit a CU: below ~3000 waves the period grid alone leaves SIMD slots empty)
-    if (kind == 2 || env_split == 0 || n_periods == 0 || groups0 * 4 >= 3072 || n < 32 * kChunk ||
-        lds_bytes(last, 256) > 150 * 1024 || (size_t)nbins * 64 * 16 > 150 * 1024)
+    if (kind == 2 || env_split == 0 || n_periods == 0 || n < 32 * kChunk || lds_bytes(last, 256) > 150 * 1024 ||
+        (size_t)nbins * 64 * 16 > 150 * 1024)
         return sh;
-    int64_t n_z = (4096 + groups0 * 4 - 1) / (groups0 * 4);
     const int64_t max_z = n / (8 * kChunk);
+    int64_t n_z;
+    if (groups0 * 4 < 3072) {
+        // (four workgroups of four waves fit a CU: below ~3000 waves the period grid alone leaves SIMD slots empty)
+        n_z = (4096 + groups0 * 4 - 1) / (groups0 * 4);
+    } else {
+        // Enough waves - but workgroups come in rounds of kSlots (4 per CU, LDS-limited), and a last round
+        // that is half empty costs as much as a full one: C5's 1563 workgroups take two rounds for 1.53
+        // rounds' worth of work.  Cutting the samples in n_z slices multiplies the workgroups (each a slice
+        // shorter); take the smallest n_z <= 8 that fills >= 90 % of its rounds, if that beats the unsplit
+        // grid by more than the split's own overhead (two statistics launches, partial histograms through
+        // L2, the finishing launch).  PDC_PDM_NZ forces a value (experiments).
+        static const int env_nz = [] { const char *e = getenv("PDC_PDM_NZ"); return e ? atoi(e) : 0; }();
+        auto rounds_filled = [&](int64_t w) { return (double)w / (double)((w + kSlots - 1) / kSlots * kSlots); };
+        // the unsplit launch packs 64, 128 or 256 periods into a workgroup (phase_stat_dev below)
+        const int64_t w_unsplit = groups0 >= 4096 ? (groups0 + 3) / 4 : (groups0 >= 2048 ? (groups0 + 1) / 2 : groups0);
+        n_z = 1;
+        double best = rounds_filled(w_unsplit);
+        for (int64_t z = 2; z <= 8 && best < 0.9; ++z)
+            if (rounds_filled(groups0 * z) > best + 0.05) {
+                best = rounds_filled(groups0 * z);
+                n_z = z;
+            }
+        if (env_nz > 0) n_z = env_nz;
+    }
     n_z = n_z < max_z ? n_z : max_z;
+    if (n_z <= 1) return sh;
     const int64_t z_len = ((n + n_z - 1) / n_z + kChunk - 1) / kChunk * kChunk;
     n_z = (n + z_len - 1) / z_len;
     if (n_z <= 1) return sh;
