@@ -88,6 +88,9 @@ __global__ __launch_bounds__(kBlock) void highest_peak_kernel(const double *powe
 // x[i] <= x[peak] is false).  Ranking is by successive "best entry strictly after the previous winner" in
 // the total order (key descending, bin ascending), so a maximum collected twice is reported once.
 constexpr int kPkBlock = 256;
+#ifndef PDC_PK_WAVES
+#define PDC_PK_WAVES 5
+#endif
 constexpr int kPkMaxBlocks = 4096;   // LDS: two doubles per block
 constexpr int kPkMaxK = 16;
 constexpr int kPkPre = 20;           // by prominence: the first walks go to the k + 4 highest maxima
@@ -125,13 +128,13 @@ __device__ __forceinline__ bool cand_before(double ka, long long ia, double kb, 
     return ib < 0 || (ia >= 0 && (ka > kb || (ka == kb && ia < ib)));
 }
 
-__global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
+__global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *bmin = reinterpret_cast<double *>(lds_raw);   // [nblk]
     double *bmax = bmin + a.nblk;                         // [nblk]
     double *ch = bmax + a.nblk;                           // [kPkCap] candidates: height,
     double *cp = ch + kPkCap;                             //          prominence (NaN: not walked yet),
-    long long *ci = reinterpret_cast<long long *>(cp + kPkCap);   //  bin
+    int *ci = reinterpret_cast<int *>(cp + kPkCap);               //  bin (rows have < 2^31 bins: launch_topk)
     __shared__ int s_ncand;
     __shared__ double s_thr;
     __shared__ double red_k[kPkBlock / 64];
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
     __shared__ long long s_count[kPkBlock / 64];
     __shared__ double win_key[kPkPre], win_h[kPkPre], win_p[kPkPre];
     __shared__ long long win_idx[kPkPre];
-    __shared__ long long s_found;
+    __shared__ unsigned s_need[32];   // second sweep: chunks that can hold a candidate at the initial tau
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *x = a.power + (int64_t)blockIdx.x * a.nf;
     const int64_t nf = a.nf;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
         }
         __syncthreads();
         for (int e = tid; e < found; e += kPkBlock) {
-            ci[e] = win_idx[e];
+            ci[e] = (int)win_idx[e];
             ch[e] = win_h[e];
             cp[e] = win_p[e];
         }
@@ -335,20 +338,66 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
         // every neighbour is a lane shuffle away, and all loads of a chunk are in flight together - in the
         // first sweep one chunk ahead of the one being examined
         constexpr int kPer = kPkChunk / kPkBlock;
+        // lane L owns the kPer CONSECUTIVE bins w0 + kPer L .. + kPer - 1 (two 16-byte loads on the fast path):
+        // three of four neighbours are the lane's own registers, the other two one DPP wave shift away
+        // (the first version gave lane L the bins w0 + 64 j + L and fetched every neighbour with
+        // ds_bpermute: 55 LDS instructions per wave and chunk)
+        static_assert(kPer == 4, "the fast path loads two pairs of doubles");
+        typedef double pair_t __attribute__((ext_vector_type(2), aligned(8)));
         auto load = [&](int64_t c0, double (&v)[kPer], double &halo_lo, double &halo_hi) __attribute__((always_inline)) {
             const int64_t w0 = c0 + (int64_t)wave * (64 * kPer);
+            const int64_t i0 = w0 + (int64_t)lane * kPer;
+            if (w0 + 64 * kPer <= nf) {   // (wave-uniform) the whole stretch lies inside the row
+                const pair_t a01 = *reinterpret_cast<const pair_t *>(x + i0);
+                const pair_t a23 = *reinterpret_cast<const pair_t *>(x + i0 + 2);
+                v[0] = a01.x;
+                v[1] = a01.y;
+                v[2] = a23.x;
+                v[3] = a23.y;
+            } else {
 #pragma unroll
-            for (int j = 0; j < kPer; ++j) {
-                const int64_t i = w0 + j * 64 + lane;
-                v[j] = i < nf ? x[i] : nan;
+                for (int j = 0; j < kPer; ++j) v[j] = i0 + j < nf ? x[i0 + j] : nan;
             }
             halo_lo = (w0 >= 1 && w0 <= nf) ? x[w0 - 1] : nan;
             halo_hi = w0 + 64 * kPer < nf ? x[w0 + 64 * kPer] : nan;
         };
+        // x of the lane below / above (lane 0 / 63: the halo), by DPP wave shifts on both halves of the double
+        auto from_below = [&](double q, double edge) __attribute__((always_inline)) -> double {
+            const long long qb = __double_as_longlong(q), eb = __double_as_longlong(edge);
+            const int lo = __builtin_amdgcn_update_dpp((int)eb, (int)qb, 0x138, 0xf, 0xf, false);           // wave_shr:1
+            const int hi = __builtin_amdgcn_update_dpp((int)(eb >> 32), (int)(qb >> 32), 0x138, 0xf, 0xf, false);
+            return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+        };
+        auto from_above = [&](double q, double edge) __attribute__((always_inline)) -> double {
+            const long long qb = __double_as_longlong(q), eb = __double_as_longlong(edge);
+            const int lo = __builtin_amdgcn_update_dpp((int)eb, (int)qb, 0x130, 0xf, 0xf, false);           // wave_shl:1
+            const int hi = __builtin_amdgcn_update_dpp((int)(eb >> 32), (int)(qb >> 32), 0x130, 0xf, 0xf, false);
+            return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+        };
+        // (first sweep: one chunk ahead of the one being examined; two ahead measured the same and cost the
+        // registers that decide between five and six workgroups per CU)
         double v[kPer], halo_lo, halo_hi, vn[kPer], next_lo = nan, next_hi = nan;
         if (FIRST) load(0, v, halo_lo, halo_hi);
+        // Second sweep: tau only rises, so a chunk whose block maxima rule a candidate out at the INITIAL tau
+        // never needs a look - found for all chunks at once, and those chunks cost neither a barrier nor an
+        // LDS scan below (of 49 chunks of a C3 row a handful remain)
+        const int64_t nchunks = (nf + kPkChunk - 1) / kPkChunk;
+        const bool masked = !FIRST && nchunks <= 32 * 32;
+        if (masked) {
+            if (tid < 32) s_need[tid] = 0u;
+            __syncthreads();
+            const double thr0 = s_thr;
+            for (int64_t c = tid; c < nchunks; c += kPkBlock) {
+                const int64_t e0 = c * kPkChunk, e1 = e0 + kPkChunk < nf ? e0 + kPkChunk : nf;
+                double tmx = -inf;
+                for (int64_t b = e0 >> sh; b < ((e1 + blk - 1) >> sh); ++b) tmx = bmax[b] > tmx ? bmax[b] : tmx;
+                if (tmx - sub >= thr0) atomicOr(&s_need[c >> 5], 1u << (c & 31));
+            }
+            __syncthreads();
+        }
         for (int64_t c0 = 0; c0 < nf; c0 += kPkChunk) {
             const int64_t c1 = c0 + kPkChunk < nf ? c0 + kPkChunk : nf;
+            if (masked && !((s_need[(c0 / kPkChunk) >> 5] >> ((c0 / kPkChunk) & 31)) & 1u)) continue;   // (workgroup-uniform)
             if (FIRST) load(c0 + kPkChunk, vn, next_lo, next_hi);
             __syncthreads();   // everyone is done with the previous chunk (and sees s_thr / s_ncand)
             if (s_ncand > kPkCap / 2) {   // (workgroup-uniform) a chunk adds at most kPkChunk / 2 maxima
@@ -371,7 +420,7 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
 #pragma unroll
                 for (int j = 0; j < kPer; ++j) {
                     const double q = v[j];
-                    isnan = isnan || (w0 + j * 64 + lane < nf && q != q);
+                    isnan = isnan || (w0 + lane * kPer + j < nf && q != q);
                     mn = q < mn ? q : mn;
                     mx = q > mx ? q : mx;
                 }
@@ -383,14 +432,12 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
                     bmax[w0 >> kPkFusedShift] = mx;
                 }
             }
+            const double below = from_below(v[kPer - 1], halo_lo), above = from_above(v[0], halo_hi);
 #pragma unroll
             for (int j = 0; j < kPer; ++j) {
-                const int64_t i = w0 + j * 64 + lane;
-                double prev = __shfl_up(v[j], 1, 64), next = __shfl_down(v[j], 1, 64);
-                const double before = j == 0 ? halo_lo : __shfl(v[j > 0 ? j - 1 : 0], 63, 64);
-                const double behind = j == kPer - 1 ? halo_hi : __shfl(v[j < kPer - 1 ? j + 1 : j], 0, 64);
-                prev = lane == 0 ? before : prev;
-                next = lane == 63 ? behind : next;
+                const int64_t i = w0 + (int64_t)lane * kPer + j;
+                const double prev = j == 0 ? below : v[j > 0 ? j - 1 : 0];
+                const double next = j == kPer - 1 ? above : v[j < kPer - 1 ? j + 1 : j];
                 // a maximum: strict rise, flat tops -> midpoint, edges and NaN never peaks
                 const double vv = v[j];
                 if (!(i >= 1 && i < nf - 1 && prev < vv)) continue;
@@ -405,7 +452,7 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
                 if (FIRST && !(vv >= thr)) continue;
                 const int slot = atomicAdd(&s_ncand, 1);
                 const int64_t mid = (i + ahead - 1) / 2;
-                ci[slot] = mid;
+                ci[slot] = (int)mid;
                 ch[slot] = mid == i ? vv : x[mid];   // (a flat top of zeros may mix +0.0 and -0.0: the reported
                                                      // height is the midpoint's own bits, as scipy's x[peaks])
                 cp[slot] = nan;
@@ -466,8 +513,10 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
     }
 
     // ---- D: half-maximum crossings of every ranked peak (periods_at_half_max) -------------------
+    // One wave per ranked peak (the k searches run side by side, no workgroup barriers): 256 bins per step
+    // outwards from the peak, four loads per lane in flight, the nearest sign change by ballot.
     if (!a.half_lo && !a.half_hi) return;
-    for (int r = 0; r < a.k; ++r) {
+    for (int r = wave; r < a.k; r += kPkBlock / 64) {
         const long long idmax = r < nwin ? win_idx[r] : -1;
         long long lo_abs = -1, hi_abs = -1;
         if (idmax >= 0) {
@@ -475,39 +524,36 @@ __global__ __launch_bounds__(kPkBlock) void peaks_topk_kernel(PeakArgs a) {
             auto flips = [&](int64_t i) {                       // signbit(x[i]-half) != signbit(x[i+1]-half)
                 return (__double_as_longlong(x[i] - half) < 0) != (__double_as_longlong(x[i + 1] - half) < 0);
             };
-            // last sign change inside x[:idmax]: pairs (i, i+1), i+1 <= idmax-1; search outwards in chunks
-            for (int64_t top = idmax - 2; top >= 0; top -= kPkBlock) {
-                const int64_t i = top - tid;
-                const bool f = i >= 0 && flips(i);
-                __syncthreads();
-                if (tid == 0) s_found = -1;
-                __syncthreads();
-                if (f) atomicMax(&s_found, (long long)i);
-                __syncthreads();
-                const long long got = s_found;
-                if (got >= 0) {   // (workgroup-uniform)
-                    hi_abs = got;
-                    break;
+            // last sign change inside x[:idmax]: pairs (i, i+1), i+1 <= idmax-1; nearest to the peak first
+            for (int64_t top = idmax - 2; top >= 0 && hi_abs < 0; top -= 256) {
+                bool f[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = top - (64 * u + lane);
+                    f[u] = i >= 0 && flips(i);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long mask = __ballot(f[u]);
+                    if (mask && hi_abs < 0) hi_abs = top - (64 * u + __builtin_ctzll(mask));
                 }
             }
             // first sign change from the peak rightwards: pairs (idmax+i, idmax+i+1)
-            for (int64_t base = idmax; base < nf - 1; base += kPkBlock) {
-                const int64_t i = base + tid;
-                const bool f = i < nf - 1 && flips(i);
-                __syncthreads();
-                if (tid == 0) s_found = nf;
-                __syncthreads();
-                if (f) atomicMin(&s_found, (long long)i);
-                __syncthreads();
-                const long long got = s_found;
-                if (got < nf) {
-                    lo_abs = got;
-                    break;
+            for (int64_t base = idmax; base < nf - 1 && lo_abs < 0; base += 256) {
+                bool f[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = base + 64 * u + lane;
+                    f[u] = i < nf - 1 && flips(i);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long mask = __ballot(f[u]);
+                    if (mask && lo_abs < 0) lo_abs = base + 64 * u + __builtin_ctzll(mask);
                 }
             }
         }
-        __syncthreads();
-        if (tid == 0) {
+        if (lane == 0) {
             if (a.half_lo) a.half_lo[ob + r] = lo_abs;
             if (a.half_hi) a.half_hi[ob + r] = hi_abs;
         }
@@ -555,13 +601,14 @@ int pdc_highest_peak(const double *power, int64_t n_curves, int64_t nf, int64_t 
 namespace {
 
 int launch_topk(hipStream_t st, PeakArgs a, int64_t n_curves) {
+    PDC_REQUIRE(a.nf < ((int64_t)1 << 31), "peaks_topk: at most 2^31-1 bins per spectrum");
     int sh = kPkFusedShift;
     while (((a.nf + ((int64_t)1 << sh) - 1) >> sh) > kPkMaxBlocks) ++sh;
     a.blk_shift = sh;
     a.nblk = (a.nf + ((int64_t)1 << sh) - 1) >> sh;
     // LDS: 24 KB of candidate slots + 12.5 KB of block extrema at 5e4 bins - four workgroups per CU
     a.tile = 0;
-    const size_t lds = (size_t)(a.nblk > 0 ? a.nblk : 1) * 16 + (size_t)kPkCap * 24 + 16;
+    const size_t lds = (size_t)(a.nblk > 0 ? a.nblk : 1) * 16 + (size_t)kPkCap * 20 + 16;
     PDC_REQUIRE(lds <= 150 * 1024, "peaks_topk: %lld bins per spectrum need %zu bytes of LDS", (long long)a.nf, lds);
     PDC_TRY(allow_dynamic_lds((const void *)peaks_topk_kernel, 150 * 1024));
     hipLaunchKernelGGL(peaks_topk_kernel, dim3((unsigned)n_curves), dim3(kPkBlock), lds, st, a);
