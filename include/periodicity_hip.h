@@ -252,10 +252,22 @@ int pdc_cond_entropy_scan_dev(int device, void *stream, const double *d_t, const
                               int64_t n, const double *d_periods, int64_t n_periods, int n_phase,
                               int n_mag, double *d_entropy);
 
-/* The four phase-fold statistics behind one device-resident entry with an EXPLICIT workspace (nothing is
+/* The third TODO of phase.py:11-15: the Gregory-Loredo method (Gregory & Loredo 1992, ApJ 398, 146) for
+ * ARRIVAL TIMES t (the signal's values are not used): for every trial period the log of
+ *     S_m(w) = (1 / 2 pi) Int dphi  m^N n_1! ... n_m! / N!      (their eq. 5.13-5.14 marginalised over the offset;
+ * the integrand of the odds ratio O_m1, eq. 5.28), n_j = counts in m phase bins, the offset integral as the
+ * mean over n_offsets equally spaced shifts of the bin boundaries; m * n_offsets <= 190.  Counts-only histogram
+ * on the PDM binning kernel (same exact phases, same edges f / F).  The reference has no implementation:
+ * parity is pinned to the published formula, restated in oracle/scan_oracle.py. */
+int pdc_gl_scan(const double *t, int64_t n, const double *periods, int64_t n_periods, int m, int n_offsets,
+                double *log_s_out, int device);
+int pdc_gl_scan_dev(int device, void *stream, const double *d_t, int64_t n, const double *d_periods,
+                    int64_t n_periods, int m, int n_offsets, double *d_log_s);
+
+/* The phase-fold statistics behind one device-resident entry with an EXPLICIT workspace (nothing is
  * cached per stream, nothing is allocated): kind 0 = PDM theta (nb, nc, sigma as pdc_pdm_scan), 1 = AoV
  * (nb = n_bins), 2 = conditional entropy (nb = n_phase, nc = n_mag, v = magnitude bins), 3 = StringLength
- * (v = m; nb, nc, sigma ignored).  `work` holds at least pdc_phase_work_bytes(kind, n, n_periods, nb, nc)
+ * (v = m; nb, nc, sigma ignored), 4 = Gregory-Loredo (v may be NULL; nb = m * n_offsets, nc = m).  `work` holds at least pdc_phase_work_bytes(kind, n, n_periods, nb, nc)
  * bytes (0 for most PDM shapes: only short period grids over long curves split the samples and need
  * scratch for partial histograms). */
 int64_t pdc_phase_work_bytes(int kind, int64_t n, int64_t n_periods, int nb, int nc);
@@ -276,6 +288,8 @@ int pdc_aov_scan_multi(const double *t, const double *x, int64_t n, const double
 int pdc_cond_entropy_scan_multi(const double *t, const double *mag_bin, int64_t n, const double *periods,
                                 int64_t n_periods, int n_phase, int n_mag, double *entropy_out,
                                 const int *devices, int n_devices);
+int pdc_gl_scan_multi(const double *t, int64_t n, const double *periods, int64_t n_periods, int m, int n_offsets,
+                      double *log_s_out, const int *devices, int n_devices);
 
 /* The same fan-out as a persistent plan for callers that scan repeatedly or want the samples resident
  * (bench.py, a survey loop): replaces Pool(cores).map of phase.py:69-70,185-186.

@@ -324,6 +324,32 @@ def cond_entropy_scan(t, mag_bin, periods, n_phase=10, n_mag=5):
     return np.array([cond_entropy(t, mag_bin, p, n_phase, n_mag) for p in periods])
 
 
+def gl_log_s(t, period, m, n_offsets=8):
+    """Gregory & Loredo (1992, ApJ 398, 146), eq. 5.13-5.14 marginalised over the bin offset: the log of
+    ``<m^N / W_m(w, phi)>_phi`` with ``W_m = N! / (n_1! ... n_m!)`` the multiplicity of the counts of the
+    arrival times ``t`` in ``m`` phase bins, the offset average over ``n_offsets`` shifts of the bin
+    boundaries by ``1 / (m n_offsets)`` of a cycle.  Phases and fine-bin edges as ``PDM._pdm`` computes and
+    compares them (``phase.py:131,137``).  The reference lists the method as TODO (``phase.py:13``): parity
+    is to this restatement of the paper."""
+    from scipy.special import gammaln
+    fine = m * n_offsets
+    k = _phase_bins(t, period, fine)
+    counts = np.bincount(k[k >= 0], minlength=fine).astype(np.int64)
+    n = int(counts.sum())
+    if n == 0:
+        return np.nan
+    log_terms = np.empty(n_offsets)
+    for off in range(n_offsets):
+        per_bin = np.roll(counts, -off).reshape(m, n_offsets).sum(axis=1)
+        log_terms[off] = n * np.log(m) + gammaln(per_bin + 1.0).sum() - gammaln(n + 1.0)
+    top = log_terms.max()
+    return top + np.log(np.exp(log_terms - top).sum() / n_offsets)
+
+
+def gl_scan(t, periods, m, n_offsets=8):
+    return np.array([gl_log_s(t, p, m, n_offsets) for p in periods])
+
+
 def stringlength_one(t, m, period):
     """Dworetsky string length for one trial period: ``StringLength._stringlength``
     (``phase.py:45-51``) through ``TSeries.fold`` (``core.py:543-544``) and the stable

@@ -80,11 +80,14 @@ PROTOTYPES = {
     "pdc_stringlength_scan": (_I, [_VP, _VP, _L, _VP, _L, _VP, _I]),
     "pdc_stringlength_work_bytes": (_L, [_L, _L]),
     "pdc_stringlength_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _VP, _VP, _L]),
+    "pdc_gl_scan": (_I, [_VP, _L, _VP, _L, _I, _I, _VP, _I]),
+    "pdc_gl_scan_dev": (_I, [_I, _VP, _VP, _L, _VP, _L, _I, _I, _VP]),
     "pdc_phase_work_bytes": (_L, [_I, _L, _L, _I, _I]),
     "pdc_phase_scan_dev": (_I, [_I, _I, _VP, _VP, _VP, _L, _VP, _L, _I, _I, _D, _VP, _VP, _L]),
     "pdc_pdm_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _I, _I, _D, _VP, _VP, _I]),
     "pdc_aov_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _I, _VP, _VP, _I]),
     "pdc_cond_entropy_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _I, _I, _VP, _VP, _I]),
+    "pdc_gl_scan_multi": (_I, [_VP, _L, _VP, _L, _I, _I, _VP, _VP, _I]),
     "pdc_phase_plan_create": (_I, [_VP, _I, _L, _L, C.POINTER(_VP)]),
     "pdc_phase_plan_upload": (_I, [_VP, _VP, _VP, _L]),
     "pdc_phase_plan_scan": (_I, [_VP, _I, _VP, _L, _I, _I, _D]),
@@ -496,6 +499,24 @@ def cond_entropy_scan(t, mag_bin, periods, n_phase, n_mag, device=None, devices=
     return out
 
 
+def gl_scan(t, periods, m, n_offsets, device=None, devices=None):
+    """Gregory-Loredo ``ln S_m`` at every trial period for the arrival times ``t`` (``pdc_gl_scan``): ``m``
+    phase bins, the bin-offset integral as the mean over ``n_offsets`` shifts; ``devices`` as in
+    :func:`pdm_scan`."""
+    t, periods = _f64(t, "t"), _f64(periods, "periods")
+    out = np.empty(periods.size, dtype=np.float64)
+    if devices is not None and len(devices) > 1:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        check(lib().pdc_gl_scan_multi(_ptr(t), t.size, _ptr(periods), periods.size, int(m), int(n_offsets),
+                                      _ptr(out), _ptr(devs), devs.size))
+        return out
+    if devices is not None and device is None:
+        device = devices[0]
+    dev = default_device() if device is None else device
+    check(lib().pdc_gl_scan(_ptr(t), t.size, _ptr(periods), periods.size, int(m), int(n_offsets), _ptr(out), dev))
+    return out
+
+
 def stringlength_scan(t, m, periods, device=None, devices=None):
     """String length at every trial period; ``devices`` as in :func:`pdm_scan`
     (``pdc_stringlength_scan_multi``)."""
@@ -516,7 +537,7 @@ def stringlength_scan(t, m, periods, device=None, devices=None):
     return out
 
 
-PHASE_KINDS = {"pdm": 0, "aov": 1, "cond_entropy": 2, "stringlength": 3}
+PHASE_KINDS = {"pdm": 0, "aov": 1, "cond_entropy": 2, "stringlength": 3, "gregory_loredo": 4}
 
 
 class PhasePlan:

@@ -543,11 +543,11 @@ int phase_upload(PhasePlan *p, const double *t, const double *v, int64_t n) {
 }
 
 // kind 0 = PDM (v = x), 1 = AoV (v = x; nb phase bins), 2 = conditional entropy (v = magnitude bins; nb x nc
-// cells), 3 = StringLength (v = m).  Enqueues on every slot: its slab of the trial periods H2D, the scan,
+// cells), 3 = StringLength (v = m), 4 = Gregory-Loredo (v unused; nb = m * offsets fine bins, nc = m).  Enqueues on every slot: its slab of the trial periods H2D, the scan,
 // the slab of results D2H into the page-locked result block - and returns.
 int phase_scan(PhasePlan *p, int kind, const double *periods, int64_t n_periods, int nb, int nc, double sigma) {
-    PDC_REQUIRE(kind >= 0 && kind <= 3, "phase_plan_scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional "
-                                        "entropy) or 3 (StringLength)");
+    PDC_REQUIRE(kind >= 0 && kind <= 4, "phase_plan_scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional "
+                                        "entropy), 3 (StringLength) or 4 (Gregory-Loredo)");
     PDC_REQUIRE((periods || n_periods == 0) && n_periods >= 0, "phase_plan_scan: bad period grid");
     const int nd = (int)p->slot.size();
     PDC_TRY(phase_wait(p));   // the period / result staging blocks of the previous scan are free after this
@@ -626,8 +626,9 @@ int cached_phase_plan(const char *who, const int *devices, int n_devices, PhaseP
 int phase_multi_entry(int kind, const char *who, const double *t, const double *v, int64_t n,
                       const double *periods, int64_t n_periods, int nb, int nc, double sigma,
                       double *out, const int *devices, int n_devices) {
-    PDC_REQUIRE(t && v && devices && (periods || n_periods == 0) && (out || n_periods == 0),
+    PDC_REQUIRE(t && (v || kind == 4) && devices && (periods || n_periods == 0) && (out || n_periods == 0),
                 "%s: NULL argument", who);
+    if (kind == 4) v = t;   // (the plan replicates two arrays; arrival times alone are scanned)
     PDC_REQUIRE(n >= 0 && n_periods >= 0 && n_devices >= 1 && n_devices <= 64, "%s: bad size", who);
     if (kind == 2)
         for (int64_t i = 0; i < n; ++i)
@@ -729,6 +730,13 @@ int pdc_cond_entropy_scan_multi(const double *t, const double *mag_bin, int64_t 
                                 const int *devices, int n_devices) {
     return phase_multi_entry(2, "cond_entropy_multi", t, mag_bin, n, periods, n_periods, n_phase, n_mag, 1.0,
                              entropy_out, devices, n_devices);
+}
+
+int pdc_gl_scan_multi(const double *t, int64_t n, const double *periods, int64_t n_periods, int m, int n_offsets,
+                      double *log_s_out, const int *devices, int n_devices) {
+    PDC_REQUIRE(m >= 1 && n_offsets >= 1 && (int64_t)m * n_offsets <= 190, "gregory_loredo: m * n_offsets must be 1..190");
+    return phase_multi_entry(4, "gl_multi", t, nullptr, n, periods, n_periods, m * n_offsets, m, 1.0, log_s_out,
+                             devices, n_devices);
 }
 
 int pdc_stringlength_scan_multi(const double *t, const double *m, int64_t n,

@@ -198,6 +198,45 @@ __device__ __forceinline__ double ce_from_bins(CntAt cnt_at, int m0, int mag) {
     return h;
 }
 
+// Gregory & Loredo (1992, ApJ 398, 146): arrival times t_i, model M_m = a periodic rate that is constant in
+// each of m phase bins.  For trial frequency w and phase offset phi the likelihood depends on the data only
+// through the multiplicity W_m(w, phi) = N! / (n_1! ... n_m!) of the bin counts (their eq. 5.13-5.14), and
+// the marginal over the offset,
+//     S_m(w) = (1 / 2 pi) Int dphi  m^N / W_m(w, phi),
+// is what the odds ratio O_m1 (eq. 5.28) integrates over dw / w.  Here: ln S_m(w) with the offset integral as
+// the mean over `offsets` equally spaced shifts of the bin boundaries by 1 / (m offsets) of a cycle - the
+// counts of every shift are sums of `offsets` consecutive FINE bins of a histogram over F = m offsets bins
+// [f / F, (f + 1) / F) (phi == 1.0 joins the last), cnt_at(f).  Log-sum-exp over the shifts, lgamma for the
+// factorials.
+template <typename CntAt>
+__device__ __forceinline__ double gl_from_bins(CntAt cnt_at, int F, int m) {
+    const int offsets = F / m;
+    long long n = 0;
+    for (int f = 0; f <= F; ++f) n += cnt_at(f);
+    if (n == 0 || offsets < 1) return __builtin_nan("");
+    const double base = (double)n * log((double)m) - lgamma((double)n + 1.0);
+    double top = 0.0, sum = 0.0;
+    for (int k = 0; k < offsets; ++k) {
+        double lw = base;
+        int f = k;
+        for (int j = 0; j < m; ++j) {
+            long long c = 0;
+            for (int i = 0; i < offsets; ++i) {
+                c += cnt_at(f) + (f == F - 1 ? cnt_at(F) : 0);
+                f = f + 1 == F ? 0 : f + 1;
+            }
+            lw += lgamma((double)c + 1.0);
+        }
+        if (k == 0 || lw > top) {   // running log-sum-exp
+            sum = k == 0 ? 1.0 : sum * exp(top - lw) + 1.0;
+            top = lw;
+        } else {
+            sum += exp(lw - top);
+        }
+    }
+    return top + log(sum / (double)offsets);
+}
+
 // SPLIT waves of a workgroup share one group of 64 trial periods (lane = period) and split every
 // staged chunk of samples between them, so that a grid of ~1e5 periods still puts several waves on
 // every SIMD (the loop is a chain of LDS read -> ALU -> LDS atomic: it needs wave-level parallelism
@@ -209,10 +248,11 @@ __device__ __forceinline__ double ce_from_bins(CntAt cnt_at, int m0, int mag) {
 // only) instead of phase bins.
 template <int BLOCK, int SPLIT, bool ZS = false, int KIND = 0>
 __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
-    constexpr bool CE = KIND == 2;
+    constexpr bool CE = KIND == 2 || KIND == 4;   // counts only
+    constexpr bool GL = KIND == 4;                // ... of arrival times alone: x is not read
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int mag = CE ? a.nc : 1;                 // magnitude bins per phase bin
-    const int m0 = CE ? a.nb : a.nb * a.nc;        // phase bins
+    const int mag = KIND == 2 ? a.nc : 1;          // magnitude bins per phase bin
+    const int m0 = CE ? a.nb : a.nb * a.nc;        // phase bins (Gregory-Loredo: the fine bins, nb = m * offsets)
     const int nbins = (m0 + 1) * mag;              // + overflow row for phi == 1.0
     double2 *stage = reinterpret_cast<double2 *>(lds_raw);                  // [kChunk] (t, x')
     // the staging area doubles as the q_over/q_nan exchange ([2][BLOCK] doubles) at the end
@@ -239,14 +279,14 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         double acc = 0.0;
         tmax = 0.0;
         for (int64_t i = tid; i < a.n; i += BLOCK) {
-            acc += a.x[i];
+            acc += GL ? 0.0 : a.x[i];
             const double at = __builtin_fabs(a.t[i]);
             tmax = at > tmax ? at : tmax;
         }
         mean = block_reduce<BLOCK>(acc, red, false) / (double)a.n;
         tmax = block_reduce<BLOCK>(tmax, red, true);
         acc = 0.0;
-        for (int64_t i = tid; i < a.n; i += BLOCK) {
+        for (int64_t i = tid; i < a.n && !CE; i += BLOCK) {
             const double d = a.x[i] - mean;
             acc += d * d;
         }
@@ -275,8 +315,8 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         __syncthreads();
         for (int i = tid; i < kChunk; i += BLOCK) {
             const int64_t g = base + i;
-            double2 v = g < s_end ? make_double2(a.t[g], CE ? a.x[g] : a.x[g] - mean) : make_double2(0.0, 0.0);
-            if (CE && !(v.y >= 0.0 && v.y < (double)mag)) {
+            double2 v = g < s_end ? make_double2(a.t[g], GL ? 0.0 : (CE ? a.x[g] : a.x[g] - mean)) : make_double2(0.0, 0.0);
+            if (KIND == 2 && !(v.y >= 0.0 && v.y < (double)mag)) {
                 // the magnitude bin is the caller's double and indexes the cell histogram: anything outside
                 // 0 .. mag-1 (NaN included) is staged with a NaN time - its phase is NaN, so it takes the exact
                 // path and counts nowhere, exactly as if the sample were absent (the host entries reject such
@@ -405,7 +445,8 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     }
     auto sum_at = [&](int b) { return hsum[b * BLOCK + tid]; };
     auto cnt_at = [&](int b) { return (long long)hcnt[b * BLOCK + tid]; };
-    if (CE) a.theta[pidx] = ce_from_bins(cnt_at, m0, mag);
+    if (GL) a.theta[pidx] = gl_from_bins(cnt_at, m0, a.nc);
+    else if (CE) a.theta[pidx] = ce_from_bins(cnt_at, m0, mag);
     else if (KIND == 1) a.theta[pidx] = aov_from_bins(sum_at, cnt_at, m0, q_total - q_nan);
     else a.theta[pidx] = theta_from_bins(sum_at, cnt_at, m0, a.nc, q_total, q_nan, q_over, a.sigma);
 }
@@ -465,11 +506,11 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
     static const int env_split = [] { const char *e = getenv("PDC_PDM_SPLIT"); return e ? atoi(e) : -1; }();
     SplitShape sh;
     if (kind == 1) nc = 1;
-    const int m0 = kind == 2 ? nb : nb * nc;
+    const int m0 = kind >= 2 ? nb : nb * nc;
     const int last = kind == 2 ? (nb + 1) * nc - 1 : m0;
     const int nbins = last + 1;
     const int64_t groups0 = (n_periods + 63) / 64;
-    if (kind == 2 || env_split == 0 || n_periods == 0 || n < 32 * kChunk || lds_bytes(last, 256) > 150 * 1024 ||
+    if (kind >= 2 || env_split == 0 || n_periods == 0 || n < 32 * kChunk || lds_bytes(last, 256) > 150 * 1024 ||
         (size_t)nbins * 64 * 16 > 150 * 1024)
         return sh;
     const int64_t max_z = n / (8 * kChunk);
@@ -517,7 +558,7 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
 }  // namespace
 
 int64_t pdc::phase_stat_work_bytes(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
-    if (kind < 0 || kind > 2 || n < 0 || n_periods < 0 || nb < 1 || nc < 1) return -1;
+    if (kind < 0 || kind > 4 || kind == 3 || n < 0 || n_periods < 0 || nb < 1 || nc < 1) return -1;
     return split_shape(kind, n, n_periods, nb, nc).bytes;
 }
 
@@ -527,12 +568,13 @@ int64_t pdc::phase_stat_work_bytes(int kind, int64_t n, int64_t n_periods, int n
 int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, const double *d_x, int64_t n,
                         const double *d_periods, int64_t n_periods, int nb, int nc, double sigma, double *d_out,
                         void *work, int64_t work_bytes) {
-    PDC_REQUIRE(d_t && d_x && (d_periods || n_periods == 0) && (d_out || n_periods == 0),
+    PDC_REQUIRE(d_t && (d_x || kind == 4) && (d_periods || n_periods == 0) && (d_out || n_periods == 0),
                 "phase scan: NULL argument");
     PDC_REQUIRE(n >= 0 && n_periods >= 0, "phase scan: negative size");
     PDC_REQUIRE(nb >= 1 && nc >= 1, "phase scan: bin counts must be positive");
+    PDC_REQUIRE(kind != 4 || nb % nc == 0, "gregory_loredo: the fine bins (%d) must be a multiple of m (%d)", nb, nc);
     if (kind == 1) nc = 1;
-    const int m0 = kind == 2 ? nb : nb * nc;                    // phase bins
+    const int m0 = kind >= 2 ? nb : nb * nc;                    // phase bins
     const int last = kind == 2 ? (nb + 1) * nc - 1 : m0;        // highest histogram bin
     PDC_REQUIRE(last <= 190, "phase scan: %d histogram bins exceed the 191 that fit in LDS", last + 1);
     if (n_periods == 0) return PDC_OK;
@@ -577,7 +619,7 @@ int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t,
         PDC_HIP(hipGetLastError());
         return PDC_OK;
     }
-    const int bpb = kind == 2 ? 4 : 12;
+    const int bpb = kind >= 2 ? 4 : 12;
     auto launch = [&](auto kernel, int block, int periods_per_block) -> int {
         PDC_TRY(allow_lds(kernel));
         hipLaunchKernelGGL(kernel, dim3((unsigned)((n_periods + periods_per_block - 1) / periods_per_block)),
@@ -593,7 +635,8 @@ int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t,
         if (groups >= 2048) return launch(pdm_scan_kernel<256, 2, false, K>, 256, 128);
         return launch(pdm_scan_kernel<256, 4, false, K>, 256, 64);
     };
-    if (kind == 2) PDC_TRY(launch_kind(std::integral_constant<int, 2>{}));
+    if (kind == 4) PDC_TRY(launch_kind(std::integral_constant<int, 4>{}));
+    else if (kind == 2) PDC_TRY(launch_kind(std::integral_constant<int, 2>{}));
     else if (kind == 1) PDC_TRY(launch_kind(std::integral_constant<int, 1>{}));
     else PDC_TRY(launch_kind(std::integral_constant<int, 0>{}));
     PDC_HIP(hipGetLastError());
@@ -610,8 +653,8 @@ int64_t pdc_phase_work_bytes(int kind, int64_t n, int64_t n_periods, int nb, int
 int pdc_phase_scan_dev(int kind, int device, void *stream, const double *d_t, const double *d_v, int64_t n,
                        const double *d_periods, int64_t n_periods, int nb, int nc, double sigma, double *d_out,
                        void *work, int64_t work_bytes) {
-    PDC_REQUIRE(kind >= 0 && kind <= 3, "phase scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional entropy) or 3 "
-                                        "(StringLength)");
+    PDC_REQUIRE(kind >= 0 && kind <= 4, "phase scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional entropy), 3 "
+                                        "(StringLength) or 4 (Gregory-Loredo)");
     if (kind == 3)
         return pdc_stringlength_scan_dev(device, stream, d_t, d_v, n, d_periods, n_periods, d_out, work, work_bytes);
     const int64_t need = phase_stat_work_bytes(kind, n, n_periods, nb, nc);
@@ -647,7 +690,8 @@ namespace {
 
 int phase_stat_host(int kind, const double *t, const double *x, int64_t n, const double *periods,
                     int64_t n_periods, int nb, int nc, double sigma, double *out, int device) {
-    PDC_REQUIRE(t && x && (periods || n_periods == 0) && (out || n_periods == 0), "phase scan: NULL argument");
+    PDC_REQUIRE(t && (x || kind == 4) && (periods || n_periods == 0) && (out || n_periods == 0),
+                "phase scan: NULL argument");
     PDC_REQUIRE(n >= 0 && n_periods >= 0, "phase scan: negative size");
     if (kind == 2)   // the magnitude bins index the cell histogram: reject what is not one of 0 .. n_mag-1
         for (int64_t i = 0; i < n; ++i)
@@ -664,7 +708,7 @@ int phase_stat_host(int kind, const double *t, const double *x, int64_t n, const
     PDC_TRY(cached(device, SLOT_OUT0, n_periods * 8, &d_th));
     hipStream_t st = nullptr;
     PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
-    PDC_HIP(hipMemcpyAsync(d_x, x, n * 8, hipMemcpyHostToDevice, st));
+    if (x) PDC_HIP(hipMemcpyAsync(d_x, x, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_p, periods, n_periods * 8, hipMemcpyHostToDevice, st));
     PDC_TRY(phase_stat_dev(kind, device, st, (double *)d_t, (double *)d_x, n, (double *)d_p, n_periods, nb, nc,
                            sigma, (double *)d_th, d_work, wb > 0 ? wb : 0));
@@ -683,6 +727,19 @@ int pdc_aov_scan(const double *t, const double *x, int64_t n, const double *peri
 int pdc_cond_entropy_scan(const double *t, const double *mag_bin, int64_t n, const double *periods,
                           int64_t n_periods, int n_phase, int n_mag, double *entropy_out, int device) {
     return phase_stat_host(2, t, mag_bin, n, periods, n_periods, n_phase, n_mag, 1.0, entropy_out, device);
+}
+
+int pdc_gl_scan_dev(int device, void *stream, const double *d_t, int64_t n, const double *d_periods,
+                    int64_t n_periods, int m, int n_offsets, double *d_log_s) {
+    PDC_REQUIRE(m >= 1 && n_offsets >= 1 && (int64_t)m * n_offsets <= 190, "gregory_loredo: m * n_offsets must be 1..190");
+    return phase_stat_dev(4, device, (hipStream_t)stream, d_t, nullptr, n, d_periods, n_periods, m * n_offsets, m, 1.0,
+                          d_log_s, nullptr, 0);
+}
+
+int pdc_gl_scan(const double *t, int64_t n, const double *periods, int64_t n_periods, int m, int n_offsets,
+                double *log_s_out, int device) {
+    PDC_REQUIRE(m >= 1 && n_offsets >= 1 && (int64_t)m * n_offsets <= 190, "gregory_loredo: m * n_offsets must be 1..190");
+    return phase_stat_host(4, t, nullptr, n, periods, n_periods, m * n_offsets, m, 1.0, log_s_out, device);
 }
 
 int pdc_pdm_scan(const double *t, const double *x, int64_t n, const double *periods,

@@ -21,7 +21,7 @@ from .core import FSeries, TSeries
 
 MAX_CORES = cpu_count()
 
-__all__ = ["StringLength", "PDM", "AOV", "ConditionalEntropy"]
+__all__ = ["StringLength", "PDM", "AOV", "ConditionalEntropy", "GregoryLoredo"]
 
 
 # ---- host-side grid / scaling rules (O(N) or O(n_periods) numpy, as upstream) -----------------------
@@ -258,4 +258,56 @@ class ConditionalEntropy(object):
         entropy = _cabi.cond_entropy_scan(self.t, self.mag_bin, self.periods, self.n_phase, self.n_mag,
                                           device=self.device, devices=self.devices)
         self.periodogram = FSeries(1 / self.periods, entropy)
+        return self.periodogram
+
+
+class GregoryLoredo(object):
+    """Gregory-Loredo period search (Gregory & Loredo 1992, ApJ 398, 146) - the third scan the reference
+    lists as TODO (``phase.py:13``), shaped like :class:`PDM`.  It works on ARRIVAL TIMES: the time stamps of
+    ``signal`` are the events, its values are not used.  Model ``M_m`` is a periodic rate that is constant
+    in each of ``m`` phase bins; per trial frequency the data enter through the multiplicity of the bin
+    counts, ``W_m = N! / (n_1! ... n_m!)``, marginalised over the unknown offset of the bins (their eq.
+    5.13-5.14).  The periodogram returned is the log of the per-frequency odds in favour of a periodic
+    signal, ``ln sum_{m=2}^{m_max} O_m1(w) / (m_max - 1)`` with
+    ``O_m1(w) = N! (m-1)! / (N+m-1)! * <m^N / W_m(w, phi)>_phi`` (the integrand of eq. 5.28; equal prior
+    odds for every ``m``); it peaks at the period.  ``.log_s[m]`` keeps ``ln <m^N / W_m>`` per ``m``.
+
+    Parameters
+    ----------
+    m_max: int, optional
+        Largest number of phase bins (the default is 12, as in the paper); ``m`` runs over 2 .. m_max.
+    n_offsets: int, optional
+        Shifts of the bin boundaries the offset integral is averaged over (the default is 8);
+        ``m_max * n_offsets`` must not exceed 190.
+    p_min, p_max, n_periods, oversample, cores:
+        The trial-period grid, exactly as for :class:`PDM` (``phase.py:167-180``).
+    device / devices: keyword-only
+        GPU ordinal / several GPUs of this node, one contiguous slab of the period grid each.
+    """
+
+    def __init__(self, m_max=12, n_offsets=8, p_min=None, p_max=None, n_periods=1000, oversample=1, cores=None,
+                 *, device=None, devices=None):
+        self.m_max, self.n_offsets = m_max, n_offsets
+        self.p_min, self.p_max = p_min, p_max
+        self.n_periods = n_periods
+        self.oversample = oversample
+        self.cores = cores
+        self.device = device
+        self.devices = None if devices is None else tuple(devices)
+
+    def __call__(self, signal):
+        from scipy.special import gammaln, logsumexp
+        signal = _coerce(signal)
+        self.signal = signal
+        self.t = np.asarray(signal.time, dtype=float)
+        self.periods, _, _ = _pdm_periods(signal, self.p_min, self.p_max, self.n_periods, self.oversample)
+        n = int(np.sum(np.isfinite(self.t)))
+        self.log_s, terms = {}, []
+        for m in range(2, self.m_max + 1):
+            self.log_s[m] = _cabi.gl_scan(self.t, self.periods, m, self.n_offsets, device=self.device,
+                                          devices=self.devices)
+            # ln [N! (m-1)! / (N+m-1)!]: the prior volume of the m bin heights
+            terms.append(self.log_s[m] + gammaln(n + 1) + gammaln(m) - gammaln(n + m))
+        log_odds = logsumexp(np.array(terms), axis=0) - np.log(self.m_max - 1)
+        self.periodogram = FSeries(1 / self.periods, log_odds)
         return self.periodogram

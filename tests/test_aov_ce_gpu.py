@@ -113,3 +113,53 @@ def test_full_size_c5_aov_and_entropy():
     ce = _cabi.cond_entropy_scan(t, mag, periods, 10, 5)
     np.testing.assert_allclose(ce[pick], so.cond_entropy_scan(t, mag, periods[pick], 10, 5), rtol=RTOL)
     assert abs(periods[np.argmax(aov)] - 13.7) < 0.05 and abs(periods[np.argmin(ce)] - 13.7) < 0.05
+
+
+# ---- Gregory-Loredo (phase.py:13, TODO upstream): counts-only histogram path -----------------------------------
+def arrival_times(n, period, depth, seed, t_shift=0.0):
+    """Events of a periodic Poisson process: uniform times thinned by 1 + depth * cos(2 pi t / P)."""
+    rng = np.random.default_rng(seed)
+    t = rng.uniform(0, 50.0 * period, 3 * n)
+    keep = rng.uniform(0, 1 + depth, t.size) < 1 + depth * np.cos(2 * np.pi * t / period)
+    return np.sort(t[keep][:n]) + t_shift
+
+
+@pytest.mark.parametrize("n,n_periods,m,n_off", [(800, 150, 4, 8), (3000, 70, 12, 8), (257, 300, 2, 1), (5000, 4200, 7, 5),
+                                                 (40, 9, 19, 10)])
+def test_gregory_loredo_matches_published_formula(n, n_periods, m, n_off):
+    t = arrival_times(n, 3.7, 0.8, n + m)
+    periods = np.linspace(0.5, 12.0, n_periods)
+    got = _cabi.gl_scan(t, periods, m, n_off)
+    want = so.gl_scan(t, periods, m, n_off)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-9)
+    assert np.argmax(got) == np.argmax(want)
+
+
+def test_gregory_loredo_edges_devices_and_class():
+    t = arrival_times(2500, 5.3, 0.9, 7, t_shift=-400.0)             # negative times
+    periods = np.linspace(1.0, 20.0, 400)
+    want = so.gl_scan(t, periods, 6, 4)
+    np.testing.assert_allclose(_cabi.gl_scan(t, periods, 6, 4), want, rtol=RTOL, atol=1e-9)
+    assert np.array_equal(_cabi.gl_scan(t, periods, 6, 4, devices=(0, 0, 0)), _cabi.gl_scan(t, periods, 6, 4))
+    tn = t.copy()
+    tn[[3, 77]] = np.nan                                              # NaN stamps are events of no bin: N drops
+    np.testing.assert_allclose(_cabi.gl_scan(tn, periods, 6, 4), so.gl_scan(tn, periods, 6, 4), rtol=RTOL, atol=1e-9)
+    te = np.arange(600.0)                                             # phases on the bin edges, phi == 1.0 cases
+    pe = np.array([1.0, 2.0, 2.5, 4.0, 5.0, 12.5, 25.0, 50.0, 3.0000000000000004])
+    np.testing.assert_allclose(_cabi.gl_scan(te, pe, 5, 2), so.gl_scan(te, pe, 5, 2), rtol=RTOL, atol=1e-9)
+    tiny = np.concatenate([[-1e-300, -1e-18], t[:500] + 401.0])       # (t / P) % 1 == 1.0 exactly
+    np.testing.assert_allclose(_cabi.gl_scan(tiny, periods[:50], 4, 4), so.gl_scan(tiny, periods[:50], 4, 4),
+                               rtol=RTOL, atol=1e-9)
+    assert _cabi.gl_scan(t, np.empty(0), 4, 4).size == 0
+    with pytest.raises(ValueError):
+        _cabi.gl_scan(t, periods, 20, 10)                             # 200 fine bins do not fit
+    # the class: log odds summed over m = 2 .. m_max peak at the injected period (or its harmonics' base)
+    gl = phase.GregoryLoredo(m_max=8, n_offsets=6, p_min=2.0, p_max=12.0, n_periods=600)
+    res = gl(TSeries(arrival_times(4000, 5.3, 0.9, 11)))
+    assert abs(res.period[np.argmax(res.values)] - 5.3) < 0.05 and res.values.max() > 10.0
+    assert sorted(gl.log_s) == list(range(2, 9))
+    plan = _cabi.PhasePlan((0, 0))
+    plan.upload(t, t)
+    plan.scan("gregory_loredo", periods, 6 * 4, 6)
+    assert np.array_equal(plan.download(), _cabi.gl_scan(t, periods, 6, 4))
+    plan.close()

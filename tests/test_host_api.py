@@ -99,6 +99,8 @@ def oracle_backend(monkeypatch):
                         lambda t, m, p, device=None, devices=None: so.stringlength_scan(t, m, np.asarray(p)))
     monkeypatch.setattr(_cabi, "aov_scan",
                         lambda t, x, p, n_bins, device=None, devices=None: so.aov_scan(t, x, np.asarray(p), n_bins))
+    monkeypatch.setattr(_cabi, "gl_scan",
+                        lambda t, p, m, n_off, device=None, devices=None: so.gl_scan(t, np.asarray(p), m, n_off))
     monkeypatch.setattr(_cabi, "cond_entropy_scan",
                         lambda t, mb, p, n_phase, n_mag, device=None, devices=None: so.cond_entropy_scan(t, mb, np.asarray(p), n_phase, n_mag))
 

@@ -186,3 +186,25 @@ def test_conditional_entropy_restatement_equals_joint_minus_marginal_entropy():
         cells, _, _ = np.histogram2d(phi, mag, bins=(12, 6), range=((0.0, 1.0), (-0.5, 5.5)))
         want = entropy(cells.ravel()) - entropy(cells.sum(axis=1))
         np.testing.assert_allclose(so.cond_entropy(t, mag, period, 12, 6), want, rtol=1e-10)
+
+
+def test_gregory_loredo_restatement_is_the_multinomial_multiplicity():
+    """An independent pin of the Gregory-Loredo restatement: m^N / W_m with W_m = N! / prod n_j! in exact
+    integer arithmetic (math.factorial), the bin counts of every offset from numpy's own histogram of the
+    shifted phases."""
+    import math
+    rng = np.random.default_rng(99)
+    t = np.sort(rng.uniform(0, 400.0, 150))
+    for period, m, n_off in ((7.3, 3, 4), (19.1, 5, 2), (2.2, 2, 8), (50.0, 4, 1)):
+        phi = (t / period) % 1
+        terms = []
+        for off in range(n_off):
+            shifted = (phi - off / (m * n_off)) % 1
+            counts, _ = np.histogram(shifted, bins=m, range=(0.0, 1.0))
+            w = math.factorial(t.size)
+            for c in counts:
+                w //= math.factorial(int(c))
+            terms.append(m ** t.size / w)          # exact rational -> float
+        want = math.log(sum(terms) / n_off)
+        assert abs(so.gl_log_s(t, period, m, n_off) - want) < 1e-9 * abs(want)
+    assert np.isnan(so.gl_log_s(np.array([np.nan, np.nan]), 3.0, 2, 2))
