@@ -146,13 +146,14 @@ def pmc_for(kernel_substr, measured_ms):
     summ = json.load(open(PMC_SUMMARY))
     now, then = source_hashes(), summ.get("src_sha", {})
     best = None
+    parts = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
     for name, k in summ.get("kernels", {}).items():
-        if kernel_substr in name and "SQ_INSTS_VALU" in k and k.get("ms"):
+        if all(p in name for p in parts) and "SQ_INSTS_VALU" in k and k.get("ms"):
             d = abs(k["ms"] - measured_ms) / measured_ms
             if best is None or d < best[0]:
                 best = (d, name, k)
     if best is None or best[0] > 0.25:
-        return None, f"no profiled '{kernel_substr}' launch within 25% of {measured_ms:.3f} ms"
+        return None, f"no profiled '{' ... '.join(parts)}' launch within 25% of {measured_ms:.3f} ms"
     changed = [f for f in sources_of(best[1]) if now.get(f) != then.get(f)]
     if changed:
         return None, f"{rel} was collected before {', '.join(changed)} changed: refused as stale"
@@ -167,6 +168,12 @@ def valu_issue_block(kernel_substr, kernel_ms):
     out = {"kernel": k["name"], "valu_wave_instr_per_launch": k["SQ_INSTS_VALU"],
            "frac": round(busy_s / (kernel_ms * 1e-3), 4),
            "profiled_ms": k["ms"], "source": os.path.relpath(PMC_SUMMARY, ROOT)}
+    if k.get("GRBM_GUI_ACTIVE"):
+        # the chip is power-limited under fp64 load: the clock the PROFILED launch actually ran at (GRBM_GUI_ACTIVE
+        # summed over 8 XCDs / 8 / its duration) and the issue fraction of that launch at that clock
+        clk = k["GRBM_GUI_ACTIVE"] / 8.0 / (k["ms"] * 1e-3)
+        out["profiled_clock_GHz"] = round(clk / 1e9, 3)
+        out["frac_at_profiled_clock"] = round(k["SQ_INSTS_VALU"] * FP64_ISSUE_CYCLES / SIMDS / clk / (k["ms"] * 1e-3), 4)
     for key in ("hbm_bytes", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_LDS_BANK_CONFLICT",
                 "SQ_LDS_IDX_ACTIVE", "TCP_TCC_READ_REQ_sum"):
         if key in k:
@@ -181,7 +188,8 @@ def two_fracs(kernel_substr, ms, algorithmic_frac, unit):
            "algorithmic_frac": None if algorithmic_frac is None else round(algorithmic_frac, 4),
            "algorithmic_unit": unit}
     if blk:
-        out["executed_issue"] = {k: blk[k] for k in ("kernel", "valu_wave_instr_per_launch", "profiled_ms", "source")}
+        out["executed_issue"] = {k: blk[k] for k in ("kernel", "valu_wave_instr_per_launch", "profiled_ms", "source",
+                                                     "profiled_clock_GHz", "frac_at_profiled_clock") if k in blk}
     else:
         out["executed_issue_note"] = why
     return out, blk
@@ -392,7 +400,7 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
     sigma = float(np.var(y5, ddof=1))
     ms = tm.ms(lambda: cabi.check(lib.pdc_pdm_scan_dev(dev, stream, bt5.ptr, bx.ptr, n, bp.ptr, n_per, 5, 2,
                                                        sigma, bth.ptr)), reps=5)
-    fr, _ = two_fracs("pdm_scan_kernel<256, 4, false, 0>", ms, pdm_algorithmic_frac(pairs, ms), "40 flop/pair vs 78.6 TFLOP/s")
+    fr, _ = two_fracs(("pdm_scan_kernel<", ", 0> grid"), ms, pdm_algorithmic_frac(pairs, ms), "40 flop/pair vs 78.6 TFLOP/s")
     ach = pairs * PDM_FLOP_PER_PAIR / ms / 1e9
     out["c5_pdm"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), **fr,
                      "roofline": {"bound": "valu", "achieved": round(ach, 2), "peak": PEAK_FP64_VECTOR_TFLOPS,
@@ -454,14 +462,14 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
                 "multiprocessing_pool": pooled}
     ms = tm.ms(lambda: cabi.check(lib.pdc_aov_scan_dev(dev, stream, bt5.ptr, bx.ptr, n, bp.ptr, n_per, 10, bth.ptr)),
                reps=3)
-    fr, _ = two_fracs("pdm_scan_kernel<256, 4, false, 1>", ms, pdm_algorithmic_frac(pairs, ms), "40 flop/pair vs 78.6 TFLOP/s")
+    fr, _ = two_fracs(("pdm_scan_kernel<", ", 1> grid"), ms, pdm_algorithmic_frac(pairs, ms), "40 flop/pair vs 78.6 TFLOP/s")
     out["c5_aov"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), "n_bins": 10, **fr}
     lo5, hi5 = y5.min(), y5.max()
     mag = np.minimum(np.floor((y5 - lo5) / (hi5 - lo5) * 5), 4).astype(np.float64)
     bmag = DB.from_array(mag, dev)
     ms = tm.ms(lambda: cabi.check(lib.pdc_cond_entropy_scan_dev(dev, stream, bt5.ptr, bmag.ptr, n, bp.ptr, n_per,
                                                                 10, 5, bth.ptr)), reps=3)
-    fr, _ = two_fracs("pdm_scan_kernel<256, 4, false, 2>", ms, pdm_algorithmic_frac(pairs, ms), "40 flop/pair vs 78.6 TFLOP/s")
+    fr, _ = two_fracs(("pdm_scan_kernel<", ", 2> grid"), ms, pdm_algorithmic_frac(pairs, ms), "40 flop/pair vs 78.6 TFLOP/s")
     out["c5_cond_entropy"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), "cells": "10 x 5", **fr}
     for b in (bt5, bx, bp, bth, bm, bsp, be, swork, bmag):
         b.free()

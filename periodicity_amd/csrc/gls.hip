@@ -614,7 +614,12 @@ __global__ __launch_bounds__(kBlock) void gls_finish_kernel(GlsArgs a, int parts
 // 128 pair-curves it can hold with 6 of 8 outputs useful; the 96 v_fma_f64 it replaces take 48.)
 constexpr int kShBlock = 1024;
 constexpr int kShWaves = kShBlock / 64;
-constexpr int kShChunk = 32;
+// samples per LDS tile (48 and 64 - fewer fill phases and barriers - measured 2-3 % SLOWER with individual
+// weights, equal within noise with equal weights: the barriers are not what the kernel waits for)
+#ifndef PDC_SH_CHUNK
+#define PDC_SH_CHUNK 32
+#endif
+constexpr int kShChunk = PDC_SH_CHUNK;
 constexpr int kShCurvesW = 8;   // curves per wave, individual weights (48 accumulators)
 constexpr int kShCurvesU = 16;  // curves per wave, equal weights (32 + 4 accumulators)
 

@@ -715,6 +715,13 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
 //   P3b/P3c  deferred ranges and the links between ranges, as above.
 namespace fast {
 
+// samples per software-pipelined group in P1 (loads + folds) and P2 (rank atomics + index stores)
+#ifndef PDC_SL_G1
+#define PDC_SL_G1 4
+#endif
+#ifndef PDC_SL_G2
+#define PDC_SL_G2 4
+#endif
 constexpr int kNB = kBuckets;
 constexpr int kFWin = 216;             // sorted positions per range window (a range = window + < one bucket)
 constexpr int kFCap = 255;             // samples a wave ranks by itself: counts and starts fit in bytes
@@ -950,30 +957,38 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         unsigned pk[(KMAX + 1) / 2];
 #pragma unroll
         for (int k = 0; k < (KMAX + 1) / 2; ++k) pk[k] = 0u;
-        // (groups of four coalesced loads, the next group requested before the current one is folded;
+        // (groups of G1 coalesced loads, the next group requested before the current one is folded;
         // the scheduling barrier keeps the compiler from hoisting all <= 52 loads to the top)
-        double tv[4], tn[4];
+        constexpr int G1 = PDC_SL_G1, G2 = PDC_SL_G2;
+        static_assert(G1 % 4 == 0, "phases are computed four at a time");
+        double tv[G1], tn[G1];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < G1; ++u) {
             const int i = u * kBlock + tid;
             tn[u] = a.t[i < n ? i : n - 1];
         }
 #pragma unroll
-        for (int k0 = 0; k0 < KMAX; k0 += 4) {
+        for (int k0 = 0; k0 < KMAX; k0 += G1) {
             if (k0 * kBlock < n) {   // workgroup-uniform
 #pragma unroll
-                for (int u = 0; u < 4; ++u) tv[u] = tn[u];
-                if (k0 + 4 < KMAX && (k0 + 4) * kBlock < n) {
+                for (int u = 0; u < G1; ++u) tv[u] = tn[u];
+                if (k0 + G1 < KMAX && (k0 + G1) * kBlock < n) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = (k0 + 4 + u) * kBlock + tid;
-                        tn[u] = a.t[i < n ? i : n - 1];
+                    for (int u = 0; u < G1; ++u) {
+                        const int i = (k0 + G1 + u) * kBlock + tid;
+                        if (k0 + G1 + u < KMAX) tn[u] = a.t[i < n ? i : n - 1];
                     }
                 }
-                double phi[4];
-                phases4(tv, period, y, safe, phi);
+                double phi[G1];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int q = 0; q < G1; q += 4) {
+                    double t4[4] = {tv[q], tv[q + 1], tv[q + 2], tv[q + 3]}, p4[4];
+                    phases4(t4, period, y, safe, p4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) phi[q + u] = p4[u];
+                }
+#pragma unroll
+                for (int u = 0; u < G1; ++u) {
                     if (k0 + u < KMAX) {
                         const int i = (k0 + u) * kBlock + tid;
                         const int b = i < n ? coarse_of<NB>(phi[u]) : NB + lane;
@@ -989,18 +1004,18 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
 
         // ---- P2: the permutation, grouped by coarse bucket ----------------------------------------
 #pragma unroll
-        for (int k0 = 0; k0 < KMAX; k0 += 4) {
+        for (int k0 = 0; k0 < KMAX; k0 += G2) {
             if (k0 * kBlock < n) {   // workgroup-uniform
-                unsigned pos[4];
+                unsigned pos[G2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < G2; ++u) {
                     if (k0 + u < KMAX) {
                         const unsigned b = (pk[(k0 + u) >> 1] >> (((k0 + u) & 1) * 16)) & 0xFFFFu;
                         pos[u] = atomicAdd(&hist[b], 1u);
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < G2; ++u) {
                     if (k0 + u < KMAX) {
                         const int i = (k0 + u) * kBlock + tid;
                         order[i < n ? pos[u] : (unsigned)(n + lane)] = (IdxT)i;

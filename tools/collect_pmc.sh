@@ -23,6 +23,6 @@ rocprofv3 --kernel-trace --stats -d "$out/stats" -o run --output-format csv -- p
 # the headline workload alone, 20 timed steps + 3 warm-up, so that the statistics of gls_scan_kernel are
 # the C2 launch's; the bench line of THIS run (same lease, same process) is kept beside the trace
 rocprofv3 --kernel-trace --stats -d "$out/stats_c2" -o run --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > "$out/stats_c2.log" 2>&1
-tail -1 "$out/stats_c2.log" > "$out/bench_under_kernel_trace.json"
+grep '^{"metric"' "$out/stats_c2.log" | tail -1 > "$out/bench_under_kernel_trace.json"
 python3 tools/kernel_median.py "$out/stats_c2/run_kernel_trace.csv" "$out/bench_c2_kernel_median.json"
 python3 tools/pmc_summary.py "$out" --out "$out/pmc_summary.json" --command "rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py $args"
