@@ -715,6 +715,8 @@ def main():
                     help="take the torch.distributed path even with one rank (testing)")
     ap.add_argument("--force-plan", action="store_true",
                     help="take the one-process multi-device plan path even with one GPU (testing)")
+    ap.add_argument("--force-sharded-extras", action="store_true",
+                    help="run the N > 1 extras even with one rank / one slot (testing)")
     ap.add_argument("--loopback", type=int, default=0, metavar="N",
                     help="N logical slots on ONE device through the plan path (testing the N > 1 code on a 1-GPU box); "
                          "the all-gather runs as device-to-device copies; `value` is not a scaling figure")
@@ -889,11 +891,16 @@ def main():
     kernel_s = float(np.median(kernel_all_ms)) / 1e3
 
     sharded = None
-    if n_slots > 1 and not args.no_extras:
-        if dist_mode:
-            sharded = sharded_extras_dist(_cabi, lib, torch, dist, dev, rank, world)
-        else:
-            sharded = sharded_extras_one_process(_cabi, lib, [0] * loopback if loopback else list(range(args.gpus)))
+    if (n_slots > 1 or args.force_sharded_extras) and not args.no_extras:
+        # (informational: a failure here must not cost the headline line - every rank runs the same code, so an
+        # exception raised before a collective is raised on all of them)
+        try:
+            if dist_mode:
+                sharded = sharded_extras_dist(_cabi, lib, torch, dist, dev, rank, world)
+            else:
+                sharded = sharded_extras_one_process(_cabi, lib, [0] * loopback if loopback else list(range(args.gpus)))
+        except Exception as exc:
+            sharded = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         if plan_mode:
