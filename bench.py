@@ -111,7 +111,7 @@ def c5_inputs():
 KERNEL_SOURCES = {
     "gls_": ("gls.hip", "gls_epilogue.h", "pdc_device.h"),
     "pdm_": ("pdm.hip", "pdc_device.h"),
-    "sl_": ("stringlength.hip", "pdc_device.h"),
+    "sl_": ("stringlength.hip", "sl_ranges.inc", "pdc_device.h"),
     "fft_": ("glsfft.hip", "pdc_device.h"),
     "glsfft_": ("glsfft.hip", "gls_epilogue.h", "pdc_device.h"),
     "peak": ("peaks.hip", "pdc_device.h"),
@@ -126,7 +126,7 @@ def source_hashes():
     """sha256 (first 16 hex digits) of every kernel source; tools/pmc_summary.py stores the same."""
     src = os.path.join(ROOT, "periodicity_amd", "csrc")
     return {name: file_sha(os.path.join(src, name))
-            for name in sorted(os.listdir(src)) if name.endswith((".hip", ".h"))}
+            for name in sorted(os.listdir(src)) if name.endswith((".hip", ".h", ".inc"))}
 
 
 def sources_of(kernel_name):

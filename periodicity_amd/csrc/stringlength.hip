@@ -1178,218 +1178,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         __syncthreads();   // (the histogram is dead from here on: its LDS becomes wave scratch)
 
         // ---- P3a: wave-autonomous ranges -------------------------------------------------------------
-        // records of range r (requested one range ahead of their use)
-        int n_cnt = 0, n_slo = 0, n_lob = 0, n_hib = 0;
-        unsigned n_idx[kRPer];
-        rec_t n_rec[kRPer];
-        auto request = [&](int r) {
-            n_lob = __builtin_amdgcn_readfirstlane((int)bndb[r]);
-            n_hib = __builtin_amdgcn_readfirstlane((int)bndb[r + 1]);
-            n_slo = __builtin_amdgcn_readfirstlane((int)bnds[r]);
-            n_cnt = __builtin_amdgcn_readfirstlane((int)bnds[r + 1]) - n_slo;
-            if (n_cnt > 0 && n_cnt <= kFCap) {
-#pragma unroll
-                for (int e = 0; e < kRPer; ++e) {
-                    const int s = lane + e * 64;
-                    n_idx[e] = (unsigned)order[n_slo + (s < n_cnt ? s : 0)];
-                }
-#pragma unroll
-                for (int e = 0; e < kRPer; ++e) n_rec[e] = a.rec[n_idx[e]];
-            }
-        };
-        unsigned *fine32 = fine_w;                                          // [kFine / 4] packed counters
-        unsigned char *fine8 = reinterpret_cast<unsigned char *>(fine_w);   // [kFine + 1] starts
-        // One range, ranked and summed by this wave.  ROWS3: the first three rows of 64 are known to be
-        // full (cnt > 192, the usual case with 216-position windows), so only the last row carries the
-        // dead-lane selects; the generic instance serves short ranges (the last one of a period,
-        // sparse phases).
-        int r_next = nranges;
-        auto process = [&](const int r, auto rows3_tag) {
-            constexpr bool ROWS3 = decltype(rows3_tag)::value;
-            const int cnt = n_cnt, lo_b = n_lob, hi_b = n_hib;
-            // the range after this one is handed out dynamically (waves that draw short or deferred ranges
-            // take more of them); the ticket is drawn now and used when the request goes out
-            unsigned ticket = 0u;
-            if (lane == 0) ticket = atomicAdd(&defer[15], 1u);
-            if (cnt <= 0 || cnt > kFCap) {
-                if (lane == 0) {
-                    if (cnt <= 0) rcnt[r_base + r] = 0;
-                    else atomicOr(&defer[r >> 5], 1u << (r & 31));
-                }
-                r_next = __builtin_amdgcn_readfirstlane((int)ticket);
-                if (r_next < nranges) request(r_next);
-                return;
-            }
-            // Lanes past the range's end ("dead", only in its last row) are not branched around: they
-            // add 0 to a counter word of their own, park in the free slot lane + 64 e >= cnt, and their
-            // segment is masked out.
-            // Monotone map of the range's phases [lo_b, hi_b) / kNB onto kFine fine buckets: one fma
-            // with a positive multiplier (any monotone map keeps the sort exact; mean occupancy ~0.2).
-            // (the scale only has to be positive and keep the map inside [0, kFine): a float reciprocal
-            // is plenty; indices are clamped anyway)
-            const double fsc = (double)((float)(kFine - 1) * __builtin_amdgcn_rcpf((float)(hi_b - lo_b)));
-            const double fmul = (double)NB * fsc, fadd = -(double)lo_b * fsc;
-            reinterpret_cast<uint4 *>(fine32)[lane] = make_uint4(0u, 0u, 0u, 0u);
-            if (lane < 4) fine32[kFine / 4 + lane] = 0u;
-            wave_sync();
-            double et[kRPer], em[kRPer], ephi[kRPer];
-            unsigned ei[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                et[e] = n_rec[e].x;
-                em[e] = n_rec[e].y;
-                ei[e] = n_idx[e];
-            }
-            phases4(et, period, y, safe, ephi);
-            unsigned er[kRPer];
-            int ef[kRPer];
-            bool live[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                live[e] = (ROWS3 && e < 3) ? true : lane + e * 64 < cnt;
-                const double phi = ephi[e];
-                int fb = (int)__builtin_fma(phi, fmul, fadd);
-                fb = fb < 0 ? 0 : (fb > kFine - 1 ? kFine - 1 : fb);
-                fb = phi == phi ? fb : kFine - 1;
-                // one bit pattern for every NaN phase: the sort key is the pattern itself
-                ephi[e] = __longlong_as_double((long long)phase_key(phi));
-                ef[e] = fb;
-                const unsigned esh = ((unsigned)fb & 3u) * 8u;
-                const unsigned old = atomicAdd(&fine32[live[e] ? fb >> 2 : lane], live[e] ? 1u << esh : 0u);
-                er[e] = (old >> esh) & 0xFFu;
-            }
-#define EK(e) ((unsigned long long)__double_as_longlong(ephi[e]))
-            // the records of the next range go out now: t[] and the indices of this one are consumed
-            r_next = __builtin_amdgcn_readfirstlane((int)ticket);
-            if (r_next < nranges) request(r_next);
-            unsigned mx = 0;
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                const unsigned v = live[e] ? er[e] : 0u;
-                mx = v > mx ? v : mx;
-            }
-            const int mxu = (int)wave_max_u32(mx) + 1;   // members of the fullest fine bucket
-            if (mxu > kWInsertMax) {
-                if (lane == 0) atomicOr(&defer[r >> 5], 1u << (r & 31));
-                return;
-            }
-            wave_sync();
-            // exclusive scan of the kFine byte counters (sixteen per lane); every start is <= cnt <= 255
-            {
-                const uint4 cv = reinterpret_cast<uint4 *>(fine32)[lane];
-                unsigned w[4] = {cv.x, cv.y, cv.z, cv.w}, x[4], tot[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    x[q] = w[q] + (w[q] << 8);
-                    x[q] += x[q] << 16;            // inclusive prefix of the four bytes (no carries)
-                    tot[q] = x[q] >> 24;
-                }
-                const unsigned lane_tot = (tot[0] + tot[1]) + (tot[2] + tot[3]);
-                const unsigned incl = wave_scan_add(lane_tot);
-                unsigned base = incl - lane_tot;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    x[q] = (x[q] - w[q]) + __builtin_amdgcn_perm(base, base, 0u);   // + base in every byte
-                    base += tot[q];
-                }
-                reinterpret_cast<uint4 *>(fine32)[lane] = make_uint4(x[0], x[1], x[2], x[3]);
-                if (lane == 63) fine32[kFine / 4] = incl;  // == cnt: the start behind the last bucket
-            }
-            wave_sync();
-            // park the members of every fine bucket in arrival order, then count, per sample, the OTHER
-            // members that sort before it (a wave-uniform loop over the fullest bucket's others)
-            unsigned eb0[kRPer], ec[kRPer], park[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                eb0[e] = fine8[ef[e]];
-                ec[e] = fine8[ef[e] + 1];
-            }
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                ec[e] = live[e] ? ec[e] - eb0[e] : 0u;
-                park[e] = live[e] ? eb0[e] + er[e] : (unsigned)(lane + e * 64);
-                keys_w[park[e]] = EK(e);
-                idx_w[park[e]] = (IdxT)ei[e];
-            }
-            wave_sync();
-            unsigned before[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) before[e] = 0u;
-            for (int j = 1; j < mxu; ++j) {
-                unsigned long long ky[kRPer];
-                unsigned oth[kRPer];
-                bool tie = false;
-#pragma unroll
-                for (int e = 0; e < kRPer; ++e) {
-                    const bool in = (unsigned)j < ec[e];
-                    unsigned o = er[e] + (unsigned)j;          // the j-th other member, cyclically
-                    o = o >= ec[e] ? o - ec[e] : o;
-                    oth[e] = in ? eb0[e] + o : park[e];
-                    ky[e] = keys_w[oth[e]];
-                    before[e] += (in && ky[e] < EK(e)) ? 1u : 0u;
-                    tie = tie || (in && ky[e] == EK(e));
-                }
-                if (__any(tie)) {  // equal phases of two different samples (rare): the index decides
-#pragma unroll
-                    for (int e = 0; e < kRPer; ++e) {
-                        const bool in = (unsigned)j < ec[e];
-                        if (in && ky[e] == EK(e) && (unsigned)idx_w[oth[e]] < ei[e]) ++before[e];
-                    }
-                }
-            }
-            wave_sync();
-#undef EK
-            // every sample writes its phase, then its m, to its final slot; lane j reads slot j back (the
-            // 2 KB key array serves both in turn), so the segments are summed in sorted order whatever
-            // order the atomics of P2 delivered the samples in: the result does not depend on timing
-            unsigned fs[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                fs[e] = live[e] ? eb0[e] + before[e] : (unsigned)(lane + e * 64);
-                keys_w[fs[e]] = (unsigned long long)__double_as_longlong(ephi[e]);
-            }
-            wave_sync();
-            double sphi[kRPer], sm[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) sphi[e] = __longlong_as_double((long long)keys_w[lane + e * 64]);
-            wave_sync();
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) keys_w[fs[e]] = (unsigned long long)__double_as_longlong(em[e]);
-            wave_sync();
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) sm[e] = __longlong_as_double((long long)keys_w[lane + e * 64]);
-            // the predecessor of lane j's point sits in lane j - 1 (one DPP shift per half); lane 0 takes
-            // lane 63 of the previous row, carried as a wave-uniform pair
-            double carry_phi = 0.0, carry_m = 0.0, last_phi = 0.0, last_m = 0.0, inside = 0.0;
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                const int j = lane + e * 64;
-                const double phi = sphi[e], mm = sm[e];
-                const double pphi = lane_below(phi, carry_phi), pm = lane_below(mm, carry_m);
-                const double seg = short_hypot(mm - pm, phi - pphi);
-                inside += (live[e] && j > 0) ? seg : 0.0;
-                carry_phi = read_lane(phi, 63);
-                carry_m = read_lane(mm, 63);
-                if (e == ((cnt - 1) >> 6)) {  // wave-uniform: the row that holds the range's last point
-                    last_phi = read_lane(phi, (cnt - 1) & 63);
-                    last_m = read_lane(mm, (cnt - 1) & 63);
-                }
-            }
-            // the range's own length, lanes added in a fixed order: ranges are handed out dynamically, so
-            // the per-range sums (added up in range order in P3c), not per-lane running sums, keep the
-            // result independent of timing
-            inside = wave_sum_fixed(inside);
-            if (lane == 0) {
-                const int64_t g = r_base + r;
-                rsum[g * 4 + 0] = sphi[0];
-                rsum[g * 4 + 1] = sm[0];
-                rsum[g * 4 + 2] = last_phi;
-                rsum[g * 4 + 3] = last_m;
-                rcnt[g] = cnt;
-                rlen[g] = inside;
-            }
-            wave_sync();
-        };
+#include "sl_ranges.inc"
         if (wave < nranges) request(wave);
         for (int r = wave; r < nranges; r = r_next) {
             if (n_cnt > 192) process(r, std::true_type{});
@@ -1692,191 +1481,10 @@ __global__ __launch_bounds__(kB, 4) void sl_duo_kernel(DuoArgs a) {
         }
         __syncthreads();   // (the histogram is dead from here on: its LDS becomes wave scratch)
 
-        // ---- P3a: wave-autonomous ranges (sl_fast_kernel's, with this workgroup's 8 waves) ---------------
-        int n_cnt = 0, n_slo = 0, n_lob = 0, n_hib = 0;
-        unsigned n_idx[kRPer];
-        rec_t n_rec[kRPer];
-        auto request = [&](int r) {
-            n_lob = __builtin_amdgcn_readfirstlane((int)bndb[r]);
-            n_hib = __builtin_amdgcn_readfirstlane((int)bndb[r + 1]);
-            n_slo = __builtin_amdgcn_readfirstlane((int)bnds[r]);
-            n_cnt = __builtin_amdgcn_readfirstlane((int)bnds[r + 1]) - n_slo;
-            if (n_cnt > 0 && n_cnt <= kFCap) {
-#pragma unroll
-                for (int e = 0; e < kRPer; ++e) {
-                    const int sI = lane + e * 64;
-                    n_idx[e] = (unsigned)order[n_slo + (sI < n_cnt ? sI : 0)];
-                }
-#pragma unroll
-                for (int e = 0; e < kRPer; ++e) n_rec[e] = a.rec[n_idx[e]];
-            }
-        };
-        unsigned *fine32 = fine_w;
-        unsigned char *fine8 = reinterpret_cast<unsigned char *>(fine_w);
-        int r_next = nranges;
-        auto process = [&](const int r, auto rows3_tag) {
-            constexpr bool ROWS3 = decltype(rows3_tag)::value;
-            const int cnt = n_cnt, lo_b = n_lob, hi_b = n_hib;
-            unsigned ticket = 0u;
-            if (lane == 0) ticket = atomicAdd(&defer[15], 1u);
-            if (cnt <= 0 || cnt > kFCap) {
-                if (lane == 0) {
-                    if (cnt <= 0) rcnt[r] = 0;
-                    else atomicOr(&defer[r >> 5], 1u << (r & 31));
-                }
-                r_next = __builtin_amdgcn_readfirstlane((int)ticket);
-                if (r_next < nranges) request(r_next);
-                return;
-            }
-            const double fsc = (double)((float)(kFine - 1) * __builtin_amdgcn_rcpf((float)(hi_b - lo_b)));
-            const double fmul = (double)kNB * fsc, fadd = -(double)lo_b * fsc;
-            reinterpret_cast<uint4 *>(fine32)[lane] = make_uint4(0u, 0u, 0u, 0u);
-            if (lane < 4) fine32[kFine / 4 + lane] = 0u;
-            wave_sync();
-            double et[kRPer], em[kRPer], ephi[kRPer];
-            unsigned ei[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                et[e] = n_rec[e].x;
-                em[e] = n_rec[e].y;
-                ei[e] = n_idx[e];
-            }
-            phases4(et, period, y, safe, ephi);
-            unsigned er[kRPer];
-            int ef[kRPer];
-            bool live[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                live[e] = (ROWS3 && e < 3) ? true : lane + e * 64 < cnt;
-                const double phi = ephi[e];
-                int fb = (int)__builtin_fma(phi, fmul, fadd);
-                fb = fb < 0 ? 0 : (fb > kFine - 1 ? kFine - 1 : fb);
-                fb = phi == phi ? fb : kFine - 1;
-                ephi[e] = __longlong_as_double((long long)phase_key(phi));
-                ef[e] = fb;
-                const unsigned esh = ((unsigned)fb & 3u) * 8u;
-                const unsigned old = atomicAdd(&fine32[live[e] ? fb >> 2 : lane], live[e] ? 1u << esh : 0u);
-                er[e] = (old >> esh) & 0xFFu;
-            }
-#define EK(e) ((unsigned long long)__double_as_longlong(ephi[e]))
-            r_next = __builtin_amdgcn_readfirstlane((int)ticket);
-            if (r_next < nranges) request(r_next);
-            unsigned mx = 0;
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                const unsigned v = live[e] ? er[e] : 0u;
-                mx = v > mx ? v : mx;
-            }
-            const int mxu = (int)wave_max_u32(mx) + 1;
-            if (mxu > kWInsertMax) {
-                if (lane == 0) atomicOr(&defer[r >> 5], 1u << (r & 31));
-                return;
-            }
-            wave_sync();
-            {
-                const uint4 cv = reinterpret_cast<uint4 *>(fine32)[lane];
-                unsigned w[4] = {cv.x, cv.y, cv.z, cv.w}, x[4], tot[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    x[q] = w[q] + (w[q] << 8);
-                    x[q] += x[q] << 16;
-                    tot[q] = x[q] >> 24;
-                }
-                const unsigned lane_tot = (tot[0] + tot[1]) + (tot[2] + tot[3]);
-                const unsigned incl = wave_scan_add(lane_tot);
-                unsigned base = incl - lane_tot;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    x[q] = (x[q] - w[q]) + __builtin_amdgcn_perm(base, base, 0u);
-                    base += tot[q];
-                }
-                reinterpret_cast<uint4 *>(fine32)[lane] = make_uint4(x[0], x[1], x[2], x[3]);
-                if (lane == 63) fine32[kFine / 4] = incl;
-            }
-            wave_sync();
-            unsigned eb0[kRPer], ec[kRPer], park[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                eb0[e] = fine8[ef[e]];
-                ec[e] = fine8[ef[e] + 1];
-            }
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                ec[e] = live[e] ? ec[e] - eb0[e] : 0u;
-                park[e] = live[e] ? eb0[e] + er[e] : (unsigned)(lane + e * 64);
-                keys_w[park[e]] = EK(e);
-                idx_w[park[e]] = (IdxT)ei[e];
-            }
-            wave_sync();
-            unsigned before[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) before[e] = 0u;
-            for (int j = 1; j < mxu; ++j) {
-                unsigned long long ky[kRPer];
-                unsigned oth[kRPer];
-                bool tie = false;
-#pragma unroll
-                for (int e = 0; e < kRPer; ++e) {
-                    const bool in = (unsigned)j < ec[e];
-                    unsigned o = er[e] + (unsigned)j;
-                    o = o >= ec[e] ? o - ec[e] : o;
-                    oth[e] = in ? eb0[e] + o : park[e];
-                    ky[e] = keys_w[oth[e]];
-                    before[e] += (in && ky[e] < EK(e)) ? 1u : 0u;
-                    tie = tie || (in && ky[e] == EK(e));
-                }
-                if (__any(tie)) {
-#pragma unroll
-                    for (int e = 0; e < kRPer; ++e) {
-                        const bool in = (unsigned)j < ec[e];
-                        if (in && ky[e] == EK(e) && (unsigned)idx_w[oth[e]] < ei[e]) ++before[e];
-                    }
-                }
-            }
-            wave_sync();
-#undef EK
-            unsigned fs[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                fs[e] = live[e] ? eb0[e] + before[e] : (unsigned)(lane + e * 64);
-                keys_w[fs[e]] = (unsigned long long)__double_as_longlong(ephi[e]);
-            }
-            wave_sync();
-            double sphi[kRPer], sm[kRPer];
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) sphi[e] = __longlong_as_double((long long)keys_w[lane + e * 64]);
-            wave_sync();
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) keys_w[fs[e]] = (unsigned long long)__double_as_longlong(em[e]);
-            wave_sync();
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) sm[e] = __longlong_as_double((long long)keys_w[lane + e * 64]);
-            double carry_phi = 0.0, carry_m = 0.0, last_phi = 0.0, last_m = 0.0, inside = 0.0;
-#pragma unroll
-            for (int e = 0; e < kRPer; ++e) {
-                const int j = lane + e * 64;
-                const double phi = sphi[e], mm = sm[e];
-                const double pphi = lane_below(phi, carry_phi), pm = lane_below(mm, carry_m);
-                const double seg = short_hypot(mm - pm, phi - pphi);
-                inside += (live[e] && j > 0) ? seg : 0.0;
-                carry_phi = read_lane(phi, 63);
-                carry_m = read_lane(mm, 63);
-                if (e == ((cnt - 1) >> 6)) {
-                    last_phi = read_lane(phi, (cnt - 1) & 63);
-                    last_m = read_lane(mm, (cnt - 1) & 63);
-                }
-            }
-            inside = wave_sum_fixed(inside);
-            if (lane == 0) {
-                rsum[(int64_t)r * 4 + 0] = sphi[0];
-                rsum[(int64_t)r * 4 + 1] = sm[0];
-                rsum[(int64_t)r * 4 + 2] = last_phi;
-                rsum[(int64_t)r * 4 + 3] = last_m;
-                rcnt[r] = cnt;
-                rlen[r] = inside;
-            }
-            wave_sync();
-        };
+        // ---- P3a: wave-autonomous ranges (the same code as sl_fast_kernel's, on this workgroup's 8 waves) --
+        constexpr int NB = kNB;
+        const int r_base = 0;
+#include "sl_ranges.inc"
         if (wave < nranges) request(wave);
         for (int r = wave; r < nranges; r = r_next) {
             if (n_cnt > 192) process(r, std::true_type{});
