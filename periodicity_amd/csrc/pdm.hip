@@ -40,7 +40,8 @@ namespace {
 constexpr int kChunk = PDC_PDM_CHUNK;
 
 constexpr int kStatParts = 512;  // partial sums of the sample statistics (split mode)
-constexpr int kSlots = 1024;     // resident workgroups of the scan kernel on an MI355X: 256 CUs x 4 (38 KB of LDS each)
+constexpr int kCUs = 256;        // MI355X
+constexpr int kLdsPerCU = 163840;
 
 struct PdmArgs {
     const double *t, *x, *periods;
@@ -97,11 +98,11 @@ __global__ __launch_bounds__(256) void pdm_stats_kernel(PdmArgs a, int pass) {
     double acc = 0.0, tmax = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
         if (pass == 0) {
-            acc += a.x[i];
+            acc += a.x ? a.x[i] : 0.0;
             const double at = __builtin_fabs(a.t[i]);
             tmax = at > tmax ? at : tmax;
         } else {
-            const double d = a.x[i] - mean;
+            const double d = (a.x ? a.x[i] : 0.0) - mean;
             acc += d * d;
         }
     }
@@ -436,11 +437,13 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     if (ZS) {  // split mode: leave the histogram of this slice of the samples for pdm_finish_kernel
         const int64_t z = blockIdx.y;
         for (int k = 0; k < nbins; ++k) {
-            a.psum[(z * nbins + k) * a.p_pad + pidx] = hsum[k * BLOCK + tid];
+            if (!CE) a.psum[(z * nbins + k) * a.p_pad + pidx] = hsum[k * BLOCK + tid];
             a.pcnt[(z * nbins + k) * a.p_pad + pidx] = hcnt[k * BLOCK + tid];
         }
-        a.pq[(z * 2 + 0) * a.p_pad + pidx] = q_over;
-        a.pq[(z * 2 + 1) * a.p_pad + pidx] = q_nan;
+        if (!CE) {
+            a.pq[(z * 2 + 0) * a.p_pad + pidx] = q_over;
+            a.pq[(z * 2 + 1) * a.p_pad + pidx] = q_nan;
+        }
         return;
     }
     auto sum_at = [&](int b) { return hsum[b * BLOCK + tid]; };
@@ -456,7 +459,9 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
 __global__ __launch_bounds__(64) void pdm_finish_kernel(PdmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __shared__ double red[1];
-    const int m0 = a.nb * a.nc, nbins = m0 + 1, tid = threadIdx.x;
+    const bool counts_only = a.kind == 2 || a.kind == 4;
+    const int m0 = counts_only ? a.nb : a.nb * a.nc;
+    const int nbins = a.kind == 2 ? (a.nb + 1) * a.nc : m0 + 1, tid = threadIdx.x;
     double *hsum = reinterpret_cast<double *>(lds_raw);                     // [nbins][64]
     long long *hcnt = reinterpret_cast<long long *>(hsum + (size_t)nbins * 64);  // [nbins][64]
     const double q_total = fold_parts<64>(a.stat + 2 * kStatParts, a.n_stat, red, false);
@@ -467,19 +472,21 @@ __global__ __launch_bounds__(64) void pdm_finish_kernel(PdmArgs a) {
         double sum = 0.0;
         long long cnt = 0;
         for (int64_t z = 0; z < a.n_z; ++z) {
-            sum += a.psum[(z * nbins + k) * a.p_pad + pidx];
+            if (!counts_only) sum += a.psum[(z * nbins + k) * a.p_pad + pidx];
             cnt += a.pcnt[(z * nbins + k) * a.p_pad + pidx];
         }
         hsum[k * 64 + tid] = sum;
         hcnt[k * 64 + tid] = cnt;
     }
-    for (int64_t z = 0; z < a.n_z; ++z) {
+    for (int64_t z = 0; z < a.n_z && !counts_only; ++z) {
         q_over += a.pq[(z * 2 + 0) * a.p_pad + pidx];
         q_nan += a.pq[(z * 2 + 1) * a.p_pad + pidx];
     }
     auto sum_at = [&](int b) { return hsum[b * 64 + tid]; };
     auto cnt_at = [&](int b) { return hcnt[b * 64 + tid]; };
-    if (a.kind == 1) a.theta[pidx] = aov_from_bins(sum_at, cnt_at, m0, q_total - q_nan);
+    if (a.kind == 4) a.theta[pidx] = gl_from_bins(cnt_at, m0, a.nc);
+    else if (a.kind == 2) a.theta[pidx] = ce_from_bins(cnt_at, m0, a.nc);
+    else if (a.kind == 1) a.theta[pidx] = aov_from_bins(sum_at, cnt_at, m0, q_total - q_nan);
     else a.theta[pidx] = theta_from_bins(sum_at, cnt_at, m0, a.nc, q_total, q_nan, q_over, a.sigma);
 }
 
@@ -510,7 +517,8 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
     const int last = kind == 2 ? (nb + 1) * nc - 1 : m0;
     const int nbins = last + 1;
     const int64_t groups0 = (n_periods + 63) / 64;
-    if (kind >= 2 || env_split == 0 || n_periods == 0 || n < 32 * kChunk || lds_bytes(last, 256) > 150 * 1024 ||
+    const bool counts_only = kind >= 2;
+    if (env_split == 0 || n_periods == 0 || n < 32 * kChunk || lds_bytes(last, 256, counts_only ? 4 : 12) > 150 * 1024 ||
         (size_t)nbins * 64 * 16 > 150 * 1024)
         return sh;
     const int64_t max_z = n / (8 * kChunk);
@@ -526,6 +534,10 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
         // grid by more than the split's own overhead (two statistics launches, partial histograms through
         // L2, the finishing launch).  PDC_PDM_NZ forces a value (experiments).
         static const int env_nz = [] { const char *e = getenv("PDC_PDM_NZ"); return e ? atoi(e) : 0; }();
+        // resident workgroups of the scan kernel: LDS-limited (PDM at nb x nc = 10: 38 KB -> 4 per CU, 1024 on
+        // the chip; the counts-only kinds with many cells hold fewer), at most 8 per CU (4 waves each)
+        const int64_t per_cu = kLdsPerCU / (int64_t)(lds_bytes(last, 256, counts_only ? 4 : 12) + 512);
+        const int64_t kSlots = kCUs * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
         auto rounds_filled = [&](int64_t w) { return (double)w / (double)((w + kSlots - 1) / kSlots * kSlots); };
         // the unsplit launch packs 64, 128 or 256 periods into a workgroup (phase_stat_dev below)
         const int64_t w_unsplit = groups0 >= 4096 ? (groups0 + 3) / 4 : (groups0 >= 2048 ? (groups0 + 1) / 2 : groups0);
@@ -548,8 +560,8 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
     sh.p_pad = groups0 * 64;
     sh.n_stat = (int)((n + 1023) / 1024 < kStatParts ? (n + 1023) / 1024 : kStatParts);
     sh.stat_b = (size_t)3 * kStatParts * 8;
-    sh.psum_b = (size_t)n_z * nbins * sh.p_pad * 8;
-    sh.pq_b = (size_t)n_z * 2 * sh.p_pad * 8;
+    sh.psum_b = counts_only ? 0 : (size_t)n_z * nbins * sh.p_pad * 8;
+    sh.pq_b = counts_only ? 0 : (size_t)n_z * 2 * sh.p_pad * 8;
     sh.pcnt_b = (size_t)n_z * nbins * sh.p_pad * 4;
     sh.bytes = (int64_t)(sh.stat_b + sh.psum_b + sh.pq_b + sh.pcnt_b);
     return sh;
@@ -593,8 +605,6 @@ int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t,
         a.n_z = (int)sh.n_z;
         a.z_len = sh.z_len;
         a.n_stat = sh.n_stat;
-        PDC_TRY(allow_lds(pdm_scan_kernel<256, 4, true, 0>));
-        PDC_TRY(allow_lds(pdm_scan_kernel<256, 4, true, 1>));
         PDC_TRY(allow_lds(pdm_finish_kernel));
         void *spv = work;
         if (work) {
@@ -614,14 +624,19 @@ int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t,
         a.pcnt = reinterpret_cast<unsigned *>(sp + sh.stat_b + sh.psum_b + sh.pq_b);
         hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 0);
         hipLaunchKernelGGL(pdm_stats_kernel, dim3((unsigned)a.n_stat), dim3(256), 0, st, a, 1);
-        // (the statistic only matters to the finishing launch; it is a template argument here so that a
-        // profile tells the PDM launches from the AoV ones)
-        if (kind == 1)
-            hipLaunchKernelGGL((pdm_scan_kernel<256, 4, true, 1>), dim3((unsigned)groups0, (unsigned)sh.n_z), dim3(256),
-                               lds_bytes(last, 256), st, a);
-        else
-            hipLaunchKernelGGL((pdm_scan_kernel<256, 4, true, 0>), dim3((unsigned)groups0, (unsigned)sh.n_z), dim3(256),
-                               lds_bytes(last, 256), st, a);
+        // (the statistic only matters to the finishing launch - and, for the counts-only kinds, to what the
+        // histogram holds; it is a template argument so that a profile tells the launches apart)
+        const size_t zlds = lds_bytes(last, 256, kind >= 2 ? 4 : 12);
+        const dim3 zgrid((unsigned)groups0, (unsigned)sh.n_z);
+        auto zlaunch = [&](auto kernel) -> int {
+            PDC_TRY(allow_lds(kernel));
+            hipLaunchKernelGGL(kernel, zgrid, dim3(256), zlds, st, a);
+            return PDC_OK;
+        };
+        if (kind == 4) PDC_TRY(zlaunch(pdm_scan_kernel<256, 4, true, 4>));
+        else if (kind == 2) PDC_TRY(zlaunch(pdm_scan_kernel<256, 4, true, 2>));
+        else if (kind == 1) PDC_TRY(zlaunch(pdm_scan_kernel<256, 4, true, 1>));
+        else PDC_TRY(zlaunch(pdm_scan_kernel<256, 4, true, 0>));
         hipLaunchKernelGGL(pdm_finish_kernel, dim3((unsigned)groups0), dim3(64), (size_t)nbins * 64 * 16, st, a);
         PDC_HIP(hipGetLastError());
         return PDC_OK;
