@@ -259,16 +259,19 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     // the staging area doubles as the q_over/q_nan exchange ([2][BLOCK] doubles) at the end
     constexpr int kStage = kChunk > BLOCK ? kChunk : BLOCK;
     double *hsum = reinterpret_cast<double *>(stage + kStage);              // [nbins][BLOCK] (not with CE: counts only)
-    unsigned *hcnt = reinterpret_cast<unsigned *>(hsum + (CE ? 0 : (size_t)nbins * BLOCK));  // [nbins][BLOCK]
-    double *edge = reinterpret_cast<double *>(hcnt + (size_t)nbins * BLOCK);      // [m0 + 2]
+    // counts: one word per bin - or, for the counts-only kinds, two 16-bit cells per word (a thread's cells
+    // count at most the samples of its workgroup's slice, kept <= 65 280 by the launcher: the histogram of 55
+    // cells x 256 threads then takes 28 KB instead of 56, five workgroups per CU instead of two)
+    const int ncw = CE ? (nbins + 1) / 2 : nbins;                                  // count words per thread
+    unsigned *hcnt = reinterpret_cast<unsigned *>(hsum + (CE ? 0 : (size_t)nbins * BLOCK));  // [ncw][BLOCK]
+    double *edge = reinterpret_cast<double *>(hcnt + (size_t)ncw * BLOCK);         // [m0 + 2] (BLOCK words: 8-byte aligned)
     double *red = edge + m0 + 2;                                                  // [BLOCK/64]
     const int tid = threadIdx.x;
 
     for (int k = tid; k < m0 + 2; k += BLOCK) edge[k] = (double)k / (double)m0;  // Python's k / m0
-    for (int k = 0; k < nbins; ++k) {
+    for (int k = 0; k < nbins; ++k)
         if (!CE) hsum[k * BLOCK + tid] = 0.0;
-        hcnt[k * BLOCK + tid] = 0u;
-    }
+    for (int k = 0; k < ncw; ++k) hcnt[k * BLOCK + tid] = 0u;
 
     // mean of x, total sum of squares about it, and max |t| (identical in every workgroup)
     double mean, tmax, q_total;
@@ -356,7 +359,8 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         };
         auto add = [&](const int k, const double val, const unsigned inc) {
             if (CE) {   // val = the sample's magnitude bin (range-checked when staged); a NaN phase (inc == 0) counts nowhere
-                atomicAdd(&hcnt[(k * mag + (int)val) * BLOCK + tid], inc);
+                const int cell = k * mag + (int)val;
+                atomicAdd(&hcnt[(cell >> 1) * BLOCK + tid], inc << ((cell & 1) * 16));
             } else {
                 atomicAdd(&hsum[k * BLOCK + tid], val);
                 atomicAdd(&hcnt[k * BLOCK + tid], inc);
@@ -424,10 +428,9 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         if (part == 0) {
             for (int q = 1; q < SPLIT; ++q) {
                 const int other = tid + 64 * q;
-                for (int k = 0; k < nbins; ++k) {
+                for (int k = 0; k < nbins; ++k)
                     if (!CE) hsum[k * BLOCK + tid] += hsum[k * BLOCK + other];
-                    hcnt[k * BLOCK + tid] += hcnt[k * BLOCK + other];
-                }
+                for (int k = 0; k < ncw; ++k) hcnt[k * BLOCK + tid] += hcnt[k * BLOCK + other];   // (fields cannot carry)
                 q_over += qx[other];
                 q_nan += qx[BLOCK + other];
             }
@@ -436,10 +439,9 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
     if (part != 0 || pidx >= a.n_periods) return;
     if (ZS) {  // split mode: leave the histogram of this slice of the samples for pdm_finish_kernel
         const int64_t z = blockIdx.y;
-        for (int k = 0; k < nbins; ++k) {
+        for (int k = 0; k < nbins; ++k)
             if (!CE) a.psum[(z * nbins + k) * a.p_pad + pidx] = hsum[k * BLOCK + tid];
-            a.pcnt[(z * nbins + k) * a.p_pad + pidx] = hcnt[k * BLOCK + tid];
-        }
+        for (int k = 0; k < ncw; ++k) a.pcnt[(z * ncw + k) * a.p_pad + pidx] = hcnt[k * BLOCK + tid];
         if (!CE) {
             a.pq[(z * 2 + 0) * a.p_pad + pidx] = q_over;
             a.pq[(z * 2 + 1) * a.p_pad + pidx] = q_nan;
@@ -447,7 +449,9 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
         return;
     }
     auto sum_at = [&](int b) { return hsum[b * BLOCK + tid]; };
-    auto cnt_at = [&](int b) { return (long long)hcnt[b * BLOCK + tid]; };
+    auto cnt_at = [&](int b) {
+        return CE ? (long long)((hcnt[(b >> 1) * BLOCK + tid] >> ((b & 1) * 16)) & 0xFFFFu) : (long long)hcnt[b * BLOCK + tid];
+    };
     if (GL) a.theta[pidx] = gl_from_bins(cnt_at, m0, a.nc);
     else if (CE) a.theta[pidx] = ce_from_bins(cnt_at, m0, mag);
     else if (KIND == 1) a.theta[pidx] = aov_from_bins(sum_at, cnt_at, m0, q_total - q_nan);
@@ -462,17 +466,31 @@ __global__ __launch_bounds__(64) void pdm_finish_kernel(PdmArgs a) {
     const bool counts_only = a.kind == 2 || a.kind == 4;
     const int m0 = counts_only ? a.nb : a.nb * a.nc;
     const int nbins = a.kind == 2 ? (a.nb + 1) * a.nc : m0 + 1, tid = threadIdx.x;
-    double *hsum = reinterpret_cast<double *>(lds_raw);                     // [nbins][64]
-    long long *hcnt = reinterpret_cast<long long *>(hsum + (size_t)nbins * 64);  // [nbins][64]
+    // sums [nbins][64] then counts [nbins][64]; the counts-only kinds keep no sums
+    double *hsum = reinterpret_cast<double *>(lds_raw);
+    long long *hcnt = reinterpret_cast<long long *>(hsum + (counts_only ? 0 : (size_t)nbins * 64));
     const double q_total = fold_parts<64>(a.stat + 2 * kStatParts, a.n_stat, red, false);
     const int64_t pidx = (int64_t)blockIdx.x * 64 + tid;
     if (pidx >= a.n_periods) return;
     double q_over = 0.0, q_nan = 0.0;
-    for (int k = 0; k < nbins; ++k) {
+    if (counts_only) {   // two 16-bit cells per word in a slice's partial histogram; their sum over the slices is not
+        const int ncw = (nbins + 1) / 2;
+        for (int k = 0; k < ncw; ++k) {
+            long long lo = 0, hi = 0;
+            for (int64_t z = 0; z < a.n_z; ++z) {
+                const unsigned w = a.pcnt[(z * ncw + k) * a.p_pad + pidx];
+                lo += w & 0xFFFFu;
+                hi += w >> 16;
+            }
+            hcnt[(2 * k) * 64 + tid] = lo;
+            if (2 * k + 1 < nbins) hcnt[(2 * k + 1) * 64 + tid] = hi;
+        }
+    }
+    for (int k = 0; k < nbins && !counts_only; ++k) {
         double sum = 0.0;
         long long cnt = 0;
         for (int64_t z = 0; z < a.n_z; ++z) {
-            if (!counts_only) sum += a.psum[(z * nbins + k) * a.p_pad + pidx];
+            sum += a.psum[(z * nbins + k) * a.p_pad + pidx];
             cnt += a.pcnt[(z * nbins + k) * a.p_pad + pidx];
         }
         hsum[k * 64 + tid] = sum;
@@ -490,9 +508,12 @@ __global__ __launch_bounds__(64) void pdm_finish_kernel(PdmArgs a) {
     else a.theta[pidx] = theta_from_bins(sum_at, cnt_at, m0, a.nc, q_total, q_nan, q_over, a.sigma);
 }
 
-size_t lds_bytes(int m0, int block, int bytes_per_bin = 12) {   // 12: sum + count; 4: counts only (CE)
+// `last` = highest histogram bin; bytes_per_bin 12: sum + count, 4: counts only (two 16-bit cells per word)
+size_t lds_bytes(int last, int block, int bytes_per_bin = 12) {
     const size_t stage = (size_t)(kChunk > block ? kChunk : block) * 16;
-    return stage + (size_t)(m0 + 1) * block * bytes_per_bin + (size_t)(m0 + 2) * 8 + 64;
+    const size_t nbins = (size_t)last + 1;
+    const size_t hist = bytes_per_bin == 4 ? ((nbins + 1) / 2 + 1) * block * 4 : nbins * block * 12;
+    return stage + hist + (size_t)(last + 2) * 8 + 64;
 }
 
 // dynamic-LDS limit of a kernel, raised once per device (not on every call)
@@ -509,6 +530,8 @@ struct SplitShape {
     size_t stat_b = 0, psum_b = 0, pq_b = 0, pcnt_b = 0;
 };
 
+constexpr int64_t kCellSamples = 65280;   // samples a workgroup of a counts-only kind may bin: its cells are 16-bit
+
 SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
     static const int env_split = [] { const char *e = getenv("PDC_PDM_SPLIT"); return e ? atoi(e) : -1; }();
     SplitShape sh;
@@ -518,12 +541,18 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
     const int nbins = last + 1;
     const int64_t groups0 = (n_periods + 63) / 64;
     const bool counts_only = kind >= 2;
-    if (env_split == 0 || n_periods == 0 || n < 32 * kChunk || lds_bytes(last, 256, counts_only ? 4 : 12) > 150 * 1024 ||
-        (size_t)nbins * 64 * 16 > 150 * 1024)
-        return sh;
-    const int64_t max_z = n / (8 * kChunk);
-    int64_t n_z;
-    if (groups0 * 4 < 3072) {
+    // the counts-only kinds MUST cut more than kCellSamples samples into slices (16-bit cells); everything
+    // else about the split is a choice, which PDC_PDM_SPLIT=0 turns off
+    const int64_t must_z = counts_only ? (n + kCellSamples - 1) / kCellSamples : 1;
+    if (n_periods == 0 || n == 0) return sh;
+    const bool may = env_split != 0 && n >= 32 * kChunk && lds_bytes(last, 256, counts_only ? 4 : 12) <= 150 * 1024 &&
+                     (size_t)nbins * 64 * (counts_only ? 8 : 16) <= 150 * 1024;
+    if (!may && must_z <= 1) return sh;
+    const int64_t max_z = n / (8 * kChunk) > must_z ? n / (8 * kChunk) : must_z;
+    int64_t n_z = 1;
+    if (!may) {
+        n_z = must_z;
+    } else if (groups0 * 4 < 3072) {
         // (four workgroups of four waves fit a CU: below ~3000 waves the period grid alone leaves SIMD slots empty)
         n_z = (4096 + groups0 * 4 - 1) / (groups0 * 4);
     } else {
@@ -541,7 +570,6 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
         auto rounds_filled = [&](int64_t w) { return (double)w / (double)((w + kSlots - 1) / kSlots * kSlots); };
         // the unsplit launch packs 64, 128 or 256 periods into a workgroup (phase_stat_dev below)
         const int64_t w_unsplit = groups0 >= 4096 ? (groups0 + 3) / 4 : (groups0 >= 2048 ? (groups0 + 1) / 2 : groups0);
-        n_z = 1;
         double best = rounds_filled(w_unsplit);
         for (int64_t z = 2; z <= 8 && best < 0.9; ++z)
             if (rounds_filled(groups0 * z) > best + 0.05) {
@@ -551,8 +579,10 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
         if (env_nz > 0) n_z = env_nz;
     }
     n_z = n_z < max_z ? n_z : max_z;
+    n_z = n_z > must_z ? n_z : must_z;
     if (n_z <= 1) return sh;
-    const int64_t z_len = ((n + n_z - 1) / n_z + kChunk - 1) / kChunk * kChunk;
+    int64_t z_len = ((n + n_z - 1) / n_z + kChunk - 1) / kChunk * kChunk;
+    if (counts_only && z_len > kCellSamples) z_len = kCellSamples;   // (kCellSamples is a multiple of kChunk)
     n_z = (n + z_len - 1) / z_len;
     if (n_z <= 1) return sh;
     sh.n_z = n_z;
@@ -562,7 +592,7 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
     sh.stat_b = (size_t)3 * kStatParts * 8;
     sh.psum_b = counts_only ? 0 : (size_t)n_z * nbins * sh.p_pad * 8;
     sh.pq_b = counts_only ? 0 : (size_t)n_z * 2 * sh.p_pad * 8;
-    sh.pcnt_b = (size_t)n_z * nbins * sh.p_pad * 4;
+    sh.pcnt_b = (size_t)n_z * (counts_only ? (nbins + 1) / 2 : nbins) * sh.p_pad * 4;
     sh.bytes = (int64_t)(sh.stat_b + sh.psum_b + sh.pq_b + sh.pcnt_b);
     return sh;
 }
@@ -637,7 +667,7 @@ int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t,
         else if (kind == 2) PDC_TRY(zlaunch(pdm_scan_kernel<256, 4, true, 2>));
         else if (kind == 1) PDC_TRY(zlaunch(pdm_scan_kernel<256, 4, true, 1>));
         else PDC_TRY(zlaunch(pdm_scan_kernel<256, 4, true, 0>));
-        hipLaunchKernelGGL(pdm_finish_kernel, dim3((unsigned)groups0), dim3(64), (size_t)nbins * 64 * 16, st, a);
+        hipLaunchKernelGGL(pdm_finish_kernel, dim3((unsigned)groups0), dim3(64), (size_t)nbins * 64 * (kind >= 2 ? 8 : 16), st, a);
         PDC_HIP(hipGetLastError());
         return PDC_OK;
     }

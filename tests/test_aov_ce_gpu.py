@@ -163,3 +163,32 @@ def test_gregory_loredo_edges_devices_and_class():
     plan.scan("gregory_loredo", periods, 6 * 4, 6)
     assert np.array_equal(plan.download(), _cabi.gl_scan(t, periods, 6, 4))
     plan.close()
+
+
+def test_counts_only_kinds_cut_long_curves_into_slices_of_16_bit_cells():
+    """The conditional-entropy / Gregory-Loredo histograms keep two 16-bit cells per LDS word, so a workgroup
+    bins at most 65 280 samples: longer curves are cut into sample slices whose partial histograms are added
+    (unpacked) by the finishing launch - whatever the period count, and also with PDC_PDM_SPLIT=0 (checked in
+    a child process)."""
+    import os
+    import subprocess
+    import sys
+    t, x = curve(140_000, 17, period=9.1)
+    mag = so.magnitude_bins(x, 4)
+    for periods in (np.linspace(2.0, 30.0, 33), np.linspace(2.0, 30.0, 5000)):
+        pick = np.unique(np.linspace(0, periods.size - 1, 25).astype(int))
+        got = _cabi.cond_entropy_scan(t, mag, periods, 8, 4)
+        np.testing.assert_allclose(got[pick], so.cond_entropy_scan(t, mag, periods[pick], 8, 4), rtol=RTOL)
+        got = _cabi.gl_scan(t, periods, 5, 6)
+        np.testing.assert_allclose(got[pick], so.gl_scan(t, periods[pick], 5, 6), rtol=RTOL, atol=1e-9)
+    same = np.full(70_000, 3.25)                      # every sample in ONE cell: a count of 70 000 > 65 535
+    np.testing.assert_allclose(_cabi.gl_scan(same, [2.0, 7.0], 4, 2), so.gl_scan(same, np.array([2.0, 7.0]), 4, 2),
+                               rtol=RTOL, atol=1e-9)
+    code = ("import numpy as np; from periodicity_amd import _cabi; from oracle import scan_oracle as so;"
+            "same = np.full(70_000, 3.25);"
+            "a = _cabi.gl_scan(same, [2.0, 7.0], 4, 2); b = so.gl_scan(same, np.array([2.0, 7.0]), 4, 2);"
+            "assert np.allclose(a, b, rtol=1e-9, atol=1e-9), (a, b); print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PDC_PDM_SPLIT="0"), cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
