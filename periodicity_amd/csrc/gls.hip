@@ -61,7 +61,20 @@ struct GlsArgs {
     int64_t z_len = 0;
     int parts = 1, parts_by_xcd = 0;   // parts_by_xcd: part z runs on XCD z % 8 (1-D grid), see the kernel
     double *partial = nullptr;
+    // balanced pieces (gls_scan_kernel<..., BAL = true>, single curve): the (tile, chunk) space - bal_units =
+    // tiles x bal_chunks chunk-units, tile-major - is cut into bal_slots equal runs, one per workgroup, so that
+    // every resident workgroup slot gets the same work whatever tiles / slots is; a run covers pieces of at most
+    // two tiles, a tile falls into at most three runs (`partial` = [3][6][nf]), gls_finish_kernel adds them
+    int64_t bal_slots = 0, bal_units = 0, bal_chunks = 0, bal_tile_freqs = 0;
 };
+
+// balanced pieces: run s covers the units [s U / W, (s + 1) U / W); the run that holds unit x
+__device__ __forceinline__ int64_t bal_slot_of(const GlsArgs &a, int64_t x) {
+    int64_t s = x * a.bal_slots / a.bal_units;
+    while ((s + 1) * a.bal_units / a.bal_slots <= x) ++s;
+    while (s * a.bal_units / a.bal_slots > x) --s;
+    return s;
+}
 
 struct PrepArgs {
     const double *t, *y, *dy;
@@ -252,7 +265,7 @@ __device__ __forceinline__ double gls_power(double Sh, double Ch, double S, doub
 // tile and split every staged chunk of samples between them (S = 1, 2 or 4), so that a short grid
 // still puts >= 2 waves on every SIMD; their partial sums are combined through LDS in a fixed
 // order before the epilogue, so results do not depend on timing.
-template <int K, int MODE, int SPLIT>
+template <int K, int MODE, int SPLIT, bool BAL = false>
 __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(GlsArgs a) {
     constexpr int FT = kBlock / SPLIT;        // frequency-owning threads per workgroup
     constexpr int COLS = FT / 64;             // 64-lane columns of the tile
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
 
     // Workgroup p runs on XCD p % 8 (observed dispatch rule, used for speed only): hand each XCD a
     // contiguous run of logical tiles so the tiles of one curve share that XCD's L2.
-    const int64_t G = a.n_curves * a.tiles;
+    const int64_t G = BAL ? a.bal_slots : a.n_curves * a.tiles;
     const int64_t per_xcd = (G + 7) / 8;
     int64_t L = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     int zpart = blockIdx.y;
@@ -279,8 +292,24 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         if (zpart >= a.parts) return;
     }
     if (L >= G) return;
-    const int64_t curve = L / a.tiles;
-    const int64_t tile = L - curve * a.tiles;
+    int64_t bal_u = 0, bal_hi = 0;   // BAL: this workgroup's run of chunk-units
+    if (BAL) {
+        bal_u = L * a.bal_units / a.bal_slots;
+        bal_hi = (L + 1) * a.bal_units / a.bal_slots;
+        if (bal_u >= bal_hi) return;
+    }
+    do {   // (one trip; BAL: one trip per piece - the stretch of ONE tile's chunks inside the run)
+    int64_t curve = L / a.tiles;
+    int64_t tile = L - curve * a.tiles;
+    int64_t bal_take = 0;
+    int bal_piece = 0;
+    if (BAL) {
+        curve = 0;
+        tile = bal_u / a.bal_chunks;
+        const int64_t c0 = bal_u - tile * a.bal_chunks;
+        bal_take = a.bal_chunks - c0 < bal_hi - bal_u ? a.bal_chunks - c0 : bal_hi - bal_u;
+        bal_piece = (int)(L - bal_slot_of(a, tile * a.bal_chunks));   // 0, 1 or 2: which of the tile's pieces
+    }
 
     const int64_t off = a.offsets ? a.offsets[curve] : 0;
     const int64_t n = a.offsets ? a.offsets[curve + 1] - off : a.n_total;
@@ -302,8 +331,9 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         return make_double2(__builtin_fma(x.x, y.y, x.y * y.x), __builtin_fma(x.y, y.y, -(x.x * y.x)));
     };
     const int slot_a = col * 8 + (lane >> 3), slot_b = COLS * 8 + (lane & 7);
-    const int64_t s_begin = a.partial ? (int64_t)zpart * a.z_len : 0;
-    const int64_t s_end = a.partial ? (s_begin + a.z_len < n ? s_begin + a.z_len : n) : n;
+    const int64_t s_begin = BAL ? (bal_u - tile * a.bal_chunks) * kChunk : (a.partial ? (int64_t)zpart * a.z_len : 0);
+    const int64_t s_stop = BAL ? s_begin + bal_take * kChunk : s_begin + a.z_len;
+    const int64_t s_end = (BAL || a.partial) ? (s_stop < n ? s_stop : n) : n;
     for (int64_t base = s_begin; base < s_end; base += kChunk) {
         __syncthreads();  // everyone is done with the previous chunk's tables
         // ---- per-sample rotation tables (two threads per sample) ------------------------------------
@@ -460,8 +490,8 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     }
     const bool owner = part == 0;  // only part 0 holds complete sums
 
-    if (MODE != MODE_RAW && a.partial) {   // (workgroup-uniform) this sample part's sums; gls_finish_kernel does the rest
-        double *out = a.partial + (int64_t)zpart * 6 * a.nf;
+    if (MODE != MODE_RAW && (BAL || a.partial)) {   // (workgroup-uniform) this sample part's sums; gls_finish_kernel does the rest
+        double *out = a.partial + (int64_t)(BAL ? bal_piece : zpart) * 6 * a.nf;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int64_t j = jl + k;
@@ -474,8 +504,13 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
                 out[5 * a.nf + j] = SC[k];
             }
         }
+        if (BAL) {
+            bal_u += bal_take;
+            continue;   // the next piece of the run, if any
+        }
         return;
     }
+    if (BAL) return;   // (not reached: a balanced launch always leaves partial sums)
 
     const double *sc = a.scal + curve * 4;
     if (MODE == MODE_RAW) {
@@ -538,6 +573,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
             a.blk_arg[L] = best_j;
         }
     }
+    } while (BAL && bal_u < bal_hi);
 }
 
 // Sample parts of gls_scan_kernel (GlsArgs::partial) added up in a fixed order + the epilogue: four lanes
@@ -554,6 +590,10 @@ __global__ __launch_bounds__(kBlock) void gls_finish_kernel(GlsArgs a, int parts
     const bool live = j < a.nf;
     double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (live) {
+        if (a.bal_slots) {   // balanced pieces: the runs that cut this frequency's tile
+            const int64_t tile = j / a.bal_tile_freqs;
+            parts = (int)(bal_slot_of(a, (tile + 1) * a.bal_chunks - 1) - bal_slot_of(a, tile * a.bal_chunks)) + 1;
+        }
         for (int z = q4; z < parts; z += 4) {
             const double *in = a.partial + (int64_t)z * 6 * a.nf + j;
 #pragma unroll
@@ -895,7 +935,8 @@ WorkLayout layout(int64_t n_total, int64_t n_curves, int64_t nf) {
     w.blk_arg = w.blk_max + up(n_curves * tiles_max * 8);
     w.partial = w.blk_arg + up(n_curves * tiles_max * 8);
     // (grows with nf: a plan sized for a long grid also serves short ones)
-    const int64_t cells = kPartsMax * nf < kPartialCells ? kPartsMax * nf : kPartialCells;
+    int64_t cells = kPartsMax * nf < kPartialCells ? kPartsMax * nf : kPartialCells;
+    cells = cells > 3 * nf ? cells : 3 * nf;   // balanced pieces: up to three partial sums per frequency
     w.total = w.partial + (n_curves == 1 ? up(cells * 6 * 8) : 0);
     return w;
 }
@@ -1035,7 +1076,40 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
             grid.y = (unsigned)parts;
         }
     }
-    if (mode == MODE_FIT_MEAN) {
+    // Balanced pieces (one long curve on a long grid, K = 16): a workgroup slot holds 4 waves at 2 waves per
+    // SIMD, 2 per CU, 512 on the chip, and the tiles rarely fill their last round of slots - C2's 489 tiles
+    // leave 23 slots idle for the whole launch, C4's slabs end with a round of 197.  When that costs more than
+    // 2 % the (tile, chunk) space is cut into ceil(tiles / 512) * 512 equal runs instead (GlsArgs::bal_*), every
+    // slot gets the same work, and gls_finish_kernel adds the <= 3 pieces of a tile.  PDC_GLS_BAL=0/1 forces it.
+    static const int env_bal = [] { const char *e = getenv("PDC_GLS_BAL"); return e ? atoi(e) : -1; }();
+    bool balanced = false;
+    if (n_curves == 1 && parts == 1 && mode != MODE_RAW && K == 16 && S >= 2 && env_bal != 0) {
+        const int64_t slots = 512, nchunks = (n_total + 127) / 128;
+        const int64_t full = a.tiles / slots, rem = a.tiles % slots;
+        // (a slot's partner gone, a workgroup runs alone on its CU at about twice the speed)
+        const double t_tiles = (double)full + (rem == 0 ? 0.0 : (rem <= slots / 2 ? 0.5 : 1.0));
+        const double t_bal = (double)a.tiles / (double)slots + 0.004;   // (+ the pieces through HBM, the finishing launch)
+        const int64_t w_bal = (a.tiles + slots - 1) / slots * slots;
+        if ((env_bal == 1 || t_tiles > 1.02 * t_bal) && a.tiles * 2 > w_bal && nchunks >= 32) {
+            balanced = true;
+            a.bal_slots = w_bal;
+            a.bal_chunks = nchunks;
+            a.bal_units = a.tiles * nchunks;
+            a.bal_tile_freqs = tile_freqs;
+            a.partial = reinterpret_cast<double *>(base + w.partial);
+            grid = dim3((unsigned)(((w_bal + 7) / 8) * 8));
+            if (mode == MODE_FIT_MEAN) {
+                if (S == 2) hipLaunchKernelGGL((gls_scan_kernel<16, MODE_FIT_MEAN, 2, true>), grid, dim3(kBlock), 0, st, a);
+                else hipLaunchKernelGGL((gls_scan_kernel<16, MODE_FIT_MEAN, 4, true>), grid, dim3(kBlock), 0, st, a);
+            } else {
+                if (S == 2) hipLaunchKernelGGL((gls_scan_kernel<16, MODE_NO_MEAN, 2, true>), grid, dim3(kBlock), 0, st, a);
+                else hipLaunchKernelGGL((gls_scan_kernel<16, MODE_NO_MEAN, 4, true>), grid, dim3(kBlock), 0, st, a);
+            }
+        }
+    }
+    if (balanced) {
+        // (launched above)
+    } else if (mode == MODE_FIT_MEAN) {
         launch_scan<MODE_FIT_MEAN>(K, S, grid, st, a);
     } else if (mode == MODE_NO_MEAN) {
         launch_scan<MODE_NO_MEAN>(K, S, grid, st, a);
