@@ -525,6 +525,7 @@ int allow_lds(Kernel kernel) {
 // Split mode (few trial periods, many samples; see phase_stat_dev): how the samples are cut and how
 // much scratch the partial histograms take.  n_z == 1: not split.
 struct SplitShape {
+    bool use = false;   // take the split mode (possibly with ONE slice: statistics once per launch, not per workgroup)
     int64_t n_z = 1, z_len = 0, p_pad = 0, bytes = 0;
     int n_stat = 0;
     size_t stat_b = 0, psum_b = 0, pq_b = 0, pcnt_b = 0;
@@ -559,32 +560,46 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
         // Enough waves - but workgroups come in rounds of kSlots (4 per CU, LDS-limited), and a last round
         // that is half empty costs as much as a full one: C5's 1563 workgroups take two rounds for 1.53
         // rounds' worth of work.  Cutting the samples in n_z slices multiplies the workgroups (each a slice
-        // shorter); take the smallest n_z <= 8 that fills >= 90 % of its rounds, if that beats the unsplit
-        // grid by more than the split's own overhead (two statistics launches, partial histograms through
-        // L2, the finishing launch).  PDC_PDM_NZ forces a value (experiments).
+        // shorter): take the n_z <= 16 with the best (share of its rounds filled) - (cost of its slices), or
+        // the unsplit grid if that scores higher.  PDC_PDM_NZ forces a value (experiments).
         static const int env_nz = [] { const char *e = getenv("PDC_PDM_NZ"); return e ? atoi(e) : 0; }();
         // resident workgroups of the scan kernel: LDS-limited (PDM at nb x nc = 10: 38 KB -> 4 per CU, 1024 on
         // the chip; the counts-only kinds with many cells hold fewer), at most 8 per CU (4 waves each)
         const int64_t per_cu = kLdsPerCU / (int64_t)(lds_bytes(last, 256, counts_only ? 4 : 12) + 512);
         const int64_t kSlots = kCUs * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
         auto rounds_filled = [&](int64_t w) { return (double)w / (double)((w + kSlots - 1) / kSlots * kSlots); };
-        // the unsplit launch packs 64, 128 or 256 periods into a workgroup (phase_stat_dev below)
+        // the unsplit launch packs 64, 128 or 256 periods into a workgroup (phase_stat_dev below), and every
+        // one of its workgroups reduces the sample statistics by itself (two passes over all samples: ~5 % of
+        // a C5 workgroup's time) where the split mode has them from two short launches.  A slice costs its
+        // partial histograms through L2 and a share of the finishing launch: ~1.2 % each (measured at C5:
+        // 3 slices 2.74 ms, 5 2.66, 8 2.65, 13 2.71, 16 2.73; unsplit with 99 % of its rounds filled at N = 1e5 x
+        // 1.3e5 periods 6.50 ms against 5.91 in 5 slices)
         const int64_t w_unsplit = groups0 >= 4096 ? (groups0 + 3) / 4 : (groups0 >= 2048 ? (groups0 + 1) / 2 : groups0);
-        double best = rounds_filled(w_unsplit);
-        for (int64_t z = 2; z <= 8 && best < 0.9; ++z)
-            if (rounds_filled(groups0 * z) > best + 0.05) {
-                best = rounds_filled(groups0 * z);
+        double best = rounds_filled(w_unsplit) - 0.05;
+        n_z = 0;   // 0: unsplit
+        // (slices of at most ~16k samples measured best wherever they were tried - N = 5e4: 5 slices, 1e5: 8 -
+        // beyond what the filled rounds explain)
+        int64_t z_min = (n + 16383) / 16384;
+        z_min = z_min > 16 ? 16 : z_min;
+        for (int64_t z = z_min; z <= 16 && z <= (max_z > 1 ? max_z : 1); ++z) {
+            // (a slice's cost is per period, the work it is paid from grows with N: 1.2 % per slice at N = 5e4)
+            const double score = rounds_filled(groups0 * z) - 0.012 * (double)z * (5e4 / (double)n);
+            if (score > best) {
+                best = score;
                 n_z = z;
             }
+        }
         if (env_nz > 0) n_z = env_nz;
+        if (n_z == 0 && must_z <= 1) return sh;
+        if (n_z == 0) n_z = must_z;
     }
     n_z = n_z < max_z ? n_z : max_z;
     n_z = n_z > must_z ? n_z : must_z;
-    if (n_z <= 1) return sh;
+    n_z = n_z < 1 ? 1 : n_z;
     int64_t z_len = ((n + n_z - 1) / n_z + kChunk - 1) / kChunk * kChunk;
     if (counts_only && z_len > kCellSamples) z_len = kCellSamples;   // (kCellSamples is a multiple of kChunk)
     n_z = (n + z_len - 1) / z_len;
-    if (n_z <= 1) return sh;
+    sh.use = true;
     sh.n_z = n_z;
     sh.z_len = z_len;
     sh.p_pad = groups0 * 64;
@@ -630,7 +645,7 @@ int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t,
     const int64_t groups0 = (n_periods + 63) / 64;
     const int nbins = last + 1;
     const SplitShape sh = split_shape(kind, n, n_periods, nb, nc);
-    if (sh.n_z > 1) {
+    if (sh.use) {
         a.p_pad = sh.p_pad;
         a.n_z = (int)sh.n_z;
         a.z_len = sh.z_len;
