@@ -1335,6 +1335,7 @@ constexpr int kCapD = ((((kLdsWg - kFixedD - kStaticD) / 2) & ~7) - 64);   // sa
 static_assert(kCapD / kFWin + 2 <= kRangesD, "range table too small");
 static_assert(kW * kWaveB >= (kNB + 64) * 4 && kW * kWaveB >= kDCap * 10, "aliases must fit");
 static_assert(kRangesD <= 15 * 32, "deferred-range bits live in defer[0..14]");
+constexpr int kCapQ = 4096;             // samples per period of the 256-thread instance (four workgroups per CU)
 
 struct DuoArgs {
     const double *t, *m, *periods;
@@ -1351,9 +1352,15 @@ struct DuoArgs {
     int64_t nr_pad;
 };
 
-template <int KMAX>
-__global__ __launch_bounds__(kB, 4) void sl_duo_kernel(DuoArgs a) {
-    constexpr int NBL = kNB;
+// BLK = 512: two workgroups per CU (N <= kCapD); BLK = 256: four (N <= kCapQ - short periods have too few
+// ranges for eight waves: 10 at N = 2000, 3 at N = 500)
+// NBL: coarse buckets (512 suffice for the short periods of the 256-thread instance: their zeroing, scan and
+// binary searches are fixed work per period)
+template <int KMAX, int BLK = duo::kB, int NBL = kNB>
+__global__ __launch_bounds__(BLK, 4) void sl_duo_kernel(DuoArgs a) {
+    constexpr int kB = BLK, kW = BLK / 64;                 // (shadow the namespace's 512-thread values)
+    constexpr int kDCap = BLK >= 512 ? ::kDCap : 1024;     // deferred LDS sort: keys + indices alias the wave scratch
+    static_assert(kW * kWaveB >= (NBL + 64) * 4 && kW * kWaveB >= kDCap * 10, "aliases must fit");
     typedef unsigned short IdxT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char *wbuf = lds_raw;                                                  // P3a: per-wave scratch
@@ -1428,7 +1435,7 @@ __global__ __launch_bounds__(kB, 4) void sl_duo_kernel(DuoArgs a) {
                 for (int u = 0; u < 4; ++u) {
                     if (k0 + u < KMAX) {
                         const int i = (k0 + u) * kB + tid;
-                        const int b = i < n ? coarse_of<kNB>(phi[u]) : NBL + lane;
+                        const int b = i < n ? coarse_of<NBL>(phi[u]) : NBL + lane;
                         atomicAdd(&hist[b], 1u);
                         pk[(k0 + u) >> 1] |= (unsigned)b << (((k0 + u) & 1) * 16);
                     }
@@ -1482,7 +1489,7 @@ __global__ __launch_bounds__(kB, 4) void sl_duo_kernel(DuoArgs a) {
         __syncthreads();   // (the histogram is dead from here on: its LDS becomes wave scratch)
 
         // ---- P3a: wave-autonomous ranges (the same code as sl_fast_kernel's, on this workgroup's 8 waves) --
-        constexpr int NB = kNB;
+        constexpr int NB = NBL;
         const int r_base = 0;
 #include "sl_ranges.inc"
         if (wave < nranges) request(wave);
@@ -1590,11 +1597,12 @@ int64_t fast_table_bytes(int64_t n) { return ((n * 16 + 255) & ~(int64_t)255) + 
 // kernel and the ticket counter
 int64_t duo_bytes(int64_t n_periods) { return ((n_periods + 255) & ~(int64_t)255) + 256; }
 
-template <int KMAX>
+template <int KMAX, int BLK = duo::kB, int NBL = fast::kNB>
 int launch_duo(const duo::DuoArgs &a, int64_t grid, hipStream_t st) {
-    const size_t lds = (size_t)duo::kFixedD + (size_t)((a.n + 64 + 7) & ~7) * 2;
-    PDC_TRY(allow_dynamic_lds((const void *)duo::sl_duo_kernel<KMAX>, duo::kLdsWg - duo::kStaticD));
-    hipLaunchKernelGGL((duo::sl_duo_kernel<KMAX>), dim3((unsigned)grid), dim3(duo::kB), lds, st, a);
+    const size_t fixed = (size_t)(BLK / 64) * duo::kWaveB + 2 * (duo::kRangesD + 8) * 2 + 64;
+    const size_t lds = fixed + (size_t)((a.n + 64 + 7) & ~7) * 2;
+    PDC_TRY(allow_dynamic_lds((const void *)duo::sl_duo_kernel<KMAX, BLK, NBL>, duo::kLdsWg - duo::kStaticD));
+    hipLaunchKernelGGL((duo::sl_duo_kernel<KMAX, BLK, NBL>), dim3((unsigned)grid), dim3(BLK), lds, st, a);
     return PDC_OK;
 }
 
@@ -1709,11 +1717,14 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
             d.rcnt = a.rcnt;
             d.rlen = rlen;
             d.nr_pad = a.nr_pad;
-            int64_t dgrid = 2 * (int64_t)cu_count(device);
+            static const bool quad_on = [] { const char *e = getenv("PDC_SL_QUAD"); return !(e && e[0] == '0'); }();
+            const bool quad = quad_on && n <= duo::kCapQ;   // four 256-thread workgroups per CU
+            int64_t dgrid = (quad ? 4 : 2) * (int64_t)cu_count(device);
             dgrid = dgrid < grid ? dgrid : grid;       // (the range scratch is laid out for `grid` workgroups)
             PDC_HIP(hipMemsetAsync(d.ticket, 0, 4, st));
             const int kd = (int)((n + duo::kB - 1) / duo::kB);
-            if (kd <= 16) PDC_TRY(launch_duo<16>(d, dgrid, st));
+            if (quad) PDC_TRY((launch_duo<16, 256, 512>(d, dgrid, st)));
+            else if (kd <= 16) PDC_TRY(launch_duo<16>(d, dgrid, st));
             else if (kd <= 36) PDC_TRY(launch_duo<36>(d, dgrid, st));
             else PDC_TRY(launch_duo<52>(d, dgrid, st));
             f.todo = todo;   // the periods the duo kernel marked (clustered phases) go through the one-slice kernel

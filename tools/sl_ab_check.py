@@ -11,7 +11,7 @@ from periodicity_amd import _cabi  # noqa: E402
 
 rng = np.random.default_rng(2024)
 out = {}
-for n, n_per in ((1, 5), (2, 5), (63, 40), (500, 300), (4097, 130), (12_345, 700), (26_048, 300), (26_049, 64)):
+for n, n_per in ((1, 5), (2, 5), (63, 40), (500, 300), (4096, 200), (4097, 130), (12_345, 700), (26_048, 300), (26_049, 64)):
     t = np.sort(rng.uniform(0, float(n), n)) - 0.3 * n
     y = np.sin(2 * np.pi * t / 13.7) + 0.1 * rng.standard_normal(n)
     m = so.stringlength_scale(y) if n > 1 else np.zeros(n)
