@@ -208,7 +208,8 @@ int pdc_gls_batch_highest_peak(const double *t, const double *y, const double *d
  * the ranking quantity, that FSeries.periods_at_half_max (core.py:963-978) looks up for
  * peak_order = rank + 1: half_hi = the last one inside x[:idx], half_lo = the first one of x[idx:]
  * as an absolute bin (np.where(np.diff(np.signbit(..))), core.py:362); the method returns
- * (period[half_lo], period[half_hi]).  Equal keys rank the lower bin first.
+ * (period[half_lo], period[half_hi]).  Exactly equal keys rank the lower bin first (upstream's argsort()[::-1]
+ * leaves ties to numpy's unstable sort: see INTEGRATION.md).
  * pdc_gls_batch_peaks runs the batched periodogram first; the spectra never leave HBM. */
 int pdc_peaks_topk(const double *power, int64_t n_curves, int64_t nf, int k, int by_prominence,
                    int64_t *count_out, int64_t *idx_out, double *height_out, double *prominence_out,

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(kBlock) void highest_peak_kernel(const double *powe
 // period_at_highest_prominence :957-961); only the first k <= 16 come back, together with the two
 // sign changes of x - (x[peak] - height/2) that periods_at_half_max (:963-978) looks up: the last
 // one left of the peak and the first one from the peak rightwards (np.diff(np.signbit(..)), core.py:362).
-// Equal heights / prominences rank the lower bin first (numpy's argsort leaves that order open).
+// Equal heights / prominences rank the lower bin first - a documented deviation: upstream's
+// argsort()[::-1] (core.py:944-950, 969) is an unstable sort read backwards, which for short arrays puts the
+// HIGHER bin first; the host-side FSeries methods of this package run numpy as upstream does.
 //
 // One workgroup per spectrum.  Only k peaks are wanted, and walking every maximum (6300 per 5e4-bin C3
 // row; what the first version did, 7.9 ms for the C3 batch, 85 % of it in wave-iterations as long as
