@@ -179,6 +179,38 @@ def test_pdm_random_cases(seed=11):
         np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=str(case))
 
 
+def test_binned_scans_random_cases(seed=17):
+    """PDM / AoV / conditional entropy / Gregory-Loredo at the sizes where the launcher changes mode: few
+    periods on long curves (sample slices + finishing launch), more than 65 280 samples (16-bit count cells
+    force slices), one period, periods spread over device slots of one GPU."""
+    rng = np.random.default_rng(seed)
+    for case in range(10):
+        n = int(rng.choice([700, 5000, 16_385, 33_000, 65_281, 70_001]))
+        n_per = int(rng.choice([1, 2, 9, 40, 130]))
+        t, y, _ = random_curve(rng, n)
+        if rng.integers(0, 3) == 0:
+            t = t - t.mean()
+        periods = rng.uniform(0.3, 90.0, n_per)
+        periods[0] = 2.0
+        devices = (0, 0, 0) if rng.integers(0, 4) == 0 else None
+        tag = f"case {case}: n={n} periods={n_per} devices={devices}"
+        nb, nc = int(rng.integers(2, 9)), int(rng.integers(1, 4))
+        with np.errstate(all="ignore"):
+            np.testing.assert_allclose(_cabi.pdm_scan(t, y, periods, nb, nc, np.var(y, ddof=1), devices=devices),
+                                       so.pdm_scan(t, y, periods, nb, nc), rtol=1e-9, atol=1e-12, err_msg=tag)
+            r = int(rng.integers(2, 25))
+            np.testing.assert_allclose(_cabi.aov_scan(t, y, periods, r, devices=devices),
+                                       so.aov_scan(t, y, periods, r), rtol=1e-8, atol=1e-12, err_msg=tag)
+            n_phase, n_mag = int(rng.integers(2, 16)), int(rng.integers(1, 9))
+            mb = so.magnitude_bins(y, n_mag)
+            np.testing.assert_allclose(_cabi.cond_entropy_scan(t, mb, periods, n_phase, n_mag, devices=devices),
+                                       so.cond_entropy_scan(t, mb, periods, n_phase, n_mag), rtol=1e-10, atol=1e-12,
+                                       err_msg=tag)
+            m, n_off = int(rng.integers(2, 13)), int(rng.choice([1, 4, 8]))
+            np.testing.assert_allclose(_cabi.gl_scan(t, periods, m, n_off, devices=devices),
+                                       so.gl_scan(t, periods, m, n_off), rtol=1e-10, atol=1e-9, err_msg=tag)
+
+
 def test_stringlength_random_cases(seed=13):
     rng = np.random.default_rng(seed)
     for case in range(50):
