@@ -325,3 +325,47 @@ def test_pdm_split_mode_writes_every_scratch_word_it_reads(tmp_path):
         a, b = outs["poison"][key], outs["unsplit"][key]
         assert np.all(np.isfinite(a)), key
         np.testing.assert_allclose(a, b, rtol=1e-11, err_msg=key)
+
+
+def test_mixed_scans_from_concurrent_python_threads():
+    """ctypes drops the GIL: every scan family at once from six threads - single-device entries (cached
+    workspace behind the device lock), the device-slot plans (cached by device list, one mutex each) and the
+    peak reduction - must return what they return one at a time, bit for bit."""
+    import threading
+    rng = np.random.default_rng(404)
+    t, y, dy = synth(6000, 9)
+    m = so.stringlength_scale(y)
+    mb = so.magnitude_bins(y, 4)
+    periods = np.linspace(0.8, 60.0, 333)
+    spectra = rng.random((7, 3001))
+    jobs = {
+        "pdm": lambda: _cabi.pdm_scan(t, y, periods, 5, 2, np.var(y, ddof=1)),
+        "pdm_slots": lambda: _cabi.pdm_scan(t, y, periods, 5, 2, np.var(y, ddof=1), devices=(0, 0, 0)),
+        "sl": lambda: _cabi.stringlength_scan(t, m, periods),
+        "sl_slots": lambda: _cabi.stringlength_scan(t, m, periods, devices=(0, 0)),
+        "aov": lambda: _cabi.aov_scan(t, y, periods, 8),
+        "ce_slots": lambda: _cabi.cond_entropy_scan(t, mb, periods, 9, 4, devices=(0, 0, 0)),
+        "gl": lambda: _cabi.gl_scan(t, periods, 5, 4),
+        "peaks": lambda: _cabi.peaks_topk(spectra, k=3, by_prominence=True)["indices"],
+        "gls": lambda: _cabi.gls_scan(t, y, dy, 0.001, 0.0005, 2500),
+    }
+    want = {k: fn() for k, fn in jobs.items()}
+    names = list(jobs)
+    errors = []
+
+    def work(w):
+        try:
+            for it in range(4):
+                for k in names[w % len(names):] + names[:w % len(names)]:
+                    got = jobs[k]()
+                    if not np.array_equal(got, want[k], equal_nan=True):
+                        errors.append(f"thread {w} iteration {it}: {k} differs")
+        except Exception as exc:  # noqa: BLE001 - reported below
+            errors.append(f"thread {w}: {exc!r}")
+
+    threads = [threading.Thread(target=work, args=(w,)) for w in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
