@@ -719,6 +719,11 @@ namespace fast {
 #ifndef PDC_SL_G1
 #define PDC_SL_G1 4
 #endif
+// PMC / timing experiments only (results are garbage): 1 = every period stops after P1 (fold, histogram, scan),
+// 2 = after P2 and the range table - what each phase costs and how many LDS bank-conflict cycles it makes
+#ifndef PDC_SL_STOP
+#define PDC_SL_STOP 0
+#endif
 #ifndef PDC_SL_G2
 #define PDC_SL_G2 4
 #endif
@@ -1001,6 +1006,9 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         }
         __syncthreads();
         scan_buckets<NB>(hist, wave_tot);   // hist[b] = first sorted position of bucket b
+#if PDC_SL_STOP == 1
+        continue;
+#endif
 
         // ---- P2: the permutation, grouped by coarse bucket ----------------------------------------
 #pragma unroll
@@ -1177,6 +1185,9 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         }
         __syncthreads();   // (the histogram is dead from here on: its LDS becomes wave scratch)
 
+#if PDC_SL_STOP == 2
+        continue;
+#endif
         // ---- P3a: wave-autonomous ranges -------------------------------------------------------------
 #include "sl_ranges.inc"
         if (wave < nranges) request(wave);
