@@ -19,7 +19,10 @@ Two ways to drive N GPUs, same kernels, same collective:
   * under ``torch.distributed.run`` (WORLD_SIZE > 1 in the environment): one rank per GPU, torch is
     used for rendezvous, the barrier and the RCCL all-gather only.
 With N > 1 the line also carries ``extras``: the other configs sharded the way they shard - C5's period
-grid in N slabs (PDM, StringLength), C3's curves in N groups - kernel-only and end to end.
+grid in N slabs (PDM, StringLength), C3's curves in N groups - kernel-only and end to end; and the two
+STRONG-scaling entries: ``c4_sharded`` = BASELINE configs[3] (N=1e6 x nf=1e7, fixed, N slabs + all-gather +
+D2H of the 80 MB power array; its ``speedup_vs_1gpu`` against one slot of the same run is the north star's
+">= 6x at 8 GPUs") and ``c2_strong`` (C2's own grid cut N ways).  The headline ``value`` stays weak-scaled.
 
 The product path is the C ABI (libperiodicity_hip.so).  ``oracle/`` is touched only by the
 ``cpu_baseline`` legs, after the clock has stopped.
@@ -637,7 +640,7 @@ def sharded_extras_dist(cabi, lib, torch, dist, dev, rank, world):
         dist.barrier()
         return max_over_ranks(time.perf_counter() - t0), got
 
-    from periodicity_amd import distributed as pdist
+    from tools import torchrun_sharded as pdist
     t5, y5, m, periods, sl_periods = c5_inputs()
     n, n_per = t5.size, periods.size
     pairs = float(n) * n_per
@@ -663,7 +666,7 @@ def sharded_extras_dist(cabi, lib, torch, dist, dev, rank, world):
                     "algorithmic_frac_per_rank": None if afrac is None else round(afrac(pairs / world, ms), 4),
                     "note": f"period grid in {world} contiguous slabs, one per rank, samples replicated; kernel = HIP "
                             "events, MAX over ranks; end to end = host buffers in, slab scan, all-gather of the "
-                            "results (periodicity_amd.distributed), barrier to barrier, MAX over ranks"}
+                            "results (tools/torchrun_sharded.py), barrier to barrier, MAX over ranks"}
         for b in (bv, bp, bo, bw):
             b.free()
     bt5.free()
@@ -703,6 +706,237 @@ def sharded_extras_dist(cabi, lib, torch, dist, dev, rank, world):
                 "events, MAX over ranks; end to end = host buffers in, batched scan, all-gather of the [B] maxima"}
     for b in bufs + [work, amax, arg]:
         b.free()
+    return out
+
+# ---- N > 1: STRONG scaling - a fixed grid cut into N slabs + the all-gather of the power array ----------------
+STRONG_CONFIGS = (
+    # key, samples, frequencies, synth_curve index, steps of the back-to-back loop (0 = single shots only)
+    ("c4_sharded", 1_000_000, 10_000_000, 4, 0),
+    ("c2_strong", N_SAMPLES, NF_PER_GPU, 2, 20),
+)
+STRONG_NOTES = {
+    "c4_sharded": "BASELINE configs[3]: N=1e6 samples x nf=1e7 frequencies = 1e13 pairs, FIXED total work; the grid in "
+                  "one contiguous slab per slot + one all-gather of the power array (10 MB per rank at 8 slots) + D2H "
+                  "of power[1e7] (80 MB); the north star's '>= 6x at 8 GPUs' is speedup_vs_1gpu of THIS entry",
+    "c2_strong": "BASELINE configs[1]'s grid (N=1e5 x nf=1e6 = 1e11 pairs) cut N ways: the honest worst case of "
+                 "strong scaling - 27 ms / N of scan per GPU against the gather of an 8 MB array and the launch "
+                 "overheads",
+}
+
+
+def strong_entry(key, n, nf, slots, k_ms, scan_gather_s, e2e_s, one, loop, power, power_one, rccl, loopback, what):
+    pairs = float(n) * nf
+    worst = max(k_ms)
+    out = {
+        "workload": STRONG_NOTES[key], "scaling": "strong", "slots": slots, "pairs": pairs,
+        "kernel_ms_slowest_slot": round(worst, 4), "kernel_ms_per_slot": [round(v, 4) for v in k_ms],
+        "scan_plus_gather_ms": round(scan_gather_s * 1e3, 4), "end_to_end_ms": round(e2e_s * 1e3, 3),
+        "Gpair_per_s_kernel": round(pairs / worst / 1e6, 1),
+        "Gpair_per_s_scan_plus_gather": round(pairs / scan_gather_s / 1e9, 1),
+        "Gpair_per_s_end_to_end": round(pairs / e2e_s / 1e9, 1),
+        "algorithmic_frac_per_slot": round(gls_algorithmic_frac(pairs / slots, worst), 4),
+        "one_gpu": {k_: round(v, 4) for k_, v in one.items()},
+        "speedup_vs_1gpu": {"kernel": round(one["kernel_ms"] / worst, 3),
+                            "scan_plus_gather": round(one["scan_ms_wall"] / (scan_gather_s * 1e3), 3),
+                            "end_to_end": round(one["end_to_end_ms"] / (e2e_s * 1e3), 3)},
+        "rccl": rccl,
+        "peak_bin": int(np.nanargmax(power)),
+        "peak_bin_matches_one_gpu": bool(int(np.nanargmax(power)) == int(np.nanargmax(power_one))),
+        "max_abs_diff_vs_one_gpu": float(np.nanmax(np.abs(power - power_one))),
+        "note": what + ("; LOOPBACK: the slots share ONE device, so the speedups here are ~1 by construction - the "
+                        "entry proves the code path, the real figure needs N GPUs" if loopback else ""),
+    }
+    if loop:
+        out["back_to_back"] = loop
+    return out
+
+
+def strong_scaling_one_process(cabi, devices, loopback):
+    """One process, the listed device slots, through the persistent plan (pdc_gls_plan_*): the fixed-size
+    configs in `len(devices)` slabs against the same plan with ONE slot on devices[0] in the same run."""
+    slots = len(devices)
+    out = {}
+    for key, n, nf, k, steps in STRONG_CONFIGS:
+        t, y, dy = synth_curve(n, k)
+        freq, df, fmin = throughput_grid(t, nf)
+        f0, delta, _ = cabi.grid_params(freq)
+        del freq
+        res = {}
+        for tag, n_sl in (("one", 1), ("all", slots)):
+            if tag == "all" and loopback:
+                plan = cabi.GlsPlan([devices[0]], n, nf, loopback_slots=n_sl)
+            else:
+                plan = cabi.GlsPlan(list(devices[:n_sl]), n, nf)
+            info = plan.info()
+            plan.upload(t, y, dy)
+            plan.scan(f0, delta, min(nf, 200_000))          # clocks up, code objects loaded
+            plan.wait()
+            t0 = time.perf_counter()
+            plan.scan(f0, delta, nf)
+            plan.wait()
+            sg = time.perf_counter() - t0
+            k_ms = plan.slot_ms()
+            t0 = time.perf_counter()
+            plan.upload(t, y, dy)
+            plan.scan(f0, delta, nf)
+            power = plan.download(0)
+            e2e = time.perf_counter() - t0
+            loop = None
+            if steps:
+                plan.scan(f0, delta, nf)
+                plan.wait()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    plan.scan(f0, delta, nf)
+                plan.wait()
+                per = (time.perf_counter() - t0) / steps
+                loop = {"steps": steps, "ms_per_step": round(per * 1e3, 4),
+                        "Gpair_per_s": round(float(n) * nf / per / 1e9, 1),
+                        "note": "scans enqueued back to back; the gather of step i overlaps the scan of step i+1"}
+            if tag == "all" and slots > 1:
+                assert np.array_equal(power, plan.download(slots - 1), equal_nan=True), \
+                    f"{key}: the all-gather left the slots with different arrays"
+            plan.close()
+            res[tag] = (k_ms, sg, e2e, loop, power, info)
+        k1, sg1, e1, loop1, p1, _ = res["one"]
+        kN, sgN, eN, loopN, pN, info = res["all"]
+        one = {"kernel_ms": k1[0], "scan_ms_wall": sg1 * 1e3, "end_to_end_ms": e1 * 1e3}
+        if loop1:
+            one["back_to_back_ms_per_step"] = loop1["ms_per_step"]
+            loopN["speedup_vs_1gpu"] = round(loop1["ms_per_step"] / loopN["ms_per_step"], 3)
+        out[key] = strong_entry(
+            key, n, nf, slots, kN, sgN, eN, one, loopN, pN, p1,
+            {"ranks_in_communicator": info["rccl_ranks"], "exchange": info["exchange"], "slots": info["n_slots"]},
+            loopback,
+            "one process, N devices (pdc_gls_plan_*); kernel = HIP events around every slot's slab scan, the slowest; "
+            "scan_plus_gather = enqueue to all streams drained, wall; end to end = upload of (t, y, dy) to every "
+            "device + scans + all-gather + D2H of the whole power array from slot 0, wall; one_gpu = the same plan "
+            "with one slot on devices[0], same run")
+        del p1, pN, res
+    return out
+
+
+def strong_scaling_dist(cabi, lib, torch, dist, dev, rank, world):
+    """One rank per GPU: rank r scans slab r of the fixed grid, all_gather_into_tensor (RCCL), rank 0 brings the
+    whole array to the host.  Times are barrier to barrier, MAX over ranks; one_gpu = the whole grid on rank 0
+    alone while the others wait."""
+    out = {}
+    DB = cabi.DeviceBuffer
+    stream = torch.cuda.current_stream().cuda_stream
+    tm = EventTimer(lib, cabi, dev, stream)
+
+    def max_over_ranks(x):
+        v = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        return float(v.item())
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        got = fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        return max_over_ranks(time.perf_counter() - t0), got
+
+    for key, n, nf, k, steps in STRONG_CONFIGS:
+        t, y, dy = synth_curve(n, k)
+        freq, df, fmin = throughput_grid(t, nf)
+        f0, delta, _ = cabi.grid_params(freq)
+        del freq
+        host = np.stack([t, y, dy])
+        per = -(-nf // world)
+        b0 = min(rank * per, nf)
+        cnt = min(per, nf - b0)
+        dev_in = [torch.from_numpy(host).cuda()]
+        wb = lib.pdc_gls_work_bytes(n, 1, per)
+        work = DB(wb, dev)
+        send = torch.zeros(per, dtype=torch.float64, device="cuda")
+        full = torch.empty(per * world, dtype=torch.float64, device="cuda")
+
+        def scan(j_begin, count, out_ptr, wptr, wbytes):
+            tt = dev_in[0]
+            cabi.check(lib.pdc_gls_scan_dev(dev, stream, tt[0].data_ptr(), tt[1].data_ptr(), tt[2].data_ptr(), None, n, 1,
+                                            0, f0, delta, j_begin, count, 1, 0, out_ptr, None, None, wptr, wbytes))
+
+        def slab_scan():
+            if cnt > 0:
+                scan(b0, cnt, send.data_ptr(), work.ptr, wb)
+
+        def scan_gather():
+            slab_scan()
+            dist.all_gather_into_tensor(full, send)
+
+        def end_to_end():
+            dev_in[0] = torch.from_numpy(host).cuda()
+            scan_gather()
+            return full[:nf].cpu().numpy() if rank == 0 else None
+
+        scan(b0, min(cnt, 200_000), send.data_ptr(), work.ptr, wb)          # clocks up
+        k_ms = max_over_ranks(tm.ms(slab_scan, reps=1, warm=0))
+        mine = torch.tensor([tm.ms(slab_scan, reps=1, warm=0)], dtype=torch.float64, device="cuda")
+        all_ms = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(all_ms, mine)
+        sg, _ = timed(scan_gather)
+        e2e, power = timed(end_to_end)
+        loop = None
+        if steps:
+            def many():
+                for _ in range(steps):
+                    scan_gather()
+            many()
+            per_step = timed(many)[0] / steps
+            loop = {"steps": steps, "ms_per_step": round(per_step * 1e3, 4),
+                    "Gpair_per_s": round(float(n) * nf / per_step / 1e9, 1),
+                    "note": "scan then all-gather, step after step on one stream per rank (no overlap between a "
+                            "step's gather and the next scan)"}
+        # the whole grid on rank 0 alone
+        one, power_one = None, None
+        if rank == 0:
+            wb1 = lib.pdc_gls_work_bytes(n, 1, nf)
+            work1 = DB(wb1, dev)
+            whole = torch.empty(nf, dtype=torch.float64, device="cuda")
+
+            def one_scan():
+                scan(0, nf, whole.data_ptr(), work1.ptr, wb1)
+
+            def one_e2e():
+                dev_in[0] = torch.from_numpy(host).cuda()
+                one_scan()
+                return whole.cpu().numpy()
+            one_k = tm.ms(one_scan, reps=1, warm=0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            one_scan()
+            torch.cuda.synchronize()
+            one_wall = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            power_one = one_e2e()
+            one = {"kernel_ms": one_k, "scan_ms_wall": one_wall * 1e3, "end_to_end_ms": (time.perf_counter() - t0) * 1e3}
+            if steps:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    one_scan()
+                torch.cuda.synchronize()
+                one["back_to_back_ms_per_step"] = (time.perf_counter() - t0) / steps * 1e3
+                loop["speedup_vs_1gpu"] = round(one["back_to_back_ms_per_step"] / loop["ms_per_step"], 3)
+            work1.free()
+            del whole
+        dist.barrier()
+        if rank == 0:
+            out[key] = strong_entry(
+                key, n, nf, world, [float(v.item()) for v in all_ms], sg, e2e, one, loop, power, power_one,
+                {"ranks_in_communicator": dist.get_world_size(),
+                 "exchange": f"rccl (torch.distributed, backend {dist.get_backend()})", "slots": world},
+                False,
+                "one rank per GPU (torch.distributed); kernel = HIP events around this rank's slab scan, every rank's "
+                "listed; scan_plus_gather / end to end = barrier to barrier, MAX over ranks; end to end = H2D of "
+                "(t, y, dy) on every rank + slab scan + all_gather_into_tensor + D2H of the whole power array on rank 0; "
+                "one_gpu = the whole grid on rank 0 alone, the other ranks waiting")
+            out[key]["kernel_ms_slowest_slot_first_launch"] = round(k_ms, 4)
+        work.free()
+        del send, full, dev_in
     return out
 
 
@@ -903,6 +1137,17 @@ def main():
                 sharded = sharded_extras_one_process(_cabi, lib, [0] * loopback if loopback else list(range(args.gpus)))
         except Exception as exc:
             sharded = {"error": f"{type(exc).__name__}: {exc}"}
+        # STRONG scaling: BASELINE configs[3] (C4, the config the '>= 6x at 8 GPUs' target is stated on) and C2's
+        # grid cut N ways, against one slot of the same run
+        try:
+            if dist_mode:
+                strong = strong_scaling_dist(_cabi, lib, torch, dist, dev, rank, world)
+            else:
+                strong = strong_scaling_one_process(_cabi, [0] * loopback if loopback else list(range(args.gpus)),
+                                                    bool(loopback))
+        except Exception as exc:
+            strong = {"strong_scaling_error": f"{type(exc).__name__}: {exc}"}
+        sharded = dict(sharded or {}, **strong)
 
     if rank == 0:
         if plan_mode:

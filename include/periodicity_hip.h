@@ -118,7 +118,8 @@ int pdc_gls_scan_multi(const double *t, const double *y, const double *dy, int64
  *   wait     drain every stream of the plan
  *   download wait, then copy the latest complete power[nf] from device slot `which` (every device
  *            holds the whole array after the gather)
- *   kernel_ms  HIP-event time of the latest slab scan on devices[0] */
+ *   kernel_ms  HIP-event time of the latest slab scan on devices[0]
+ *   slot_ms    the same for every slot (ms_out[n_slots]; the slowest slot bounds a sharded scan) */
 int pdc_gls_plan_create(const int *devices, int n_devices, int64_t n_max, int64_t nf_max, void **plan);
 /* The same plan with `n_slots` LOGICAL slots on ONE physical device ("loopback"): every slot has its own
  * buffers, streams and events, scans its own slab, and the all-gather is replaced by the equivalent
@@ -135,6 +136,7 @@ int pdc_gls_plan_scan(void *plan, double f0, double delta, int64_t nf, int fit_m
 int pdc_gls_plan_wait(void *plan);
 int pdc_gls_plan_download(void *plan, double *power_out, int64_t nf, int which);
 int pdc_gls_plan_kernel_ms(void *plan, float *ms);
+int pdc_gls_plan_slot_ms(void *plan, float *ms_out, int n_slots);
 int pdc_gls_plan_destroy(void *plan);
 
 /* Seam-level: replaces _trig_sum(t, w, df, nf, fmin) (spectral.py:11-40) by what its docstring

@@ -19,11 +19,13 @@ def build():
 
 
 def lib():
+    """``ORACLE_LIBRARY`` names another build of the same source (the sanitized one, `make -C oracle SAN=1`)."""
     global _lib
     if _lib is None:
-        if not os.path.isfile(_PATH):
+        path = os.environ.get("ORACLE_LIBRARY") or _PATH
+        if not os.path.isfile(path):
             build()
-        _lib = C.CDLL(_PATH)
+        _lib = C.CDLL(path)
     return _lib
 
 

@@ -54,6 +54,7 @@ PROTOTYPES = {
     "pdc_gls_plan_wait": (_I, [_VP]),
     "pdc_gls_plan_download": (_I, [_VP, _VP, _L, _I]),
     "pdc_gls_plan_kernel_ms": (_I, [_VP, C.POINTER(C.c_float)]),
+    "pdc_gls_plan_slot_ms": (_I, [_VP, C.POINTER(C.c_float), _I]),
     "pdc_gls_plan_destroy": (_I, [_VP]),
     "pdc_trig_sums": (_I, [_VP, _VP, _L, _D, _D, _L, _VP, _VP, _I]),
     "pdc_gls_work_bytes": (_L, [_L, _L, _L]),
@@ -144,6 +145,15 @@ def device_count():
     return n.value if status == 0 else 0
 
 
+def pick_device(device=None, devices=None):
+    """The ONE precedence rule for the ``device=`` / ``devices=`` pair every scan accepts: a ``devices``
+    list, when given, wins (its first entry for a single-device call); else ``device``; else None (the
+    process default, ``default_device()``)."""
+    if devices is not None and len(devices) > 0:
+        return int(devices[0])
+    return device
+
+
 def device_info(device=0):
     name = C.create_string_buffer(256)
     cu, mem, clk = C.c_int(0), C.c_int64(0), C.c_int(0)
@@ -221,8 +231,7 @@ def gls_scan_batch(t, y, dy, offsets, f0, delta, nf, fit_mean=True, psd=False, s
                                              f0, delta, nf, int(bool(fit_mean)), int(bool(psd)),
                                              _ptr(power), _ptr(amax), _ptr(argmax), _ptr(devs), devs.size))
         return power, amax, argmax
-    if devices is not None and device is None:
-        device = devices[0]
+    device = pick_device(device, devices)
     dev = default_device() if device is None else device
     check(lib().pdc_gls_scan_batch(_ptr(t), _ptr(y), _ptr(dy), _ptr(offsets), nb, int(shared_t),
                                    f0, delta, j_begin, nf, int(bool(fit_mean)), int(bool(psd)),
@@ -296,6 +305,12 @@ class GlsPlan:
         ms = C.c_float()
         check(lib().pdc_gls_plan_kernel_ms(self._plan, C.byref(ms)))
         return ms.value
+
+    def slot_ms(self):
+        """HIP-event time of the latest slab scan on every slot."""
+        ms = (C.c_float * len(self.devices))()
+        check(lib().pdc_gls_plan_slot_ms(self._plan, ms, len(self.devices)))
+        return [float(v) for v in ms]
 
     def close(self):
         if self._plan:
@@ -449,8 +464,7 @@ def pdm_scan(t, x, periods, nb, nc, sigma, device=None, devices=None):
         check(lib().pdc_pdm_scan_multi(_ptr(t), _ptr(x), t.size, _ptr(periods), periods.size, int(nb),
                                        int(nc), float(sigma), _ptr(out), _ptr(devs), devs.size))
         return out
-    if devices is not None and device is None:
-        device = devices[0]
+    device = pick_device(device, devices)
     dev = default_device() if device is None else device
     check(lib().pdc_pdm_scan(_ptr(t), _ptr(x), t.size, _ptr(periods), periods.size, int(nb),
                              int(nc), float(sigma), _ptr(out), dev))
@@ -469,8 +483,7 @@ def aov_scan(t, x, periods, n_bins, device=None, devices=None):
         check(lib().pdc_aov_scan_multi(_ptr(t), _ptr(x), t.size, _ptr(periods), periods.size, int(n_bins),
                                        _ptr(out), _ptr(devs), devs.size))
         return out
-    if devices is not None and device is None:
-        device = devices[0]
+    device = pick_device(device, devices)
     dev = default_device() if device is None else device
     check(lib().pdc_aov_scan(_ptr(t), _ptr(x), t.size, _ptr(periods), periods.size, int(n_bins),
                              _ptr(out), dev))
@@ -491,8 +504,7 @@ def cond_entropy_scan(t, mag_bin, periods, n_phase, n_mag, device=None, devices=
         check(lib().pdc_cond_entropy_scan_multi(_ptr(t), _ptr(mag_bin), t.size, _ptr(periods), periods.size,
                                                 int(n_phase), int(n_mag), _ptr(out), _ptr(devs), devs.size))
         return out
-    if devices is not None and device is None:
-        device = devices[0]
+    device = pick_device(device, devices)
     dev = default_device() if device is None else device
     check(lib().pdc_cond_entropy_scan(_ptr(t), _ptr(mag_bin), t.size, _ptr(periods), periods.size,
                                       int(n_phase), int(n_mag), _ptr(out), dev))
@@ -510,8 +522,7 @@ def gl_scan(t, periods, m, n_offsets, device=None, devices=None):
         check(lib().pdc_gl_scan_multi(_ptr(t), t.size, _ptr(periods), periods.size, int(m), int(n_offsets),
                                       _ptr(out), _ptr(devs), devs.size))
         return out
-    if devices is not None and device is None:
-        device = devices[0]
+    device = pick_device(device, devices)
     dev = default_device() if device is None else device
     check(lib().pdc_gl_scan(_ptr(t), t.size, _ptr(periods), periods.size, int(m), int(n_offsets), _ptr(out), dev))
     return out
@@ -529,8 +540,7 @@ def stringlength_scan(t, m, periods, device=None, devices=None):
         check(lib().pdc_stringlength_scan_multi(_ptr(t), _ptr(m), t.size, _ptr(periods), periods.size,
                                                 _ptr(out), _ptr(devs), devs.size))
         return out
-    if devices is not None and device is None:
-        device = devices[0]
+    device = pick_device(device, devices)
     dev = default_device() if device is None else device
     check(lib().pdc_stringlength_scan(_ptr(t), _ptr(m), t.size, _ptr(periods), periods.size,
                                       _ptr(out), dev))

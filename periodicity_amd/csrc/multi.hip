@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "pdc_internal.h"
@@ -280,13 +281,13 @@ int plan_scan(GlsPlan *p, double f0, double delta, int64_t nf, int fit_mean, int
         double *out = (double *)d.pow[g] + (int64_t)i * slab;
         if (s.count < slab)
             PDC_HIP(hipMemsetAsync(out + s.count, 0, (size_t)((slab - s.count) * 8), d.compute));
-        if (i == 0) PDC_HIP(hipEventRecord(d.k0, d.compute));
+        PDC_HIP(hipEventRecord(d.k0, d.compute));
         if (s.count > 0)
             PDC_TRY(pdc_gls_scan_dev(d.device, d.compute, (double *)d.t, (double *)d.y,
                                      p->has_dy ? (double *)d.dy : nullptr, nullptr, p->n, 1, 0, f0,
                                      delta, s.begin, s.count, fit_mean, psd, out, nullptr, nullptr, d.work,
                                      p->work_cap));
-        if (i == 0) PDC_HIP(hipEventRecord(d.k1, d.compute));
+        PDC_HIP(hipEventRecord(d.k1, d.compute));
         if (p->exchange != EX_NONE) {
             PDC_HIP(hipEventRecord(d.scanned[g], d.compute));
             PDC_HIP(hipStreamWaitEvent(d.comm, d.scanned[g], 0));
@@ -407,6 +408,22 @@ int pdc_gls_plan_kernel_ms(void *plan, float *ms) {
     PDC_TRY(use_device(p->dev[0].device));
     PDC_HIP(hipEventSynchronize(p->dev[0].k1));
     PDC_HIP(hipEventElapsedTime(ms, p->dev[0].k0, p->dev[0].k1));
+    return PDC_OK;
+}
+
+int pdc_gls_plan_slot_ms(void *plan, float *ms_out, int n_slots) {
+    PDC_REQUIRE(plan && ms_out, "gls_plan_slot_ms: NULL argument");
+    GlsPlan *p = static_cast<GlsPlan *>(plan);
+    std::lock_guard<std::mutex> lk(p->mu);
+    PDC_REQUIRE(p->timed, "gls_plan_slot_ms: no scan has been enqueued");
+    PDC_REQUIRE(n_slots == (int)p->dev.size(), "gls_plan_slot_ms: the plan has %d slots, not %d", (int)p->dev.size(),
+                n_slots);
+    for (int i = 0; i < n_slots; ++i) {
+        PlanDev &d = p->dev[i];
+        PDC_TRY(use_device(d.device));
+        PDC_HIP(hipEventSynchronize(d.k1));
+        PDC_HIP(hipEventElapsedTime(&ms_out[i], d.k0, d.k1));
+    }
     return PDC_OK;
 }
 
@@ -545,15 +562,9 @@ int phase_upload(PhasePlan *p, const double *t, const double *v, int64_t n) {
 // kind 0 = PDM (v = x), 1 = AoV (v = x; nb phase bins), 2 = conditional entropy (v = magnitude bins; nb x nc
 // cells), 3 = StringLength (v = m), 4 = Gregory-Loredo (v unused; nb = m * offsets fine bins, nc = m).  Enqueues on every slot: its slab of the trial periods H2D, the scan,
 // the slab of results D2H into the page-locked result block - and returns.
-int phase_scan(PhasePlan *p, int kind, const double *periods, int64_t n_periods, int nb, int nc, double sigma) {
-    PDC_REQUIRE(kind >= 0 && kind <= 4, "phase_plan_scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional "
-                                        "entropy), 3 (StringLength) or 4 (Gregory-Loredo)");
-    PDC_REQUIRE((periods || n_periods == 0) && n_periods >= 0, "phase_plan_scan: bad period grid");
+int phase_scan_enqueue(PhasePlan *p, int kind, const double *periods, int64_t n_periods, int nb, int nc,
+                       double sigma) {
     const int nd = (int)p->slot.size();
-    PDC_TRY(phase_wait(p));   // the period / result staging blocks of the previous scan are free after this
-    p->n_periods = n_periods;
-    p->scanned = true;
-    for (DevSlot &s : p->slot) s.timed = false;
     if (n_periods == 0) return PDC_OK;
     PDC_TRY(ensure(p->pin_per, n_periods * 8));
     PDC_TRY(ensure(p->pin_out, n_periods * 8));
@@ -580,6 +591,28 @@ int phase_scan(PhasePlan *p, int kind, const double *periods, int64_t n_periods,
         s.timed = true;
         PDC_HIP(hipMemcpyAsync(po + sb.begin, s.b[B_OUT].p, sb.count * 8, hipMemcpyDeviceToHost, s.stream));
     }
+    return PDC_OK;
+}
+
+// A scan counts as pending only once EVERY slot has been enqueued: a failure half-way drains what is in
+// flight (copies from / into the staging blocks) and leaves the plan with nothing to download.
+int phase_scan(PhasePlan *p, int kind, const double *periods, int64_t n_periods, int nb, int nc, double sigma) {
+    PDC_REQUIRE(kind >= 0 && kind <= 4, "phase_plan_scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional "
+                                        "entropy), 3 (StringLength) or 4 (Gregory-Loredo)");
+    PDC_REQUIRE((periods || n_periods == 0) && n_periods >= 0, "phase_plan_scan: bad period grid");
+    PDC_TRY(phase_wait(p));   // the period / result staging blocks of the previous scan are free after this
+    p->scanned = false;
+    for (DevSlot &s : p->slot) s.timed = false;
+    const int rc = phase_scan_enqueue(p, kind, periods, n_periods, nb, nc, sigma);
+    if (rc != PDC_OK) {
+        const std::string why = pdc_last_error();
+        (void)phase_wait(p);
+        for (DevSlot &s : p->slot) s.timed = false;
+        set_error("%s", why.c_str());
+        return rc;
+    }
+    p->n_periods = n_periods;
+    p->scanned = true;
     return PDC_OK;
 }
 
@@ -754,7 +787,8 @@ int pdc_gls_scan_batch_multi(const double *t, const double *y, const double *dy,
                              int psd, double *power_out, double *amax_out, int64_t *argmax_out,
                              const int *devices, int n_devices) {
     PDC_REQUIRE(t && y && offsets && devices, "gls_batch_multi: NULL argument");
-    PDC_REQUIRE(n_curves >= 1 && nf >= 0, "gls_batch_multi: negative size");
+    PDC_REQUIRE(n_curves >= 1, "gls_batch_multi: a batch holds at least one curve (n_curves = %lld)", (long long)n_curves);
+    PDC_REQUIRE(nf >= 0, "gls_batch_multi: negative size");
     PDC_REQUIRE(power_out || amax_out || argmax_out, "gls_batch_multi: no output requested");
     PDC_REQUIRE(offsets[0] == 0, "gls_batch_multi: offsets[0] must be 0");
     for (int64_t b = 0; b < n_curves; ++b) {
@@ -771,7 +805,9 @@ int pdc_gls_scan_batch_multi(const double *t, const double *y, const double *dy,
     std::vector<std::vector<int64_t>> rebased_of((size_t)nd);   // alive until the final wait
     // launches first, on every slot; the results come back afterwards (a copy into the caller's pageable
     // arrays blocks the host until that slot is done, and issued inside this loop it would run the
-    // devices one after another)
+    // devices one after another).  Whatever fails half-way, every slot already enqueued is drained before
+    // the call returns: the copies read `rebased_of` and the caller's arrays.
+    auto enqueue = [&]() -> int {
     for (int i = 0; i < nd; ++i) {
         const Slab sb = slab_of(n_curves, nd, i);
         if (sb.count == 0) continue;
@@ -816,6 +852,15 @@ int pdc_gls_scan_batch_multi(const double *t, const double *y, const double *dy,
             PDC_HIP(hipMemcpyAsync(amax_out + sb.begin, s.b[B_AMAX].p, sb.count * 8, hipMemcpyDeviceToHost, s.stream));
         if (argmax_out)
             PDC_HIP(hipMemcpyAsync(argmax_out + sb.begin, s.b[B_ARG].p, sb.count * 8, hipMemcpyDeviceToHost, s.stream));
+    }
+    return PDC_OK;
+    };
+    const int rc = enqueue();
+    if (rc != PDC_OK) {
+        const std::string why = pdc_last_error();
+        (void)phase_wait(p);
+        set_error("%s", why.c_str());
+        return rc;
     }
     return phase_wait(p);
 }

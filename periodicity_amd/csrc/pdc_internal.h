@@ -33,11 +33,23 @@ int pinned_alloc(void **hptr, int64_t bytes);
 // streams never share a buffer.  (Stream-ordered pool memory - hipMallocAsync - is NOT used: on ROCm 7.2 a
 // block handed out again by the pool gave kernels of the next call stale partial results unless the block
 // was memset first)  Released by pdc_release(); the entry of a stream handed to
-// pdc_stream_destroy() goes with it, and the table is capped (kScratchEntries, oldest first) so that a
-// caller cycling through raw HIP streams cannot grow it without bound.  Entry points that take an
+// pdc_stream_destroy() goes with it, and a device's entries are capped (kScratchPerDevice, true LRU) so that
+// a caller cycling through raw HIP streams cannot grow the table without bound - but only entries that are
+// not pinned and whose stream has run dry are ever evicted.  stream_scratch() returns the block PINNED; the
+// caller unpins it (stream_scratch_done, or the ScratchPin guard) once all launches that use it are enqueued:
+// from then on the stream itself is busy until they have run.  Entry points that take an
 // explicit workspace (pdc_phase_scan_dev, pdc_gls_scan_dev, pdc_stringlength_scan_dev) never come here.
 int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr);
+void stream_scratch_done(int device, hipStream_t stream);
 int drop_stream_scratch(int device, hipStream_t stream);
+struct ScratchPin {   // unpins on scope exit (also on the error returns of PDC_TRY / PDC_HIP)
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool held = false;
+    ~ScratchPin() {
+        if (held) stream_scratch_done(device, stream);
+    }
+};
 
 // The phase-fold statistics with an explicit workspace (pdm.hip): kind 0 = PDM theta, 1 = AoV,
 // 2 = conditional entropy.  work == NULL falls back to stream_scratch().

@@ -652,11 +652,15 @@ int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t,
         a.n_stat = sh.n_stat;
         PDC_TRY(allow_lds(pdm_finish_kernel));
         void *spv = work;
+        ScratchPin pin;
         if (work) {
             PDC_REQUIRE(work_bytes >= sh.bytes, "phase scan: workspace too small (%lld < %lld bytes)",
                         (long long)work_bytes, (long long)sh.bytes);
         } else {   // cached per (device, stream): see pdc_internal.h on why not hipMallocAsync
             PDC_TRY(stream_scratch(device, st, sh.bytes, &spv));
+            pin.device = device;
+            pin.stream = st;
+            pin.held = true;
         }
         char *const sp = static_cast<char *>(spv);
         // PDC_PDM_POISON=1 fills the scratch with a NaN pattern first (debugging aid: every word the kernels
@@ -770,7 +774,8 @@ int phase_stat_host(int kind, const double *t, const double *x, int64_t n, const
     const int64_t wb = phase_stat_work_bytes(kind, n, n_periods, nb < 1 ? 1 : nb, nc < 1 ? 1 : nc);
     PDC_TRY(cached(device, SLOT_WORK, wb > 0 ? wb : 0, &d_work));
     PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
-    PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_x));
+    d_x = nullptr;   // (Gregory-Loredo bins arrival times only: no values, no buffer, no statistics pass over them)
+    if (x) PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_x));
     PDC_TRY(cached(device, SLOT_IN2, n_periods * 8, &d_p));
     PDC_TRY(cached(device, SLOT_OUT0, n_periods * 8, &d_th));
     hipStream_t st = nullptr;

@@ -99,10 +99,11 @@ struct StreamScratch {
     hipStream_t stream;
     void *buf;
     int64_t cap;
+    int pins;   // callers between stream_scratch() and stream_scratch_done(): their launches are not enqueued yet
 };
 static std::mutex g_scratch_mutex;
-static std::vector<StreamScratch> g_scratch;   // oldest entry first
-constexpr size_t kScratchEntries = 16;
+static std::vector<StreamScratch> g_scratch;   // least recently used entry first
+constexpr size_t kScratchPerDevice = 64;
 
 // (the caller holds g_scratch_mutex) hipFree synchronises the device: no kernel still uses the block
 static int free_scratch_entry(size_t i) {
@@ -118,6 +119,16 @@ static int free_scratch_entry(size_t i) {
     return PDC_OK;
 }
 
+// An entry may go only when nobody can still be using it: no caller holds it pinned (its launches would come
+// AFTER the free) and its stream has run dry (or no longer exists).
+static bool scratch_entry_idle(const StreamScratch &s) {
+    if (s.pins > 0) return false;
+    const hipError_t q = hipStreamQuery(s.stream);
+    if (q != hipSuccess) (void)hipGetLastError();
+    return q != hipErrorNotReady;
+}
+
+// The block comes back PINNED: call stream_scratch_done() once every launch that uses it has been enqueued.
 int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
     std::lock_guard<std::mutex> lk(g_scratch_mutex);
     if (bytes < 256) bytes = 256;
@@ -125,13 +136,26 @@ int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
     for (size_t i = 0; i < g_scratch.size(); ++i)
         if (g_scratch[i].device == device && g_scratch[i].stream == stream) at = i;
     if (at == g_scratch.size()) {
-        // a stream handle this table has not seen: the caller may be cycling through transient streams
-        // (and HIP may never hand the same address out again), so the table is bounded - oldest goes
-        while (g_scratch.size() >= kScratchEntries) PDC_TRY(free_scratch_entry(0));
-        g_scratch.push_back({device, stream, nullptr, 0});
-        at = g_scratch.size() - 1;
+        // a stream handle this table has not seen: the caller may be cycling through transient streams (and
+        // HIP may never hand the same address out again), so a device's entries are bounded - the least
+        // recently used IDLE one goes; entries in use are never freed, the table rather grows
+        size_t mine = 0;
+        for (const StreamScratch &e : g_scratch) mine += e.device == device;
+        for (size_t i = 0; mine >= kScratchPerDevice && i < g_scratch.size();) {
+            if (g_scratch[i].device == device && scratch_entry_idle(g_scratch[i])) {
+                PDC_TRY(free_scratch_entry(i));
+                --mine;
+            } else {
+                ++i;
+            }
+        }
+        g_scratch.push_back({device, stream, nullptr, 0, 0});
+    } else if (at + 1 != g_scratch.size()) {   // a hit moves to the back: true LRU order
+        const StreamScratch hit = g_scratch[at];
+        g_scratch.erase(g_scratch.begin() + (long)at);
+        g_scratch.push_back(hit);
     }
-    StreamScratch *e = &g_scratch[at];
+    StreamScratch *e = &g_scratch.back();
     if (e->cap < bytes) {
         if (e->buf) PDC_HIP(hipFree(e->buf));   // (synchronises the device: no kernel still uses it)
         e->buf = nullptr;
@@ -140,8 +164,15 @@ int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
         PDC_TRY(device_alloc(&e->buf, want));
         e->cap = want;
     }
+    ++e->pins;
     *dptr = e->buf;
     return PDC_OK;
+}
+
+void stream_scratch_done(int device, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_scratch_mutex);
+    for (StreamScratch &e : g_scratch)
+        if (e.device == device && e.stream == stream && e.pins > 0) --e.pins;
 }
 
 int drop_stream_scratch(int device, hipStream_t stream) {

@@ -771,6 +771,7 @@ struct FastArgs {
     unsigned short *gbucket;    // [grid][2 n_pad]   coarse bucket of every sample, written by P1 (several slices)
     int slice_cap;              // samples per LDS slice (several slices)
     const unsigned char *todo;  // NULL, or [n_periods]: only periods with a non-zero entry are worked off
+    const unsigned *todo_count; // (with todo) how many entries are non-zero: 0 ends every workgroup at once
 };
 
 // RN(t / period) without the division: y = RN(1 / period); q0 = RN(t y) is within 1.5 ulp of the
@@ -940,6 +941,8 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
     unsigned short *gb = MULTI ? a.gbucket + (int64_t)blockIdx.x * a.n_pad * 2 : nullptr;
     static_assert(!MULTI || NB <= 65536, "bucket ids are kept as 16-bit numbers");
 
+    // the usual case behind sl_duo_kernel: nothing was left over - no walk over todo[], no LDS set-up
+    if (a.todo && *a.todo_count == 0u) return;
     for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
         if (a.todo && !a.todo[p]) continue;   // (workgroup-uniform)
         const double period = a.periods[p];
@@ -1354,7 +1357,7 @@ struct DuoArgs {
     const unsigned *flags;      // [0] != 0: every t is 0 or 1e-150 <= |t| <= 1e150
     int n;
     int64_t n_periods;
-    unsigned *ticket;           // next period (zeroed before the launch)
+    unsigned *ticket;           // [0] next period, [1] periods marked in todo[] (both zeroed before the launch)
     double *ell;
     unsigned char *todo;        // [n_periods]: 1 = left to the one-workgroup kernel
     double *rsum;               // [grid][nr_pad][4]
@@ -1576,7 +1579,8 @@ __global__ __launch_bounds__(BLK, 4) void sl_duo_kernel(DuoArgs a) {
             double sum = 0.0;
             for (int w = 0; w < kW; ++w) sum += red[w];
             a.todo[p] = s_bad ? 1 : 0;
-            if (!s_bad) a.ell[p] = sum;
+            if (s_bad) atomicAdd(&a.ticket[1], 1u);
+            else a.ell[p] = sum;
         }
     }
 }
@@ -1654,6 +1658,7 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
                 "stringlength: NULL argument");
     PDC_REQUIRE(n >= 0 && n_periods >= 0, "stringlength: negative size");
     PDC_REQUIRE(n < ((int64_t)1 << 31), "stringlength: at most 2^31-1 samples");
+    PDC_REQUIRE(n_periods < ((int64_t)1 << 32), "stringlength: at most 2^32-1 trial periods per call");
     PDC_REQUIRE(work && work_bytes >= pdc_stringlength_work_bytes(n, n_periods),
                 "stringlength: workspace too small");
     if (n_periods == 0) return PDC_OK;
@@ -1707,6 +1712,7 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
         const int k = (int)((n + kBlock - 1) / kBlock);
         f.slice_cap = fast::FL<unsigned>::capacity;
         f.todo = nullptr;
+        f.todo_count = nullptr;
         // Two workgroups per CU (sl_duo_kernel) whenever a period's permutation fits half of LDS;
         // PDC_SL_DUO=0 keeps the one-workgroup kernel (A/B, tests)
         static const bool duo_on = [] { const char *e = getenv("PDC_SL_DUO"); return !(e && e[0] == '0'); }();
@@ -1732,13 +1738,14 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
             const bool quad = quad_on && n <= duo::kCapQ;   // four 256-thread workgroups per CU
             int64_t dgrid = (quad ? 4 : 2) * (int64_t)cu_count(device);
             dgrid = dgrid < grid ? dgrid : grid;       // (the range scratch is laid out for `grid` workgroups)
-            PDC_HIP(hipMemsetAsync(d.ticket, 0, 4, st));
+            PDC_HIP(hipMemsetAsync(d.ticket, 0, 8, st));
             const int kd = (int)((n + duo::kB - 1) / duo::kB);
             if (quad) PDC_TRY((launch_duo<16, 256, 512>(d, dgrid, st)));
             else if (kd <= 16) PDC_TRY(launch_duo<16>(d, dgrid, st));
             else if (kd <= 36) PDC_TRY(launch_duo<36>(d, dgrid, st));
             else PDC_TRY(launch_duo<52>(d, dgrid, st));
             f.todo = todo;   // the periods the duo kernel marked (clustered phases) go through the one-slice kernel
+            f.todo_count = d.ticket + 1;
         }
         if (n > fast::kCapacity) PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true>(f, grid, st)));
         else if (k <= 8) PDC_TRY(launch_fast<8>(f, grid, st));

@@ -100,13 +100,13 @@ class GLS(object):
         if self.method == "fft":
             # the reference's own extirpolation + FFT evaluation of the trig sums, on the device
             df, fmin, _ = self._grid_scalars(signal)
-            dev = self.device if self.devices is None else self.devices[0]
+            dev = _cabi.pick_device(self.device, self.devices)
             power = _cabi.gls_scan_fft(t, y, dy, fmin, df, nf, fit_mean, self.psd, device=dev)
         elif self.devices is not None and len(self.devices) > 1:
             power = _cabi.gls_scan_multi(t, y, dy, f0, delta, nf, fit_mean, self.psd,
                                          self.devices)
         else:
-            dev = self.device if self.devices is None else self.devices[0]
+            dev = _cabi.pick_device(self.device, self.devices)
             power = _cabi.gls_scan(t, y, dy, f0, delta, nf, fit_mean, self.psd, device=dev)
         self.signal = signal
         self.periodogram = FSeries(self.frequency, power)

@@ -6,7 +6,7 @@ import socket
 import numpy as np
 import pytest
 
-from periodicity_amd.distributed import slab_bounds
+from tools.torchrun_sharded import slab_bounds
 
 
 def test_slab_bounds_cover_the_grid_once():
@@ -40,7 +40,7 @@ def _worker(rank, world, port, n_grid, out_dir):
     import torch.distributed as dist
 
     from oracle import scan_oracle as so
-    from periodicity_amd.distributed import sharded_scan
+    from tools.torchrun_sharded import sharded_scan
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -59,7 +59,7 @@ def _worker(rank, world, port, n_grid, out_dir):
 
     full = sharded_scan(compute, n_grid).numpy()
     # the period-sweep wrapper (PDM / StringLength shape) with the oracle as the per-slab scan
-    from periodicity_amd.distributed import sharded_periods
+    from tools.torchrun_sharded import sharded_periods
     periods = np.linspace(1.0, 40.0, n_grid)
     theta = sharded_periods(lambda p, dev: so.pdm_scan(t, y, p, 5, 2), periods)
     np.save(os.path.join(out_dir, f"theta{rank}.npy"), theta)

@@ -298,7 +298,7 @@ def test_persistent_plan_repeated_scans_and_validation():
 
 
 def test_sharded_gls_gathers_the_device_slab_over_rccl():
-    """periodicity_amd.distributed.sharded_gls under a one-rank nccl (RCCL) group: the slab is
+    """tools/torchrun_sharded.py:sharded_gls under a one-rank nccl (RCCL) group: the slab is
     written by pdc_gls_scan_dev into a device tensor and all-gathered there."""
     import subprocess
     import sys
@@ -467,6 +467,31 @@ def test_full_size_c3_batch_peaks_only():
         assert 0 <= hi < idx[b] <= lo < nf and lo - hi < 40       # the half-maximum width of the main peak
 
 
+def test_c1_exactly_as_baseline_defines_it():
+    """BASELINE configs[0] (C1): 1k samples x 1k frequencies on SURVEY 8d's grid and seed.  Upstream it is the
+    CPU-plumbing config (its CPU leg is in bench.py's cpu_baseline); here the same inputs go through the HIP
+    path: Tier E against the long-double sums at every bin, Tier R (peak bin) against the FFT-path
+    restatement of the reference, and the FFT path on the device against that restatement."""
+    n = nf = 1000
+    rng = np.random.default_rng(20241008 + 1)
+    t = np.sort(rng.uniform(0, float(n), n))
+    dy = rng.uniform(0.05, 0.2, n)
+    y = 1.0 + 0.5 * np.sin(2 * np.pi * t / 37.3) + dy * rng.standard_normal(n)
+    df = 1.0 / (t[-1] - t[0]) / 5
+    fmin = 0.5 * df
+    freq = np.arange(fmin, fmin + (nf - 1.5) * df + df, df)
+    assert freq.size == nf
+    ls = GLS(fmin=fmin, fmax=fmin + (nf - 1.5) * df)(TSeries(t, y), err=dy)
+    assert np.array_equal(ls.frequency, freq)
+    exact = np.asarray(co.gls_power_exact(t, y, dy, freq))
+    assert_tier_e(ls.values, exact)
+    ref = so.gls_power(t, y, dy, freq, df, fmin, True, False, sums="fft")
+    assert ls.argmax() == int(np.argmax(exact)) == int(np.nanargmax(ref))
+    assert ls.period_at_highest_peak == 1 / freq[int(np.nanargmax(ref))]
+    fft = GLS(fmin=fmin, fmax=fmin + (nf - 1.5) * df, method="fft")(TSeries(t, y), err=dy)
+    assert np.max(np.abs(fft.values - ref)) <= 1e-9 * np.abs(ref).max()
+
+
 def test_full_size_c4_on_one_gpu_both_paths():
     """BASELINE configs[3] (N=1e6 x nf=1e7 = 1e13 pairs) on ONE GPU: the grid in 8 slabs exactly as
     the 8-GPU run shards it, cross-checked against the FFT path (which reproduces the reference's own
@@ -480,6 +505,16 @@ def test_full_size_c4_on_one_gpu_both_paths():
     power = np.concatenate([_cabi.gls_scan(t, y, dy, f0, delta, slab, j_begin=r * slab)
                             for r in range(world)])
     assert power.shape == (nf,) and np.all(np.isfinite(power))
+    # the same sharding through the persistent plan the 8-GPU run uses (8 logical slots on this one device,
+    # the all-gather as device copies - what `bench.py --loopback 8` reports as c4_sharded): every slot
+    # must end up holding exactly the slab-wise array
+    plan = _cabi.GlsPlan([0], n, nf, loopback_slots=world)
+    plan.upload(t, y, dy)
+    plan.scan(f0, delta, nf)
+    for which in (0, 3, world - 1):
+        assert np.array_equal(plan.download(which), power), f"loopback-8 plan, slot {which}"
+    assert len(plan.slot_ms()) == world and min(plan.slot_ms()) > 0
+    plan.close()
     fft = _cabi.gls_scan_fft(t, y, dy, fmin, df, nf)
     peak = int(np.argmax(power))
     assert peak == int(np.argmax(fft))                                   # tier R at the largest config

@@ -204,13 +204,14 @@ def test_aov_and_entropy_host_rules(oracle_backend):
 
 
 def test_package_imports_and_runs_host_logic_without_torch():
-    """torch is optional plumbing of periodicity_amd.distributed only: the callables, the containers
-    and the ctypes binding import with torch made unimportable."""
+    """Nothing in the package needs torch (the one-rank-per-GPU launcher glue lives in tools/torchrun_sharded.py):
+    the callables, the containers and the ctypes binding import with torch made unimportable."""
     import subprocess
     import sys
     code = ("import sys; sys.modules['torch'] = None\n"
             "import periodicity_amd\n"
-            "from periodicity_amd import _cabi, core, phase, spectral, distributed\n"
+            "from periodicity_amd import _cabi, core, phase, spectral\n"
+            "from tools import torchrun_sharded as distributed\n"
             "assert 'torch' not in [m for m in sys.modules if sys.modules[m] is not None]\n"
             "print(distributed.slab_bounds(10, 3, 2), spectral.LombScargle.__name__, phase.AOV.__name__)\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,

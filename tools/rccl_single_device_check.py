@@ -1,7 +1,7 @@
 """Child-process checks of the collectives on ONE device (run by tests/test_gls_gpu.py).
 
     PDC_FORCE_RCCL=1 python tools/rccl_single_device_check.py         # pdc_gls_scan_multi + plan, RCCL forced
-    python tools/rccl_single_device_check.py torch                    # distributed.sharded_gls, 1-rank nccl group
+    python tools/rccl_single_device_check.py torch                    # torchrun_sharded.sharded_gls, 1-rank nccl group
 """
 import os
 import sys
@@ -27,7 +27,7 @@ y = np.sin(t / 3) + dy * rng.standard_normal(500)
 f0, delta, nf = 0.001, 0.0007, 3001
 a = _cabi.gls_scan(t, y, dy, f0, delta, nf)
 if TORCH:
-    from periodicity_amd.distributed import sharded_gls
+    from tools.torchrun_sharded import sharded_gls
     b = sharded_gls(t, y, dy, f0, delta, nf)
     print("sharded_gls equal:", np.array_equal(a, b))
     dist.destroy_process_group()

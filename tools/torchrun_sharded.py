@@ -8,11 +8,12 @@ all-gather of the result array (RCCL over xGMI when the process group's backend 
 ``/root/reference/src/periodicity/phase.py:69-70,185-186`` — has the same shape with pickling
 instead of a collective.
 
-torch is OPTIONAL plumbing: it is imported lazily, only inside the functions of this module, and
-provides rendezvous and the collective, never compute; ``spectral.py`` / ``phase.py`` / ``_cabi.py`` do
-not import it (``tests/test_host_api.py`` imports the package with torch blocked).  The torch-free
-alternative - one process driving N devices with RCCL directly - is the persistent plan
-``pdc_gls_plan_*`` / ``pdc_gls_scan_multi`` in ``csrc/multi.hip`` (``_cabi.GlsPlan``, ``GLS(devices=...)``).
+NOT part of the product package: this is launcher-side plumbing for jobs that are started as one process
+per GPU (``torch.distributed.run``, as the bench driver does).  torch provides rendezvous and the
+collective, never compute, and nothing under ``periodicity_amd/`` imports torch
+(``tests/test_host_api.py`` imports the package with torch blocked).  The product's multi-GPU path - one
+process driving N devices with RCCL directly - is the persistent plan ``pdc_gls_plan_*`` /
+``pdc_gls_scan_multi`` in ``csrc/multi.hip`` (``_cabi.GlsPlan``, ``GLS(devices=...)``).
 A process that uses both must initialise torch's GPU context (``torch.cuda.set_device``) BEFORE the
 first scan call: the torch wheel carries its own HIP runtime, and the one loaded first serves both.
 """
@@ -81,7 +82,7 @@ def sharded_gls(t, y, dy, f0, delta, nf, fit_mean=True, psd=False, device=None, 
     import torch
     import torch.distributed as dist
 
-    from . import _cabi
+    from periodicity_amd import _cabi
     on_host = dist.get_backend(group) == "gloo"
     if device is None:
         device = _cabi.default_device() if on_host else torch.cuda.current_device()
@@ -132,7 +133,7 @@ def sharded_periods(scan, periods, device=None, group=None):
 
 def sharded_pdm(t, x, periods, nb=5, nc=2, sigma=None, device=None, group=None):
     """theta for every trial period, period grid sharded over the ranks of ``group``."""
-    from . import _cabi
+    from periodicity_amd import _cabi
     sigma = np.var(x, ddof=1) if sigma is None else sigma
     return sharded_periods(lambda p, dev: _cabi.pdm_scan(t, x, p, nb, nc, sigma, device=dev),
                            periods, device, group)
@@ -140,6 +141,6 @@ def sharded_pdm(t, x, periods, nb=5, nc=2, sigma=None, device=None, group=None):
 
 def sharded_stringlength(t, m, periods, device=None, group=None):
     """String length for every trial period, period grid sharded over the ranks of ``group``."""
-    from . import _cabi
+    from periodicity_amd import _cabi
     return sharded_periods(lambda p, dev: _cabi.stringlength_scan(t, m, p, device=dev),
                            periods, device, group)
