@@ -28,11 +28,12 @@ The product path is the C ABI (libperiodicity_hip.so).  ``oracle/`` is touched o
 ``cpu_baseline`` legs, after the clock has stopped.
 
 Every roofline figure in the line means one of two things, and says which:
-  * ``executed_issue_frac``: VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, read from
-    profiles/r03_pmc_summary.json, which tools/pmc_summary.py wrote for the kernel sources whose hash it
-    records - a summary of other sources is refused) x 4 cycles / 1024 SIMDs / 2.4 GHz / the HIP-event
-    time of this run: the fraction of the fp64 vector issue slots the kernel filled (an upper bound
-    where the mix holds 32-bit instructions, which issue in fewer cycles);
+  * ``executed_issue_frac``: VALU issue cycles per launch / 1024 SIMDs / 2.4 GHz / the HIP-event time of this
+    run, the cycles priced BY INSTRUCTION TYPE from rocprofv3's typed counters (profiles/r04_pmc_summary.json,
+    written by tools/pmc_summary.py for the kernel sources whose hash it records - a summary of other sources
+    is refused): the fp64 / int64 classes (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, _INT64) at 4 cycles per
+    wave64 instruction, every other VALU instruction at 2 (SIMD-32); ``executed_issue.frac_all_at_4_cycles`` is
+    the round-3 figure (everything at 4 cycles, an upper bound) and ``executed_issue.mix`` the counts;
   * ``algorithmic_frac``: SURVEY.md 8d's per-unit work (50 flop per GLS pair, 40 per PDM pair, one
     gathered record per StringLength pair, 8 B per spectrum bin) x units / time / the peak it is priced
     against.  It may exceed 1 where the kernel does less work than the unit assumes (rotation
@@ -55,13 +56,17 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR = 50.0            # algorithmic fp64 flop per (sample, frequency) pair
 PEAK_FP64_VECTOR_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz (MI355X, spec)
-SIMDS, CLOCK_HZ, FP64_ISSUE_CYCLES = 1024, 2.4e9, 4
+SIMDS, CLOCK_HZ, FP64_ISSUE_CYCLES, B32_ISSUE_CYCLES = 1024, 2.4e9, 4, 2
+# rocprofv3 counters of the VALU mix (tools/collect_pmc.sh, passes mix64 / mix32): a wave64 fp64 arithmetic
+# instruction occupies its SIMD-32 for 4 cycles, a 32-bit one for 2 (MI355X_MICROARCH.md: `v_fma_f32` (wave64) 2 cyc)
+F64_COUNTERS = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+                "SQ_INSTS_VALU_INT64")
 PDM_FLOP_PER_PAIR = 40.0
 SL_MODEL_BYTES_PER_PAIR = 48.0  # HBM bucket-pass model
 HBM_PEAK_TBS = 8.0
 N_SAMPLES = 100_000
 NF_PER_GPU = 1_000_000
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
 GATHER_UBENCH = os.path.join(ROOT, "profiles", "r03_ubench_gather_rate.json")
 
 
@@ -167,16 +172,31 @@ def valu_issue_block(kernel_substr, kernel_ms):
     k, why = pmc_for(kernel_substr, kernel_ms)
     if k is None:
         return None, why
-    busy_s = k["SQ_INSTS_VALU"] * FP64_ISSUE_CYCLES / SIMDS / CLOCK_HZ
-    out = {"kernel": k["name"], "valu_wave_instr_per_launch": k["SQ_INSTS_VALU"],
+    # issue cycles by instruction type: the typed fp64 / int64 classes at 4 cycles, every other VALU instruction
+    # at 2.  The classes the counters do not name (v_cmp_f64, v_floor/fract_f64, 64-bit moves ...) fall in "other" and
+    # are priced at 2: the weighted figure is a LOWER bound of the slots taken, the all-at-4 one an upper bound.
+    total = k["SQ_INSTS_VALU"]
+    have_mix = all(c in k for c in F64_COUNTERS)
+    n64 = sum(k[c] for c in F64_COUNTERS) if have_mix else None
+    cycles = (n64 * FP64_ISSUE_CYCLES + (total - n64) * B32_ISSUE_CYCLES) if have_mix else total * FP64_ISSUE_CYCLES
+    busy_s = cycles / SIMDS / CLOCK_HZ
+    upper_s = total * FP64_ISSUE_CYCLES / SIMDS / CLOCK_HZ
+    out = {"kernel": k["name"], "valu_wave_instr_per_launch": total,
            "frac": round(busy_s / (kernel_ms * 1e-3), 4),
+           "frac_all_at_4_cycles": round(upper_s / (kernel_ms * 1e-3), 4),
+           "priced": "typed mix: fp64/int64 classes x 4 cycles, all other VALU x 2" if have_mix
+                     else "no typed counters in the summary: every VALU instruction x 4 cycles (upper bound)",
            "profiled_ms": k["ms"], "source": os.path.relpath(PMC_SUMMARY, ROOT)}
+    if have_mix:
+        out["mix"] = {"fp64_or_int64": n64, "other": total - n64, "fp64_share": round(n64 / total, 4),
+                      **{c.replace("SQ_INSTS_VALU_", "").lower(): k[c] for c in F64_COUNTERS + ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT")
+                         if c in k}}
     if k.get("GRBM_GUI_ACTIVE"):
         # the chip is power-limited under fp64 load: the clock the PROFILED launch actually ran at (GRBM_GUI_ACTIVE
         # summed over 8 XCDs / 8 / its duration) and the issue fraction of that launch at that clock
         clk = k["GRBM_GUI_ACTIVE"] / 8.0 / (k["ms"] * 1e-3)
         out["profiled_clock_GHz"] = round(clk / 1e9, 3)
-        out["frac_at_profiled_clock"] = round(k["SQ_INSTS_VALU"] * FP64_ISSUE_CYCLES / SIMDS / clk / (k["ms"] * 1e-3), 4)
+        out["frac_at_profiled_clock"] = round(cycles / SIMDS / clk / (k["ms"] * 1e-3), 4)
     for key in ("hbm_bytes", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_LDS_BANK_CONFLICT",
                 "SQ_LDS_IDX_ACTIVE", "TCP_TCC_READ_REQ_sum"):
         if key in k:
@@ -191,7 +211,8 @@ def two_fracs(kernel_substr, ms, algorithmic_frac, unit):
            "algorithmic_frac": None if algorithmic_frac is None else round(algorithmic_frac, 4),
            "algorithmic_unit": unit}
     if blk:
-        out["executed_issue"] = {k: blk[k] for k in ("kernel", "valu_wave_instr_per_launch", "profiled_ms", "source",
+        out["executed_issue"] = {k: blk[k] for k in ("kernel", "valu_wave_instr_per_launch", "priced", "mix",
+                                                     "frac_all_at_4_cycles", "profiled_ms", "source",
                                                      "profiled_clock_GHz", "frac_at_profiled_clock") if k in blk}
     else:
         out["executed_issue_note"] = why

@@ -105,6 +105,27 @@ int pdc_gls_scan_multi(const double *t, const double *y, const double *dy, int64
                        double f0, double delta, int64_t nf, int fit_mean, int psd,
                        double *power_out, const int *devices, int n_devices);
 
+/* GLS.bootstrap (spectral.py:140-152) with the replicates given BY INDEX.  Upstream draws
+ * `bs = rng.integers(0, ndata, ndata)` per replicate (:146) and runs a full periodogram of
+ * (values[bs], err[bs]) on the unchanged time axis, keeping only `.amax()` (:147-150).  Here the caller
+ * draws the same integers and passes them as picks[n_boot][n] (int32, row b = replicate b); only the ONE
+ * curve (t, y, dy|NULL) and the indices are uploaded, the device prologue gathers y[picks], dy[picks]
+ * while it builds the weight table of the shared-time-axis kernel.  Outputs: the NaN-aware maximum of
+ * every replicate's spectrum (amax_out[n_boot]) and/or its bin (argmax_out[n_boot]).
+ * method 0: exact direct sums on the grid f0 + j*delta; method 1: the reference's FFT/extirpolation
+ * path with fmin = f0, df = delta (first listed device only).  Replicates are dealt to the listed device
+ * slots in contiguous groups, no exchange.  Any pick outside 0 .. n-1 is PDC_ERR_INVALID. */
+int pdc_gls_bootstrap(const double *t, const double *y, const double *dy, int64_t n, const int32_t *picks,
+                      int64_t n_boot, double f0, double delta, int64_t nf, int fit_mean, int psd, int method,
+                      double *amax_out, int64_t *argmax_out, const int *devices, int n_devices);
+/* Device-resident form: inputs, picks and outputs in HBM, no synchronisation; `work` of at least
+ * pdc_gls_bootstrap_work_bytes(n, n_boot, nf) bytes on the same device. */
+int64_t pdc_gls_bootstrap_work_bytes(int64_t n, int64_t n_boot, int64_t nf);
+int pdc_gls_bootstrap_dev(int device, void *stream, const double *d_t, const double *d_y, const double *d_dy,
+                          int64_t n, const int32_t *d_picks, int64_t n_boot, double f0, double delta, int64_t nf,
+                          int fit_mean, int psd, double *d_amax, int64_t *d_argmax, void *work,
+                          int64_t work_bytes);
+
 /* The same shard + all-gather as a persistent plan for callers that scan repeatedly (bench.py, a
  * survey loop over many light curves): per-device sample/power/work buffers, two streams and the
  * events per device and the RCCL communicators (ncclCommInitAll, one process, N devices) are created
@@ -201,7 +222,7 @@ int pdc_gls_batch_highest_peak(const double *t, const double *y, const double *d
                                double f0, double delta, int64_t nf, int fit_mean, int psd,
                                int64_t *idx_out, double *val_out, int device);
 
-/* The k <= 16 highest (by_prominence == 0: FSeries.psort_by_peak, core.py:944-946) or most prominent
+/* The k <= 64 highest (by_prominence == 0: FSeries.psort_by_peak, core.py:944-946) or most prominent
  * (psort_by_prominence :948-950, period_at_highest_prominence :957-961) find_peaks() maxima of each
  * spectrum, found and ranked on the device: count[b] = number of maxima scipy.signal.find_peaks(x,
  * prominence=0.0) reports; idx/height/prominence are [n_curves][k], ranked descending, padded with

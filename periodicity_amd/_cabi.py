@@ -46,6 +46,9 @@ PROTOTYPES = {
                                 _VP, _VP, _VP, _I]),
     "pdc_gls_scan_batch_multi": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _I, _I, _VP, _VP, _VP, _VP, _I]),
     "pdc_gls_scan_multi": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _I, _I, _VP, _VP, _I]),
+    "pdc_gls_bootstrap": (_I, [_VP, _VP, _VP, _L, _VP, _L, _D, _D, _L, _I, _I, _I, _VP, _VP, _VP, _I]),
+    "pdc_gls_bootstrap_work_bytes": (_L, [_L, _L, _L]),
+    "pdc_gls_bootstrap_dev": (_I, [_I, _VP, _VP, _VP, _VP, _L, _VP, _L, _D, _D, _L, _I, _I, _VP, _VP, _VP, _L]),
     "pdc_gls_plan_create": (_I, [_VP, _I, _L, _L, C.POINTER(_VP)]),
     "pdc_gls_plan_create_loopback": (_I, [_I, _I, _L, _L, C.POINTER(_VP)]),
     "pdc_gls_plan_info": (_I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
@@ -239,6 +242,31 @@ def gls_scan_batch(t, y, dy, offsets, f0, delta, nf, fit_mean=True, psd=False, s
     return power, amax, argmax
 
 
+def gls_bootstrap(t, y, dy, picks, f0, delta, nf, fit_mean=True, psd=False, method="direct", device=None,
+                  devices=None):
+    """Maxima (and their bins) of the periodograms of the bootstrap replicates ``(y[picks[b]], dy[picks[b]])``
+    on the unchanged time axis (``pdc_gls_bootstrap``): only the curve and the int32 indices are uploaded,
+    the resampled arrays are never built.  ``method="fft"``: ``f0`` / ``delta`` are ``fmin`` / ``df``."""
+    t, y = _f64(t, "t"), _f64(y, "y")
+    dy = None if dy is None else _f64(dy, "dy")
+    picks = np.ascontiguousarray(picks, dtype=np.int32)
+    if y.size != t.size or (dy is not None and dy.size != t.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    if picks.ndim != 2 or (picks.shape[0] and picks.shape[1] != t.size):
+        raise ValueError("picks must be [n_bootstraps][n_samples]")
+    nb = picks.shape[0]
+    amax = np.empty(nb, dtype=np.float64)
+    argmax = np.empty(nb, dtype=np.int64)
+    if devices is not None and len(devices) > 0:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+    else:
+        devs = np.array([default_device() if device is None else device], dtype=np.int32)
+    check(lib().pdc_gls_bootstrap(_ptr(t), _ptr(y), _ptr(dy), t.size, _ptr(picks), nb, float(f0), float(delta),
+                                  int(nf), int(bool(fit_mean)), int(bool(psd)), 1 if method == "fft" else 0,
+                                  _ptr(amax), _ptr(argmax), _ptr(devs), devs.size))
+    return amax, argmax
+
+
 def gls_scan_multi(t, y, dy, f0, delta, nf, fit_mean=True, psd=False, devices=(0,)):
     t, y = _f64(t, "t"), _f64(y, "y")
     dy = None if dy is None else _f64(dy, "dy")
@@ -418,7 +446,7 @@ def _topk_outputs(nb, k):
 
 
 def peaks_topk(power, k=1, by_prominence=False, device=None):
-    """The ``k`` (<= 16) highest, or most prominent, ``find_peaks`` maxima of each row of ``power`` with
+    """The ``k`` (<= 64) highest, or most prominent, ``find_peaks`` maxima of each row of ``power`` with
     prominences and half-maximum crossings (``pdc_peaks_topk``); a dict of arrays shaped ``[rows, k]``
     (``count``: ``[rows]``), ranked descending, padded with -1 / NaN."""
     power = np.ascontiguousarray(power, dtype=np.float64)

@@ -87,6 +87,9 @@ struct PrepArgs {
     double *rw = nullptr;   // {w (y - ybar), w} pairs, or w (y - ybar) alone when all weights are equal
     double *tp = nullptr;   // [n] t - t0
     int64_t bpad = 0;
+    // bootstrap replicates by INDEX (spectral.py:146-148): y and dy are ONE curve of n samples, replicate b's
+    // sample i is (y[picks[b n + i]], dy[picks[b n + i]]) - the resampled arrays never exist
+    const int32_t *picks = nullptr;
 };
 
 // ---- prologue: spectral.py:99-108, 120 ------------------------------------------------------------
@@ -96,8 +99,10 @@ __global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
     const int64_t off = a.offsets ? a.offsets[blockIdx.x] : 0;
     const int64_t n = a.offsets ? a.offsets[blockIdx.x + 1] - off : a.n_total;
     const double *t = a.shared_t ? a.t : a.t + off;
-    const double *y = a.y + off;
-    const double *dy = a.dy ? a.dy + off : nullptr;
+    const int32_t *pk = a.picks ? a.picks + off : nullptr;
+    const double *y = pk ? a.y : a.y + off;
+    const double *dy = a.dy ? (pk ? a.dy : a.dy + off) : nullptr;
+    auto at = [pk](int64_t i) -> int64_t { return pk ? (int64_t)pk[i] : i; };
     double *rec = a.rec + off * 6;
     const double t0 = n > 0 ? t[0] : 0.0;
 
@@ -105,15 +110,15 @@ __global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
     if (!a.raw) {
         double acc = 0.0;  // w = err**-2 ; w.sum()
         for (int64_t i = tid; i < n; i += kPrepBlock) {
-            const double e = dy ? dy[i] : 1.0;
+            const double e = dy ? dy[at(i)] : 1.0;
             acc += 1.0 / (e * e);
         }
         W = block_sum<kPrepBlock>(acc, red);
         if (a.fit_mean) {  // np.dot(w / w.sum(), values)
             acc = 0.0;
             for (int64_t i = tid; i < n; i += kPrepBlock) {
-                const double e = dy ? dy[i] : 1.0;
-                acc += (1.0 / (e * e)) / W * y[i];
+                const double e = dy ? dy[at(i)] : 1.0;
+                acc += (1.0 / (e * e)) / W * y[at(i)];
             }
             ybar = block_sum<kPrepBlock>(acc, red);
         }
@@ -122,9 +127,9 @@ __global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
     if (a.rw) {
         // shared time axis: no per-curve records, only this curve's column of the weight table
         for (int64_t i = tid; i < n; i += kPrepBlock) {
-            const double e = dy ? dy[i] : 1.0;
+            const double e = dy ? dy[at(i)] : 1.0;
             const double w = (1.0 / (e * e)) / W;
-            const double yc = y[i] - ybar;
+            const double yc = y[at(i)] - ybar;
             const double wy = w * yc;
             yy += wy * yc;
             wsum += w;
@@ -137,12 +142,12 @@ __global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
         const double tp = t[i] - t0;
         double w, wy;
         if (a.raw) {
-            w = y[i];  // the caller's weights, used as given (spectral.py:13-15)
+            w = y[at(i)];  // the caller's weights, used as given (spectral.py:13-15)
             wy = w;
         } else {
-            const double e = dy ? dy[i] : 1.0;
+            const double e = dy ? dy[at(i)] : 1.0;
             w = (1.0 / (e * e)) / W;
-            const double yc = y[i] - ybar;
+            const double yc = y[at(i)] - ybar;
             wy = w * yc;
             yy += wy * yc;
             wsum += w;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(kPrepBlock) void gls_prep_kernel(PrepArgs a) {
         sincos_cycles(frac_product(a.delta, tp), sd, cd);
         if (!a.raw) {  // the kernel carries sqrt(w) sin / sqrt(w) cos
             w = sqrt(w);
-            wy = w * (y[i] - ybar);
+            wy = w * (y[at(i)] - ybar);
         }
         double2 *r = reinterpret_cast<double2 *>(rec + i * 6);
         r[0] = make_double2(wy, w);
@@ -955,8 +960,9 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
              const int64_t *d_offsets, int64_t n_total, int64_t n_curves, int shared_t, double f0,
              double delta, int64_t j_begin, int64_t nf, int mode, int psd, double *d_power,
              double *d_raw_s, double *d_raw_c, double *d_amax, int64_t *d_argmax, void *work,
-             int64_t work_bytes) {
+             int64_t work_bytes, const int32_t *d_picks = nullptr) {
     PDC_REQUIRE(d_t && d_y, "gls: t and y must not be NULL");
+    PDC_REQUIRE(!d_picks || (shared_t && d_offsets && mode != MODE_RAW), "gls: picks need a shared time axis");
     PDC_REQUIRE(n_total >= 0 && n_curves >= 1 && nf >= 0 && j_begin >= 0, "gls: negative size");
     PDC_REQUIRE(n_curves == 1 || d_offsets, "gls: a batch needs offsets");
     PDC_REQUIRE(n_curves * ((nf + 255) / 256 + 1) < (int64_t)1 << 31, "gls: grid too large");
@@ -979,6 +985,7 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     p.delta = delta;
     p.rec = reinterpret_cast<double *>(base + w.rec);
     p.scal = reinterpret_cast<double *>(base + w.scal);
+    p.picks = d_picks;
     const bool peaks = d_amax || d_argmax;
 
     // Batches on one time axis: share the trigonometry between curves (gls_shared_kernel) when
@@ -1034,7 +1041,7 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
             return PDC_OK;
         }
     }
-    if (n_curves == 1 && mode != MODE_RAW && n_total >= 16384) {
+    if (n_curves == 1 && mode != MODE_RAW && n_total >= 16384 && !d_picks) {
         WidePrepArgs wp;
         wp.p = p;
         wp.nparts = (int)((n_total + 4 * kBlock - 1) / (4 * kBlock));
@@ -1161,6 +1168,39 @@ int pdc_gls_scan_dev(int device, void *stream, const double *d_t, const double *
     return scan_dev(device, (hipStream_t)stream, d_t, d_y, d_dy, d_offsets, n_total, n_curves,
                     shared_t, f0, delta, j_begin, nf, fit_mean ? MODE_FIT_MEAN : MODE_NO_MEAN, psd,
                     d_power, nullptr, nullptr, d_amax, d_argmax, work, work_bytes);
+}
+
+namespace {
+__global__ void gls_iota_offsets_kernel(int64_t *offsets, int64_t n, int64_t count) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= count) offsets[b] = b * n;
+}
+}  // namespace
+
+int64_t pdc_gls_bootstrap_work_bytes(int64_t n, int64_t n_boot, int64_t nf) {
+    if (n < 0 || n_boot < 1 || nf < 0) return -1;
+    return layout(n * n_boot, n_boot, nf).total + (((n_boot + 1) * 8 + 255) & ~(int64_t)255);
+}
+
+int pdc_gls_bootstrap_dev(int device, void *stream, const double *d_t, const double *d_y, const double *d_dy,
+                          int64_t n, const int32_t *d_picks, int64_t n_boot, double f0, double delta, int64_t nf,
+                          int fit_mean, int psd, double *d_amax, int64_t *d_argmax, void *work,
+                          int64_t work_bytes) {
+    PDC_REQUIRE(d_t && d_y && d_picks && (d_amax || d_argmax), "gls_bootstrap: NULL argument");
+    PDC_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && n_boot >= 1 && nf >= 0, "gls_bootstrap: bad size");
+    const int64_t need = pdc_gls_bootstrap_work_bytes(n, n_boot, nf);
+    PDC_REQUIRE(work && work_bytes >= need, "gls_bootstrap: workspace too small (%lld < %lld bytes)",
+                (long long)work_bytes, (long long)need);
+    if (nf == 0) return PDC_OK;
+    PDC_TRY(use_device(device));
+    const int64_t inner = layout(n * n_boot, n_boot, nf).total;
+    int64_t *d_off = reinterpret_cast<int64_t *>(static_cast<char *>(work) + inner);
+    hipLaunchKernelGGL(gls_iota_offsets_kernel, dim3((unsigned)((n_boot + 256) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_off, n, n_boot);
+    PDC_HIP(hipGetLastError());
+    return scan_dev(device, (hipStream_t)stream, d_t, d_y, d_dy, d_off, n * n_boot, n_boot, 1, f0, delta, 0, nf,
+                    fit_mean ? MODE_FIT_MEAN : MODE_NO_MEAN, psd, nullptr, nullptr, nullptr, d_amax, d_argmax, work,
+                    inner, d_picks);
 }
 
 int pdc_gls_scan_batch(const double *t, const double *y, const double *dy, const int64_t *offsets,

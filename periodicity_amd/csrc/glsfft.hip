@@ -20,6 +20,7 @@
 #include "gls_epilogue.h"
 
 #include <cstdlib>
+#include <vector>
 
 using namespace pdc;
 
@@ -681,6 +682,8 @@ struct FftBatchArgs {
     cplx *grids;      // [B][ngrid][nfft]
     const cplx *result;  // where the transforms ended up (grids or scratch), same layout
     double *power;    // [B][nf]
+    // bootstrap replicates by index (spectral.py:146-148): y, dy = ONE curve, sample i of replicate b is picks[b n + i]
+    const int32_t *picks = nullptr;
 };
 
 __global__ __launch_bounds__(1024) void glsfft_prep_batch_kernel(FftBatchArgs a) {
@@ -688,11 +691,13 @@ __global__ __launch_bounds__(1024) void glsfft_prep_batch_kernel(FftBatchArgs a)
     const int tid = threadIdx.x;
     const int64_t off = a.offsets[blockIdx.x], n = a.offsets[blockIdx.x + 1] - off;
     const double *t = a.shared_t ? a.t : a.t + off;
-    const double *y = a.y + off;
-    const double *dy = a.dy ? a.dy + off : nullptr;
+    const int32_t *pk = a.picks ? a.picks + off : nullptr;
+    const double *y = pk ? a.y : a.y + off;
+    const double *dy = a.dy ? (pk ? a.dy : a.dy + off) : nullptr;
+    auto at = [pk](int64_t i) -> int64_t { return pk ? (int64_t)pk[i] : i; };
     double acc = 0.0, tmin = __builtin_inf(), ntmax = __builtin_inf(), disorder = 0.0;
     for (int64_t i = tid; i < n; i += 1024) {
-        const double e = dy ? dy[i] : 1.0;
+        const double e = dy ? dy[at(i)] : 1.0;
         acc += 1.0 / (e * e);
         const double ti = t[i];
         tmin = ti < tmin ? ti : tmin;
@@ -720,16 +725,16 @@ __global__ __launch_bounds__(1024) void glsfft_prep_batch_kernel(FftBatchArgs a)
     if (a.fit_mean) {
         acc = 0.0;
         for (int64_t i = tid; i < n; i += 1024) {
-            const double e = dy ? dy[i] : 1.0;
-            acc += (1.0 / (e * e)) / W * y[i];
+            const double e = dy ? dy[at(i)] : 1.0;
+            acc += (1.0 / (e * e)) / W * y[at(i)];
         }
         ybar = block_sum<1024>(acc, red);
     }
     double yy = 0.0;
     for (int64_t i = tid; i < n; i += 1024) {
-        const double e = dy ? dy[i] : 1.0;
+        const double e = dy ? dy[at(i)] : 1.0;
         const double w = (1.0 / (e * e)) / W;
-        const double yc = y[i] - ybar;
+        const double yc = y[at(i)] - ybar;
         a.w[off + i] = w;
         a.wy[off + i] = w * yc;
         yy += w * yc * yc;
@@ -1048,10 +1053,15 @@ int pdc_gls_scan_fft(const double *t, const double *y, const double *dy, int64_t
 }
 
 
-int pdc_gls_scan_fft_batch(const double *t, const double *y, const double *dy, const int64_t *offsets,
-                           int64_t n_curves, int shared_t, double fmin, double df, int64_t nf,
-                           int fit_mean, int psd, double *power_out, double *amax_out,
-                           int64_t *argmax_out, int device) {
+}  // extern "C"
+
+namespace {
+// `picks` != NULL: the bootstrap form - y and dy hold ONE curve of offsets[1] samples, replicate b reads
+// sample picks[b n + i]; only the indices cross PCIe
+int fft_batch_host(const double *t, const double *y, const double *dy, const int64_t *offsets,
+                   int64_t n_curves, int shared_t, double fmin, double df, int64_t nf,
+                   int fit_mean, int psd, double *power_out, double *amax_out,
+                   int64_t *argmax_out, int device, const int32_t *picks) {
     PDC_REQUIRE(t && y && offsets, "gls_fft_batch: t, y and offsets must not be NULL");
     PDC_REQUIRE(n_curves >= 1 && nf >= 0, "gls_fft_batch: bad size");
     PDC_REQUIRE(power_out || amax_out || argmax_out, "gls_fft_batch: no output requested");
@@ -1084,20 +1094,25 @@ int pdc_gls_scan_fft_batch(const double *t, const double *y, const double *dy, c
     const int64_t o_pow = o_scratch + up(chunk * ngrid * nfft * 16);
     const int64_t wb = o_pow + up(chunk * nf * 8);
     void *d_t, *d_y, *d_dy = nullptr, *d_off, *d_amax = nullptr, *d_arg = nullptr, *d_work;
+    const int64_t n_y = picks ? n_t : n_total;   // values / errors on the device: one curve, or all of them
+    void *d_picks = nullptr;
     PDC_TRY(cached(device, SLOT_IN0, n_t * 8, &d_t));
-    PDC_TRY(cached(device, SLOT_IN1, n_total * 8, &d_y));
-    if (dy) PDC_TRY(cached(device, SLOT_IN2, n_total * 8, &d_dy));
+    PDC_TRY(cached(device, SLOT_IN1, n_y * 8, &d_y));
+    if (dy) PDC_TRY(cached(device, SLOT_IN2, n_y * 8, &d_dy));
     PDC_TRY(cached(device, SLOT_IN3, (n_curves + 1) * 8, &d_off));
+    if (picks) PDC_TRY(cached(device, SLOT_OUT0, n_total * 4, &d_picks));
     if (amax_out) PDC_TRY(cached(device, SLOT_OUT1, n_curves * 8, &d_amax));
     if (argmax_out) PDC_TRY(cached(device, SLOT_OUT2, n_curves * 8, &d_arg));
     PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
     hipStream_t st = nullptr;
     PDC_HIP(hipMemcpyAsync(d_t, t, n_t * 8, hipMemcpyHostToDevice, st));
-    PDC_HIP(hipMemcpyAsync(d_y, y, n_total * 8, hipMemcpyHostToDevice, st));
-    if (dy) PDC_HIP(hipMemcpyAsync(d_dy, dy, n_total * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemcpyAsync(d_y, y, n_y * 8, hipMemcpyHostToDevice, st));
+    if (dy) PDC_HIP(hipMemcpyAsync(d_dy, dy, n_y * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_off, offsets, (n_curves + 1) * 8, hipMemcpyHostToDevice, st));
+    if (picks) PDC_HIP(hipMemcpyAsync(d_picks, picks, n_total * 4, hipMemcpyHostToDevice, st));
     char *base = static_cast<char *>(d_work);
     FftBatchArgs a;
+    a.picks = static_cast<const int32_t *>(d_picks);
     a.t = (double *)d_t;
     a.y = (double *)d_y;
     a.dy = (double *)d_dy;
@@ -1152,6 +1167,26 @@ int pdc_gls_scan_fft_batch(const double *t, const double *y, const double *dy, c
     if (argmax_out) PDC_HIP(hipMemcpyAsync(argmax_out, d_arg, n_curves * 8, hipMemcpyDeviceToHost, st));
     PDC_HIP(hipStreamSynchronize(st));
     return PDC_OK;
+}
+}  // namespace
+
+int pdc::gls_bootstrap_fft(const double *t, const double *y, const double *dy, int64_t n, const int32_t *picks,
+                           int64_t n_boot, double fmin, double df, int64_t nf, int fit_mean, int psd,
+                           double *amax_out, int64_t *argmax_out, int device) {
+    std::vector<int64_t> offsets((size_t)n_boot + 1);
+    for (int64_t b = 0; b <= n_boot; ++b) offsets[(size_t)b] = b * n;
+    return fft_batch_host(t, y, dy, offsets.data(), n_boot, 1, fmin, df, nf, fit_mean, psd, nullptr, amax_out,
+                          argmax_out, device, picks);
+}
+
+extern "C" {
+
+int pdc_gls_scan_fft_batch(const double *t, const double *y, const double *dy, const int64_t *offsets,
+                           int64_t n_curves, int shared_t, double fmin, double df, int64_t nf,
+                           int fit_mean, int psd, double *power_out, double *amax_out,
+                           int64_t *argmax_out, int device) {
+    return fft_batch_host(t, y, dy, offsets, n_curves, shared_t, fmin, df, nf, fit_mean, psd, power_out, amax_out,
+                          argmax_out, device, nullptr);
 }
 
 int pdc_trig_sums_fft(const double *t, const double *h, int64_t n, double df, int64_t nf,

@@ -467,7 +467,7 @@ int pdc_gls_scan_multi(const double *t, const double *y, const double *dy, int64
 // ======================================================================================================
 namespace {
 
-enum { B_T = 0, B_V, B_PER, B_OUT, B_WORK, B_DY, B_OFF, B_POW, B_AMAX, B_ARG, B_COUNT };
+enum { B_T = 0, B_V, B_PER, B_OUT, B_WORK, B_DY, B_OFF, B_POW, B_AMAX, B_ARG, B_PICK, B_COUNT };
 
 struct DevSlot {
     int device = -1;
@@ -854,6 +854,84 @@ int pdc_gls_scan_batch_multi(const double *t, const double *y, const double *dy,
             PDC_HIP(hipMemcpyAsync(argmax_out + sb.begin, s.b[B_ARG].p, sb.count * 8, hipMemcpyDeviceToHost, s.stream));
     }
     return PDC_OK;
+    };
+    const int rc = enqueue();
+    if (rc != PDC_OK) {
+        const std::string why = pdc_last_error();
+        (void)phase_wait(p);
+        set_error("%s", why.c_str());
+        return rc;
+    }
+    return phase_wait(p);
+}
+
+// GLS.bootstrap (/root/reference/src/periodicity/spectral.py:140-152) with the replicates given BY INDEX:
+// picks[b n + i] = the sample replicate b draws at position i (rng.integers(0, n, n) per replicate, drawn
+// by the caller exactly as upstream draws them).  Only (t, y, dy) of the ONE curve and the 4-byte indices
+// cross PCIe; the prologue on the device gathers y[picks], dy[picks] while it builds the weight table.
+// Replicates are dealt to the device slots in contiguous groups (no exchange); every replicate's NaN-aware
+// maximum (and its bin) comes back.  method 0 = exact direct sums (f0, delta = grid start and step),
+// 1 = the reference's FFT/extirpolation path (one device).
+int pdc_gls_bootstrap(const double *t, const double *y, const double *dy, int64_t n, const int32_t *picks,
+                      int64_t n_boot, double f0, double delta, int64_t nf, int fit_mean, int psd, int method,
+                      double *amax_out, int64_t *argmax_out, const int *devices, int n_devices) {
+    PDC_REQUIRE(t && y && devices && (picks || n_boot == 0 || n == 0), "gls_bootstrap: NULL argument");
+    PDC_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) && n_boot >= 0 && nf >= 0, "gls_bootstrap: bad size");
+    PDC_REQUIRE(method == 0 || method == 1, "gls_bootstrap: method must be 0 (direct sums) or 1 (FFT path)");
+    PDC_REQUIRE(amax_out || argmax_out || n_boot == 0, "gls_bootstrap: no output requested");
+    if (n_boot == 0 || nf == 0) return PDC_OK;
+    {   // (one vectorisable pass; an index outside the curve would be an out-of-bounds read on the device)
+        unsigned worst = 0;
+        for (int64_t i = 0; i < n_boot * n; ++i) worst = (unsigned)picks[i] > worst ? (unsigned)picks[i] : worst;
+        PDC_REQUIRE(n_boot * n == 0 || (int64_t)worst < n, "gls_bootstrap: a pick (%u as unsigned) is not a sample index "
+                    "in 0 .. %lld", worst, (long long)n - 1);
+    }
+    if (method == 1) {
+        PDC_TRY(check_devices("gls_bootstrap", devices, n_devices, false));
+        return gls_bootstrap_fft(t, y, dy, n, picks, n_boot, f0, delta, nf, fit_mean, psd, amax_out, argmax_out,
+                                 devices[0]);
+    }
+    std::lock_guard<std::mutex> lk(g_phase_mutex);
+    PhasePlan *p = nullptr;
+    PDC_TRY(cached_phase_plan("gls_bootstrap", devices, n_devices, &p));
+    PDC_TRY(phase_wait(p));
+    const int nd = n_devices;
+    auto enqueue = [&]() -> int {
+        for (int i = 0; i < nd; ++i) {
+            const Slab sb = slab_of(n_boot, nd, i);
+            if (sb.count == 0) continue;
+            DevSlot &s = p->slot[i];
+            PDC_TRY(use_device(s.device));
+            const int64_t wb = pdc_gls_bootstrap_work_bytes(n, sb.count, nf);
+            PDC_REQUIRE(wb >= 0, "gls_bootstrap: bad size");
+            PDC_TRY(ensure(s.b[B_T], n * 8));
+            PDC_TRY(ensure(s.b[B_V], n * 8));
+            if (dy) PDC_TRY(ensure(s.b[B_DY], n * 8));
+            PDC_TRY(ensure(s.b[B_PICK], sb.count * n * 4));
+            PDC_TRY(ensure(s.b[B_AMAX], sb.count * 8));
+            PDC_TRY(ensure(s.b[B_ARG], sb.count * 8));
+            PDC_TRY(ensure(s.b[B_WORK], wb));
+            PDC_HIP(hipMemcpyAsync(s.b[B_T].p, t, n * 8, hipMemcpyHostToDevice, s.stream));
+            PDC_HIP(hipMemcpyAsync(s.b[B_V].p, y, n * 8, hipMemcpyHostToDevice, s.stream));
+            if (dy) PDC_HIP(hipMemcpyAsync(s.b[B_DY].p, dy, n * 8, hipMemcpyHostToDevice, s.stream));
+            PDC_HIP(hipMemcpyAsync(s.b[B_PICK].p, picks + sb.begin * n, sb.count * n * 4, hipMemcpyHostToDevice,
+                                   s.stream));
+            PDC_TRY(pdc_gls_bootstrap_dev(s.device, s.stream, (double *)s.b[B_T].p, (double *)s.b[B_V].p,
+                                          dy ? (double *)s.b[B_DY].p : nullptr, n, (int32_t *)s.b[B_PICK].p, sb.count,
+                                          f0, delta, nf, fit_mean, psd, (double *)s.b[B_AMAX].p,
+                                          (int64_t *)s.b[B_ARG].p, s.b[B_WORK].p, s.b[B_WORK].cap));
+        }
+        for (int i = 0; i < nd; ++i) {
+            const Slab sb = slab_of(n_boot, nd, i);
+            if (sb.count == 0) continue;
+            DevSlot &s = p->slot[i];
+            PDC_TRY(use_device(s.device));
+            if (amax_out)
+                PDC_HIP(hipMemcpyAsync(amax_out + sb.begin, s.b[B_AMAX].p, sb.count * 8, hipMemcpyDeviceToHost, s.stream));
+            if (argmax_out)
+                PDC_HIP(hipMemcpyAsync(argmax_out + sb.begin, s.b[B_ARG].p, sb.count * 8, hipMemcpyDeviceToHost, s.stream));
+        }
+        return PDC_OK;
     };
     const int rc = enqueue();
     if (rc != PDC_OK) {

@@ -66,6 +66,11 @@ int use_device(int device);
 // drives several GPUs has to set it on each of them.
 int allow_dynamic_lds(const void *kernel, int bytes);
 
+// GLS.bootstrap through the FFT path with the replicates given by index (glsfft.hip; host buffers, one device).
+int gls_bootstrap_fft(const double *t, const double *y, const double *dy, int64_t n, const int32_t *picks,
+                      int64_t n_boot, double fmin, double df, int64_t nf, int fit_mean, int psd,
+                      double *amax_out, int64_t *argmax_out, int device);
+
 // Serialises the host-level entry points that share the cached workspace of one device.
 struct DeviceLock {
     explicit DeviceLock(int device);

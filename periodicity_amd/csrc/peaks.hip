@@ -94,8 +94,8 @@ constexpr int kPkBlock = 256;
 #define PDC_PK_WAVES 5
 #endif
 constexpr int kPkMaxBlocks = 4096;   // LDS: two doubles per block
-constexpr int kPkMaxK = 16;
-constexpr int kPkPre = 20;           // by prominence: the first walks go to the k + 4 highest maxima
+constexpr int kPkMaxK = 64;
+constexpr int kPkPre = 68;           // by prominence: the first walks go to the k + 4 highest maxima
 constexpr int kPkChunk = 1024;       // bins per sweep step
 constexpr int kPkFusedShift = 8;     // 256-bin blocks = one wave's stretch of a chunk: extrema come with the sweep
 static_assert(kPkChunk / kPkBlock * 64 == 1 << kPkFusedShift, "a wave's stretch is one block");

@@ -121,34 +121,33 @@ class GLS(object):
         ``default_rng(seed).integers(0, n, n)`` once per replicate, in order, exactly as
         upstream; the replicates then run as ONE batched launch that shares the time axis and
         returns only the NaN-aware maximum of each spectrum (with ``devices=(...)``: one contiguous
-        group of replicates per GPU, no exchange)."""
+        group of replicates per GPU, no exchange).  Only the curve and the 4-byte indices go to the device
+        (``pdc_gls_bootstrap``)."""
         rng = np.random.default_rng(random_seed)
         ndata = len(self.signal)
         values = np.asarray(self.signal.values, dtype=float)
         err = np.asarray(self.err, dtype=float)
         t = np.asarray(self.signal.time, dtype=float)
-        f0, delta, nf = _cabi.grid_params(self._grid(self.signal))
-        picks = np.empty((n_bootstraps, ndata), dtype=np.int64)
+        # the draws, exactly as upstream makes them (one ``integers(0, n, n)`` call per replicate, in order) -
+        # kept as 4-byte indices: the resampled (values, err) arrays are never built on the host, the device
+        # prologue gathers ``values[picks]``, ``err[picks]`` while it lays out the weight table
+        picks = np.empty((n_bootstraps, ndata), dtype=np.int32)
         for i in range(n_bootstraps):
             picks[i] = rng.integers(0, ndata, ndata)
-        offsets = np.arange(n_bootstraps + 1, dtype=np.int64) * ndata
         bs_replicates = np.empty(n_bootstraps)
         # err=None upstream means all-ones errors (``spectral.py:99-100``): resampling leaves them
         # all ones, and the equal-weights kernels share the weight-only sums between replicates
-        resampled_err = None if np.all(err == 1.0) else err[picks].ravel()
+        dy = None if np.all(err == 1.0) else err
         if n_bootstraps and self.method == "fft":
             # all replicates through the reference's own algorithm in one batched set of launches
             df, fmin, _ = self._grid_scalars(self.signal)
-            _, amax, _ = _cabi.gls_scan_fft_batch(
-                t, values[picks].ravel(), resampled_err, offsets, fmin, df, nf, True, self.psd,
-                shared_t=True, want_power=False, want_peaks=True, device=self.device)
-            bs_replicates[:] = amax
+            nf = self._grid(self.signal).size
+            bs_replicates[:] = _cabi.gls_bootstrap(t, values, dy, picks, fmin, df, nf, True, self.psd, method="fft",
+                                                   device=_cabi.pick_device(self.device, self.devices))[0]
         elif n_bootstraps:
-            _, amax, _ = _cabi.gls_scan_batch(
-                t, values[picks].ravel(), resampled_err, offsets, f0, delta, nf, True,
-                self.psd, shared_t=True, want_power=False, want_peaks=True, device=self.device,
-                devices=self.devices)
-            bs_replicates[:] = amax
+            f0, delta, nf = _cabi.grid_params(self._grid(self.signal))
+            bs_replicates[:] = _cabi.gls_bootstrap(t, values, dy, picks, f0, delta, nf, True, self.psd,
+                                                   device=self.device, devices=self.devices)[0]
         self.bs_replicates = bs_replicates
         return self.bs_replicates
 

@@ -140,6 +140,52 @@ def test_bootstrap_fap_fal(golden_dir):
     np.testing.assert_allclose(gls.fal(0.1), float(g["fal_at_0p1_exact"]), rtol=RTOL)
 
 
+@pytest.mark.parametrize("n_boot,with_dy", [(5, True), (130, True), (200, False)])
+def test_bootstrap_by_index_equals_the_expanded_batch(n_boot, with_dy):
+    """pdc_gls_bootstrap gathers y[picks], dy[picks] on the device (spectral.py:146-148): bit for bit what the
+    batched scan gives on the resampled arrays built on the host - below and above the 96 curves from which the
+    shared-trigonometry kernel takes over, with individual and with equal weights, and through the FFT path."""
+    t, y, dy = synth(700, 61, period=9.0)
+    dy = dy if with_dy else None
+    rng = np.random.default_rng(3)
+    picks = rng.integers(0, t.size, (n_boot, t.size)).astype(np.int32)
+    freq = np.arange(0.002, 0.6, 0.00043)
+    f0, delta, nf = _cabi.grid_params(freq)
+    offsets = np.arange(n_boot + 1, dtype=np.int64) * t.size
+    _, want, want_arg = _cabi.gls_scan_batch(t, y[picks].ravel(), None if dy is None else dy[picks].ravel(), offsets,
+                                             f0, delta, nf, shared_t=True, want_power=False, want_peaks=True)
+    amax, arg = _cabi.gls_bootstrap(t, y, dy, picks, f0, delta, nf)
+    assert np.array_equal(amax, want) and np.array_equal(arg, want_arg)
+    amax2, arg2 = _cabi.gls_bootstrap(t, y, dy, picks, f0, delta, nf, devices=(0, 0, 0))     # three slots
+    assert np.array_equal(amax2, want) and np.array_equal(arg2, want_arg)
+    # one replicate against the long-double oracle on the resampled curve
+    b = n_boot // 2
+    exact = np.asarray(co.gls_power_exact(t, y[picks[b]], None if dy is None else dy[picks[b]], freq))
+    assert arg[b] == int(np.argmax(exact)) and abs(amax[b] / exact.max() - 1) < RTOL
+    _, fwant, _ = _cabi.gls_scan_fft_batch(t, y[picks].ravel(), None if dy is None else dy[picks].ravel(), offsets,
+                                           f0, delta, nf, shared_t=True, want_power=False, want_peaks=True)
+    famax, _ = _cabi.gls_bootstrap(t, y, dy, picks, f0, delta, nf, method="fft")
+    assert np.array_equal(famax, fwant)
+
+
+def test_bootstrap_by_index_rejects_bad_picks_and_handles_empty():
+    t, y, dy = synth(50, 2)
+    picks = np.zeros((3, 50), dtype=np.int32)
+    picks[1, 7] = 50
+    with pytest.raises(ValueError):
+        _cabi.gls_bootstrap(t, y, dy, picks, 0.01, 0.01, 20)
+    picks[1, 7] = -1
+    with pytest.raises(ValueError):
+        _cabi.gls_bootstrap(t, y, dy, picks, 0.01, 0.01, 20)
+    with pytest.raises(ValueError):
+        _cabi.gls_bootstrap(t, y, dy, np.zeros((3, 49), dtype=np.int32), 0.01, 0.01, 20)
+    amax, arg = _cabi.gls_bootstrap(t, y, dy, np.zeros((0, 50), dtype=np.int32), 0.01, 0.01, 20)
+    assert amax.size == 0 and arg.size == 0
+    gls = GLS()
+    gls(TSeries(t, y), err=dy)
+    assert gls.bootstrap(0).size == 0
+
+
 def test_batch_ragged_equals_single_and_peaks():
     rng = np.random.default_rng(11)
     lens = [1, 2, 255, 256, 257, 1000, 3, 777]

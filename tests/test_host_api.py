@@ -91,8 +91,15 @@ def oracle_backend(monkeypatch):
                 for a, b in zip(offsets[:-1], offsets[1:])]
         return None, np.array([np.nanmax(r) for r in rows]), None
 
+    def gls_bootstrap(t, y, dy, picks, f0, delta, nf, fit_mean=True, psd=False, method="direct", device=None,
+                      devices=None):
+        assert picks.dtype == np.int32 and picks.shape[1:] == t.shape       # indices only cross the ABI
+        rows = [gls_scan(t, y[p], None if dy is None else dy[p], f0, delta, nf, fit_mean, psd) for p in picks]
+        return np.array([np.nanmax(r) for r in rows]), np.array([np.nanargmax(r) for r in rows])
+
     monkeypatch.setattr(_cabi, "gls_scan", gls_scan)
     monkeypatch.setattr(_cabi, "gls_scan_batch", gls_scan_batch)
+    monkeypatch.setattr(_cabi, "gls_bootstrap", gls_bootstrap)
     monkeypatch.setattr(_cabi, "pdm_scan",
                         lambda t, x, p, nb, nc, sigma, device=None, devices=None: so.pdm_scan(t, x, np.asarray(p), nb, nc))
     monkeypatch.setattr(_cabi, "stringlength_scan",

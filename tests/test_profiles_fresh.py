@@ -1,4 +1,4 @@
-"""bench.py's roofline block reads executed-instruction counts from profiles/r03_pmc_summary.json and
+"""bench.py's roofline block reads executed-instruction counts from profiles/r04_pmc_summary.json and
 refuses entries collected for other kernel sources.  This test keeps the committed summary in step
 with the committed sources of the HEADLINE kernel (re-run tools/collect_pmc.sh on a GPU box after
 touching them), and checks the refusal logic itself."""
@@ -11,18 +11,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_pmc_summary_matches_the_headline_kernel_sources():
-    summ = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
+    summ = json.load(open(bench.PMC_SUMMARY))
     now = bench.source_hashes()
     for name in bench.sources_of("gls_scan_kernel<16, 0, 2>"):
         assert summ["src_sha"].get(name) == now[name], f"{name} changed since the PMC passes: re-collect"
     k, why = bench.pmc_for("gls_scan_kernel", 27.5)
     assert why is None and k["SQ_INSTS_VALU"] > 1e10
     blk, _ = bench.valu_issue_block("gls_scan_kernel", 27.5)
-    assert 0.5 < blk["frac"] <= 1.0                      # an executed-issue fraction, never above 1
+    assert 0.5 < blk["frac"] <= blk["frac_all_at_4_cycles"] <= 1.0   # executed-issue fractions, never above 1
+    assert blk["mix"]["fp64_share"] > 0.8                # the headline kernel is nearly pure fp64 arithmetic
 
 
 def test_stale_or_missing_entries_are_refused(tmp_path, monkeypatch):
-    summ = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
+    summ = json.load(open(bench.PMC_SUMMARY))
     summ["src_sha"]["gls.hip"] = "0" * 16
     path = tmp_path / "stale.json"
     path.write_text(json.dumps(summ))

@@ -15,6 +15,10 @@ pass() {
     tail -1 "$out/$name.log" | cut -c1-200
 }
 pass valu  SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+# the VALU mix by instruction type (round 4): fp64 arithmetic issues a wave64 in 4 cycles on the SIMD-32, 32-bit
+# VALU in 2 - bench.py prices the executed-issue fraction with these instead of 4 cycles for everything
+pass mix64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_IOPS
+pass mix32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_FLOPS_FP64 SQ_INSTS_SMEM SQ_INSTS_BRANCH
 pass lds   SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
