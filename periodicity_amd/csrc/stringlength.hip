@@ -36,6 +36,7 @@
 //        larger than a whole slice is gathered straight into the global scratch.
 //   P3c  links between consecutive ranges and the closing segment, from the summaries.
 // Nothing but t[], m[] (read) and ell[p] (written) touches global memory on the common path.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -83,6 +84,8 @@ struct SlArgs {
     int64_t n_pad, nr_pad;
     unsigned *gorder;           // [grid][n_pad]  samples grouped by coarse bucket (several slices only)
     unsigned *ghist;            // [grid][kBucketsLarge]  first sorted position of every coarse bucket
+    const unsigned char *todo = nullptr;   // NULL, or [n_periods]: only periods with a non-zero entry are worked off
+    const unsigned *todo_count = nullptr;  // (with todo) how many entries are non-zero: 0 ends every workgroup at once
 };
 
 __device__ __forceinline__ double fold_phase(double t, double period) {
@@ -232,6 +235,8 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
     unsigned *gorder = multi ? a.gorder + (int64_t)blockIdx.x * a.n_pad : nullptr;
     unsigned *ghist = multi ? a.ghist + (int64_t)blockIdx.x * NB : nullptr;
 
+    // behind the streamed kernels: usually no period was left over
+    if (a.todo && *a.todo_count == 0u) return;
     // max |t| once per workgroup (guard band of the bucket shortcut)
     double tmax = 0.0;
     for (int64_t i = tid; i < n; i += kBlock) {
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
     };
 
     for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
+        if (a.todo && !a.todo[p]) continue;   // (workgroup-uniform)
         const double period = a.periods[p];
         const double rp = 1.0 / period;
         const double thr = 0.5 - (double)NB * (8.9e-16 * tmax * __builtin_fabs(rp) + 8.9e-16);
@@ -1587,6 +1593,551 @@ __global__ __launch_bounds__(BLK, 4) void sl_duo_kernel(DuoArgs a) {
 
 }  // namespace duo
 
+// =====================================================================================================
+// Streamed path ("stream"), for light curves whose (t, m) table no longer fits an XCD's L2 (N > ~2.4e5):
+// there every random gather of the kernels above misses L2 (62 ps per pair at N = 1e6 against 5.5 at C5).
+// Here NOTHING is gathered: the samples of a period are counting-sorted by phase bin through global scratch
+// with coalesced stores, and every bin is then sorted in LDS.  Per batch of trial periods, five launches:
+//   sl_hist_kernel   workgroup (period, group g of W; a group = a contiguous run of tiles of 2048 samples): folds
+//                    the group's samples exactly as the other kernels do and leaves ITS histogram over 4096 coarse
+//                    phase buckets (LDS atomics, no global ones);
+//   sl_lut_kernel    one workgroup per period: adds the W histograms, cuts [0, 1] into bins of consecutive coarse
+//                    buckets that each hold just under 6144 samples - whatever the phase distribution (periods
+//                    beyond the baseline fill only part of [0, 1]) - and, from the groups' own histograms, where
+//                    every group's records start in every bin's list: the lists are packed exactly, nothing can
+//                    overflow; a coarse bucket too heavy for a bin (clustered phases: evenly sampled data at a
+//                    commensurate period) marks the period for the general kernel;
+//   sl_part_kernel   workgroup (period, group): folds again, tile by tile (the next tile's samples requested
+//                    before the current one is worked off), groups a tile's records by bin IN LDS and appends
+//                    every group as one contiguous run of (phase, m) + sample index to its place in the bin's
+//                    list - coalesced stores, no global atomics, consecutive tiles extend the same cache lines;
+//   sl_sort_kernel   persistent, one workgroup per CU over the (period, bin) items: loads a bin's records
+//                    (contiguous), ranks them in LDS - 8192 fine buckets, arrival ranks from packed 16-bit LDS
+//                    counters, exclusive scan, then every record counts the members of its fine bucket that sort
+//                    before it, by (64-bit phase pattern, sample index) = numpy's stable order - and adds the
+//                    segments of its bin in sorted order (fixed summation order: bitwise reproducible whatever
+//                    order the atomics delivered the records in);
+//   sl_link_kernel   one wave per period: the bins' lengths in bin order, the links between consecutive
+//                    non-empty bins and the closing segment (phase.py:50, not phase-wrapped).
+// Traffic: 20 bytes written and read per (sample, period) pair, sequential - HBM-bound at ~40 B per pair.
+namespace stream {
+using namespace fast;
+
+#ifndef PDC_SL_CAP
+#define PDC_SL_CAP 6144
+#define PDC_SL_BB 1024
+#define PDC_SL_FINE 8192
+#define PDC_SL_MINFILL 2700
+#endif
+constexpr int kTA = 2048;          // samples per partition tile
+constexpr int kBA = 512;           // threads of the histogram / partition kernels (4 samples each per tile)
+constexpr int kNC = 4096;          // coarse phase buckets of the histogram and the bin table
+constexpr int kS1Max = 1024;       // bins per period at most
+constexpr int kCap = PDC_SL_CAP;   // records a bin's list (and the sort kernel's LDS) holds
+constexpr int kSlack = 16;         // a period's bins are filled to kCap - kSlack - (its heaviest coarse bucket) ...
+constexpr int kMinFill = PDC_SL_MINFILL;   // ... and not below this: heavier coarse buckets (clustered phases) go to the general kernel
+constexpr int kGroupsMax = 16;     // workgroups per period in the histogram / partition kernels
+constexpr int kBB = PDC_SL_BB;     // threads of the sort kernel
+constexpr int kPerB = kCap / kBB;  // records per thread
+constexpr int kFineB = PDC_SL_FINE; // fine buckets per bin, 16-bit counters packed two to a word
+static_assert(kCap % kBB == 0 && kCap < 65536, "slice positions are 16-bit");
+static_assert(kTA == 4 * kBA && kTA < 65536, "four samples per thread");
+constexpr size_t lds_part(int s1p) { return (size_t)kTA * (8 + 8 + 2) + (size_t)kNC * 2 + (size_t)s1p * 4 * 4; }
+constexpr size_t kLdsB = (size_t)kCap * (8 + 8 + 4) + (size_t)kFineB * 2;
+
+struct StreamArgs {
+    const double *t, *m, *periods;
+    int64_t n;
+    int64_t p0;                 // first period of this batch
+    int batch;                  // periods in this batch
+    int s1;                     // bins reserved per period (the table may use fewer)
+    int groups;                 // W: workgroups per period in the histogram / partition kernels
+    int tiles_w;                // tiles of kTA samples per group
+    const unsigned *bad_t;      // [0] != 0: some |t| outside {0} u [1e-150, 1e150]
+    unsigned *hist;             // [batch][W][kNC]   the groups' histograms
+    unsigned short *lut;        // [batch][kNC]      coarse bucket -> bin
+    unsigned short *clo;        // [batch][s1 + 1]   first coarse bucket of every bin
+    unsigned *boff;             // [batch][s1][W]    where group w's records start in the bin's list (exact: from
+                                //                   the groups' own histograms - no slack, no overflow)
+    unsigned *bcnt;             // [batch][s1]       records of every bin
+    unsigned *flag;             // [batch]           != 0: left to the general kernel
+    rec_t *pm;                  // [batch][s1][kCap] (phase, m)
+    unsigned *ix;               // [batch][s1][kCap] sample index (ties)
+    double *ssum;               // [batch][s1][4]    first / last (phase, m) of every bin in sorted order
+    double *slen;               // [batch][s1]       string length inside every bin
+    double *ell;
+    unsigned char *todo;        // [n_periods]       1 = left to the general kernel
+    unsigned *todo_count;
+};
+
+__global__ __launch_bounds__(256) void sl_tame_kernel(const double *t, int64_t n, unsigned *bad) {
+    bool mine = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double at = __builtin_fabs(t[i]);
+        mine = mine || !(at == 0.0 || (at >= 1e-150 && at <= 1e150));
+    }
+    if (__any(mine) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+}
+
+// sample index of local position l of tile kappa of group w: every group owns a contiguous run of tiles_w tiles
+__device__ __forceinline__ int64_t sample_of(int64_t kappa, int l, int w, int tiles_w) {
+    return ((int64_t)w * tiles_w + kappa) * kTA + l;
+}
+
+__global__ __launch_bounds__(kBA) void sl_hist_kernel(StreamArgs a) {
+    __shared__ unsigned h[kNC];
+    const int tid = threadIdx.x;
+    const int q = (int)(blockIdx.x % (unsigned)a.batch), w = (int)(blockIdx.x / (unsigned)a.batch);
+    const double period = a.periods[a.p0 + q];
+    const double y = 1.0 / period;
+    const bool safe = period_is_safe(period, a.bad_t[0] == 0u);
+    for (int c = tid; c < kNC; c += kBA) h[c] = 0u;
+    __syncthreads();
+    for (int64_t kappa = 0; kappa < a.tiles_w; ++kappa) {
+        double tv[4], phi[4];
+        bool live[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = sample_of(kappa, u * kBA + tid, w, a.tiles_w);
+            live[u] = i < a.n;
+            tv[u] = a.t[live[u] ? i : a.n - 1];
+        }
+        phases4(tv, period, y, safe, phi);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (live[u]) atomicAdd(&h[coarse_of<kNC>(phi[u])], 1u);
+    }
+    __syncthreads();
+    unsigned *out = a.hist + ((int64_t)q * a.groups + w) * kNC;
+    for (int c = tid; c < kNC; c += kBA) out[c] = h[c];
+}
+
+__global__ __launch_bounds__(256) void sl_lut_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned *gcnt = reinterpret_cast<unsigned *>(lds_raw);   // [s1][W] records of group w in bin b
+    __shared__ unsigned short lut[kNC + 1];
+    __shared__ unsigned short clo[kS1Max + 1];
+    __shared__ unsigned wave_tot[4], wave_max[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+    constexpr int kPer = kNC / 256;   // consecutive coarse buckets per thread
+    unsigned h[kPer], sum = 0u, mx = 0u;
+#pragma unroll
+    for (int x = 0; x < kPer; ++x) {
+        unsigned v = 0u;
+        for (int w = 0; w < a.groups; ++w) v += a.hist[((int64_t)q * a.groups + w) * kNC + tid * kPer + x];
+        h[x] = v;
+        sum += v;
+        mx = v > mx ? v : mx;
+    }
+    const unsigned incl = wave_scan_add(sum);
+    mx = wave_max_u32(mx);
+    if (lane == 63) wave_tot[wave] = incl;
+    if (lane == 0) wave_max[wave] = mx;
+    for (int b = tid; b <= a.s1; b += 256) clo[b] = (unsigned short)kNC;
+    __syncthreads();
+    unsigned run = incl - sum, h_max = 0u;
+    for (int x = 0; x < 4; ++x) {
+        if (x < wave) run += wave_tot[x];
+        h_max = wave_max[x] > h_max ? wave_max[x] : h_max;
+    }
+    // Bins of consecutive coarse buckets, whatever the phase distribution: bucket c goes to bin
+    // (samples before c) / fill, so a bin holds fewer than fill + (one coarse bucket) <= kCap - kSlack samples
+    // and there are at most n / fill + 1 of them.
+    const int fill = kCap - kSlack - (int)h_max;
+    const bool general = fill < kMinFill;
+    const unsigned div = general ? (unsigned)kMinFill : (unsigned)fill;
+#pragma unroll
+    for (int x = 0; x < kPer; ++x) {
+        const unsigned b = run / div;
+        lut[tid * kPer + x + 1] = (unsigned short)(b < (unsigned)(a.s1 - 1) ? b : (unsigned)(a.s1 - 1));
+        run += h[x];
+    }
+    if (tid == 0) {
+        lut[0] = 0;
+        a.flag[q] = general ? 1u : 0u;
+    }
+    __syncthreads();
+    // first coarse bucket of every bin (a heavy bucket may skip a bin: it stays empty, c_lo == c_hi)
+#pragma unroll
+    for (int x = 0; x < kPer; ++x) {
+        const int c = tid * kPer + x;
+        const int prev = c == 0 ? -1 : (int)lut[c], cur = (int)lut[c + 1];   // lut[c + 1] = bin of bucket c
+        for (int b = prev + 1; b <= cur; ++b) clo[b] = (unsigned short)c;
+    }
+    __syncthreads();
+    for (int c = tid; c < kNC; c += 256) a.lut[(int64_t)q * kNC + c] = lut[c + 1];
+    for (int b = tid; b <= a.s1; b += 256) a.clo[(int64_t)q * (a.s1 + 1) + b] = clo[b];
+    // how many records every group contributes to every bin - from the groups' own histograms, so the partition
+    // kernel's runs are packed exactly
+    const int W = a.groups;
+    for (int x = tid; x < a.s1 * W; x += 256) gcnt[x] = 0u;
+    __syncthreads();
+    for (int w = 0; w < W; ++w) {
+        // (a thread's 16 consecutive buckets lie in one or two bins: one atomic per bin, not per bucket)
+        unsigned acc = 0u;
+        int bin = (int)lut[tid * kPer + 1];
+#pragma unroll
+        for (int x = 0; x < kPer; ++x) {
+            const int c = tid * kPer + x;
+            const int bc = (int)lut[c + 1];
+            if (bc != bin) {
+                if (acc) atomicAdd(&gcnt[bin * W + w], acc);
+                acc = 0u;
+                bin = bc;
+            }
+            acc += a.hist[((int64_t)q * W + w) * kNC + c];
+        }
+        if (acc) atomicAdd(&gcnt[bin * W + w], acc);
+    }
+    __syncthreads();
+    for (int b = tid; b < a.s1; b += 256) {
+        unsigned at = 0u;
+        for (int w = 0; w < W; ++w) {
+            a.boff[((int64_t)q * a.s1 + b) * W + w] = at;
+            at += gcnt[b * W + w];
+        }
+        a.bcnt[(int64_t)q * a.s1 + b] = at;
+    }
+}
+
+template <int S1P>
+__global__ __launch_bounds__(kBA) void sl_part_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double *st_phi = reinterpret_cast<double *>(lds_raw);          // [kTA] the tile's records grouped by bin
+    double *st_m = st_phi + kTA;
+    unsigned *tcnt = reinterpret_cast<unsigned *>(st_m + kTA);      // [2][S1P] records of a tile per bin (tile parity)
+    unsigned *start = tcnt + 2 * S1P;                                // [S1P] first staged position of every bin
+    unsigned *run = start + S1P;                                     // [S1P] next free place in the bin's list
+    unsigned short *st_l = reinterpret_cast<unsigned short *>(run + S1P);   // [kTA] position in the tile (-> sample index)
+    unsigned short *lut = st_l + kTA;                                // [kNC]
+    __shared__ unsigned wave_tot[kBA / 64];
+    __shared__ int s_over;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = (int)(blockIdx.x % (unsigned)a.batch), w = (int)(blockIdx.x / (unsigned)a.batch);
+    if (a.flag[q] != 0u) return;                          // (workgroup-uniform) the general kernel takes this period
+    const int s1 = a.s1;
+    const double period = a.periods[a.p0 + q];
+    const double y = 1.0 / period;
+    const bool safe = period_is_safe(period, a.bad_t[0] == 0u);
+    for (int c = tid; c < kNC; c += kBA) lut[c] = a.lut[(int64_t)q * kNC + c];
+    for (int b = tid; b < S1P; b += kBA) {
+        run[b] = b < s1 ? a.boff[((int64_t)q * s1 + b) * a.groups + w] : 0u;   // this group's place in the bin's list
+        tcnt[b] = 0u;
+        tcnt[S1P + b] = 0u;
+    }
+    if (tid == 0) s_over = 0;
+    const int64_t list0 = ((int64_t)q * s1) * kCap;   // + b * kCap: the list of bin b
+    constexpr int kPer = S1P / kBA;
+    // the next tile's samples are requested before this tile is worked off
+    double tn[4], mn[4];
+    auto request = [&](int64_t kappa) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = sample_of(kappa, u * kBA + tid, w, a.tiles_w);
+            const int64_t ic = i < a.n ? i : a.n - 1;
+            tn[u] = a.t[ic];
+            mn[u] = a.m[ic];
+        }
+    };
+    request(0);
+    __syncthreads();
+    for (int64_t kappa = 0; kappa < a.tiles_w; ++kappa) {
+        unsigned *tc = tcnt + (kappa & 1) * S1P;
+        double tv[4], mv[4], phi[4];
+        bool live[4];
+        int bin[4];
+        unsigned arr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            tv[u] = tn[u];
+            mv[u] = mn[u];
+            live[u] = sample_of(kappa, u * kBA + tid, w, a.tiles_w) < a.n;
+        }
+        if (kappa + 1 < a.tiles_w) request(kappa + 1);
+        phases4(tv, period, y, safe, phi);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bin[u] = lut[coarse_of<kNC>(phi[u])];
+            arr[u] = 0u;
+            if (live[u]) arr[u] = atomicAdd(&tc[bin[u]], 1u);
+        }
+        __syncthreads();
+        // exclusive scan of the tile's counts -> start[]
+        unsigned c[kPer], sum = 0u;
+#pragma unroll
+        for (int x = 0; x < kPer; ++x) {
+            c[x] = tc[tid * kPer + x];
+            sum += c[x];
+        }
+        const unsigned incl = wave_scan_add(sum);
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        unsigned pos = incl - sum, tile_n = 0u;
+#pragma unroll
+        for (int x = 0; x < kBA / 64; ++x) {
+            if (x < wave) pos += wave_tot[x];
+            tile_n += wave_tot[x];
+        }
+#pragma unroll
+        for (int x = 0; x < kPer; ++x) {
+            start[tid * kPer + x] = pos;
+            pos += c[x];
+        }
+        // (the other parity's counts were last read - by this thread - in the previous tile: zero them for the next)
+#pragma unroll
+        for (int x = 0; x < kPer; ++x) tcnt[((kappa + 1) & 1) * S1P + tid * kPer + x] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (live[u]) {
+                const unsigned l = start[bin[u]] + arr[u];
+                st_phi[l] = phi[u];
+                st_m[l] = mv[u];
+                st_l[l] = (unsigned short)(u * kBA + tid);
+            }
+        }
+        __syncthreads();
+        bool over = false;
+        for (unsigned j = tid; j < tile_n; j += kBA) {
+            const double ph = st_phi[j];
+            const int b = lut[coarse_of<kNC>(ph)];
+            const unsigned dst = run[b] + (j - start[b]);
+            if (dst < (unsigned)kCap) {   // (always: the offsets are exact; a guard against writing outside the list)
+                const int64_t at = list0 + (int64_t)b * kCap + dst;
+                rec_t r;
+                r.x = ph;
+                r.y = st_m[j];
+                a.pm[at] = r;
+                a.ix[at] = (unsigned)sample_of(kappa, (int)st_l[j], w, a.tiles_w);
+            } else {
+                over = true;
+            }
+        }
+        if (over) s_over = 1;
+        __syncthreads();
+        // the tile's runs are appended: advance the places (own elements only)
+#pragma unroll
+        for (int x = 0; x < kPer; ++x) run[tid * kPer + x] += c[x];
+    }
+    __syncthreads();
+    if (tid == 0 && s_over) atomicOr(&a.flag[q], 2u);
+}
+
+// Persistent: a workgroup per CU walks the (period, bin) items.  (A second register set for the NEXT item's
+// records, requested under the current item's LDS work, was built and measured: no gain - the kernel waits on
+// its own LDS round trips, not on HBM; so was reading the first four members of every record's fine bucket
+// side by side instead of the data-dependent loop: no gain either.)
+__global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long *key_t = reinterpret_cast<unsigned long long *>(lds_raw);   // [kCap] by fine bucket, then sorted
+    double *m_s = reinterpret_cast<double *>(key_t + kCap);                          // [kCap] m in sorted order
+    unsigned *i_t = reinterpret_cast<unsigned *>(m_s + kCap);                        // [kCap] sample index by fine bucket
+    unsigned *fcnt = i_t + kCap;                                                     // [kFineB / 2] packed 16-bit
+    __shared__ unsigned wave_tot[kBB / 64];
+    __shared__ double red[kBB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s1 = a.s1;
+    const int64_t n_items = (int64_t)a.batch * s1;
+    // records of an item; 0 for empty bins and for periods the general kernel takes
+    auto count_of = [&](int64_t it) -> int {
+        if (it >= n_items) return 0;
+        const unsigned c = a.bcnt[it];
+        return a.flag[it / s1] != 0u ? 0 : (int)c;
+    };
+    int64_t it0 = blockIdx.x, it1 = it0 + gridDim.x;
+    int n0 = count_of(it0);
+    for (; it0 < n_items; it0 = it1, it1 += gridDim.x) {
+        const int64_t item = it0;
+        const int n_s = n0;
+        n0 = count_of(it1);                               // (in flight under this item's work)
+        if (n_s <= 0) continue;                           // (workgroup-uniform)
+        if (n_s > kCap) {                                 // (cannot happen: the bin table keeps bins below kCap)
+            if (tid == 0) atomicOr(&a.flag[item / s1], 4u);
+            continue;
+        }
+        rec_t rec[kPerB];
+        unsigned id[kPerB];
+#pragma unroll
+        for (int e = 0; e < kPerB; ++e) {
+            const int j = tid + e * kBB < n_s ? tid + e * kBB : n_s - 1;
+            rec[e] = a.pm[item * kCap + j];
+            id[e] = a.ix[item * kCap + j];
+        }
+        const int q = (int)(item / s1), s = (int)(item % s1);
+        for (int x = tid; x < kFineB / 2; x += kBB) fcnt[x] = 0u;
+        const double c_lo = (double)a.clo[(int64_t)q * (s1 + 1) + s];
+        const double c_hi = (double)a.clo[(int64_t)q * (s1 + 1) + s + 1];
+        const double fscale = (double)kFineB / (c_hi - c_lo > 0.0 ? c_hi - c_lo : 1.0);
+        __syncthreads();
+        // fine bucket: a monotone refinement of the coarse bucket (phi * 4096 is exact, the scale positive);
+        // arrival rank from the packed counters
+        unsigned long long key[kPerB];
+        unsigned fb[kPerB], arr[kPerB];
+#pragma unroll
+        for (int e = 0; e < kPerB; ++e) {
+            const double phi = rec[e].x;
+            key[e] = phase_key(phi);
+            const double rel = (phi * (double)kNC - c_lo) * fscale;
+            const unsigned f = (unsigned)rel;                                    // (saturating; negative -> 0)
+            fb[e] = phi == phi ? (f < (unsigned)(kFineB - 1) ? f : (unsigned)(kFineB - 1)) : (unsigned)(kFineB - 1);
+            arr[e] = 0u;
+            if (tid + e * kBB < n_s) {
+                const unsigned sh = (fb[e] & 1u) * 16u;
+                arr[e] = (atomicAdd(&fcnt[fb[e] >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            }
+        }
+        __syncthreads();
+        {   // exclusive scan of the fine counters (8 per thread), written back as packed starts
+            constexpr int kW = kFineB / 2 / kBB;   // words per thread
+            unsigned c[2 * kW], sum = 0u;
+#pragma unroll
+            for (int x = 0; x < kW; ++x) {
+                const unsigned v = fcnt[tid * kW + x];
+                c[2 * x] = v & 0xFFFFu;
+                c[2 * x + 1] = v >> 16;
+                sum += c[2 * x] + c[2 * x + 1];
+            }
+            const unsigned incl = wave_scan_add(sum);
+            if (lane == 63) wave_tot[wave] = incl;
+            __syncthreads();
+            unsigned run = incl - sum;
+            for (int x = 0; x < wave; ++x) run += wave_tot[x];
+#pragma unroll
+            for (int x = 0; x < kW; ++x) {
+                const unsigned lo = run;
+                run += c[2 * x];
+                const unsigned hi = run;
+                run += c[2 * x + 1];
+                fcnt[tid * kW + x] = lo | (hi << 16);
+            }
+        }
+        __syncthreads();
+        auto start_of = [&](unsigned f) -> unsigned {
+            return f < (unsigned)kFineB ? (fcnt[f >> 1] >> ((f & 1u) * 16u)) & 0xFFFFu : (unsigned)n_s;
+        };
+        unsigned st[kPerB], en[kPerB];
+#pragma unroll
+        for (int e = 0; e < kPerB; ++e) {
+            st[e] = start_of(fb[e]);
+            en[e] = start_of(fb[e] + 1u);
+            if (tid + e * kBB < n_s) {
+                key_t[st[e] + arr[e]] = key[e];
+                i_t[st[e] + arr[e]] = id[e];
+            }
+        }
+        __syncthreads();
+        // final position = start of the fine bucket + members that sort before (phase pattern, then sample index)
+        unsigned fin[kPerB];
+#pragma unroll
+        for (int e = 0; e < kPerB; ++e) {
+            unsigned before = 0u;
+            if (tid + e * kBB < n_s) {
+                for (unsigned o = st[e]; o < en[e]; ++o) {
+                    const unsigned long long ko = key_t[o];
+                    before += (ko < key[e] || (ko == key[e] && i_t[o] < id[e])) ? 1u : 0u;
+                }
+            }
+            fin[e] = st[e] + before;
+        }
+        __syncthreads();   // every thread is done reading the bucket-ordered keys: they become the sorted ones
+#pragma unroll
+        for (int e = 0; e < kPerB; ++e) {
+            if (tid + e * kBB < n_s) {
+                key_t[fin[e]] = key[e];
+                m_s[fin[e]] = rec[e].y;
+            }
+        }
+        __syncthreads();
+        // segments in sorted order: position p against p - 1 (the lane below; lane 0 reads it)
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < kPerB; ++e) {
+            const int p = tid + e * kBB;
+            const bool live = p < n_s;
+            const int pc = live ? p : 0;
+            const double phi = __longlong_as_double((long long)key_t[pc]), mm = m_s[pc];
+            double pphi = 0.0, pmm = 0.0;
+            if (lane == 0 && live && p > 0) {
+                pphi = __longlong_as_double((long long)key_t[p - 1]);
+                pmm = m_s[p - 1];
+            }
+            pphi = lane_below(phi, pphi);
+            pmm = lane_below(mm, pmm);
+            if (live && p > 0) acc += short_hypot(mm - pmm, phi - pphi);
+            if (live && p == 0) {
+                a.ssum[item * 4 + 0] = phi;
+                a.ssum[item * 4 + 1] = mm;
+            }
+            if (live && p == n_s - 1) {
+                a.ssum[item * 4 + 2] = phi;
+                a.ssum[item * 4 + 3] = mm;
+            }
+        }
+        acc = wave_sum_fixed(acc);
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double sum = 0.0;
+            for (int x = 0; x < kBB / 64; ++x) sum += red[x];
+            a.slen[item] = sum;
+        }
+    }
+}
+
+// one wave per period of the batch: 64 bins' summaries are fetched side by side, then folded in bin order
+__global__ __launch_bounds__(256) void sl_link_kernel(StreamArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int q = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (q >= a.batch) return;
+    const int64_t p = a.p0 + q;
+    if (a.flag[q] != 0u) {
+        if (lane == 0) {
+            a.todo[p] = 1;
+            atomicAdd(a.todo_count, 1u);
+        }
+        return;
+    }
+    double total = 0.0, f_phi = 0.0, f_m = 0.0, l_phi = 0.0, l_m = 0.0;
+    bool any = false;
+    for (int s0 = 0; s0 < a.s1; s0 += 64) {
+        const int s = s0 + lane;
+        const int64_t item = (int64_t)q * a.s1 + (s < a.s1 ? s : a.s1 - 1);
+        const unsigned cnt = s < a.s1 ? a.bcnt[item] : 0u;
+        double len = 0.0, p0 = 0.0, m0 = 0.0, p1 = 0.0, m1 = 0.0;
+        if (cnt) {
+            len = a.slen[item];
+            p0 = a.ssum[item * 4 + 0];
+            m0 = a.ssum[item * 4 + 1];
+            p1 = a.ssum[item * 4 + 2];
+            m1 = a.ssum[item * 4 + 3];
+        }
+        unsigned long long live = __ballot(cnt != 0u);
+        while (live) {                                   // (wave-uniform) non-empty bins in order
+            const int l = __builtin_ctzll(live);
+            live &= live - 1;
+            const double bl = read_lane(len, l), bp0 = read_lane(p0, l), bm0 = read_lane(m0, l);
+            total += bl;
+            if (any) {
+                total += hypot(bm0 - l_m, bp0 - l_phi);
+            } else {
+                f_phi = bp0;
+                f_m = bm0;
+                any = true;
+            }
+            l_phi = read_lane(p1, l);
+            l_m = read_lane(m1, l);
+        }
+    }
+    // closing segment of np.roll(-1): first minus last, no phase wrap (phase.py:50)
+    if (any) total += hypot(f_m - l_m, f_phi - l_phi);
+    if (lane == 0) {
+        a.ell[p] = total;
+        a.todo[p] = 0;
+    }
+}
+
+}  // namespace stream
+
 int64_t pad_pow2(int64_t n) {
     int64_t p = 2;
     while (p < n) p <<= 1;
@@ -1611,6 +2162,65 @@ int64_t fast_table_bytes(int64_t n) { return ((n * 16 + 255) & ~(int64_t)255) + 
 // workspace of the two-workgroups-per-CU kernel, behind the (t, m) table: the marks for the one-workgroup
 // kernel and the ticket counter
 int64_t duo_bytes(int64_t n_periods) { return ((n_periods + 255) & ~(int64_t)255) + 256; }
+
+
+// ---- streamed path: batch geometry and workspace ---------------------------------------------------------
+// PDC_SL_STREAM_MIN: smallest N that takes the streamed kernels (default 240 000: measured, N = 2e5 x 8192 periods
+// 19.0 ms through the several-slice kernel against 32.4 streamed, N = 2.5e5 x 4096 22.9 against 19.5);
+// PDC_SL_STREAM=0 switches them off (A/B, tests)
+int64_t stream_min_n() {
+    static const int64_t v = [] {
+        const char *on = getenv("PDC_SL_STREAM");
+        if (on && on[0] == '0') return (int64_t)1 << 62;
+        const char *e = getenv("PDC_SL_STREAM_MIN");
+        return e ? (int64_t)atoll(e) : (int64_t)240000;
+    }();
+    return v;
+}
+constexpr int64_t kStreamMaxN = (int64_t)(stream::kS1Max - 2) * stream::kMinFill;
+bool stream_takes(int64_t n) { return n >= stream_min_n() && n >= 4096 && n <= kStreamMaxN; }
+
+struct StreamShape {
+    int s1, batch, groups, tiles_w;
+    int64_t o_bad, o_flag, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_ssum, o_slen, o_ix, o_pm, o_todo, o_tcount, total;
+};
+StreamShape stream_shape(int64_t n, int64_t n_periods) {
+    auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+    StreamShape h;
+    h.s1 = (int)(n / stream::kMinFill + 2);
+    h.s1 = h.s1 > stream::kS1Max ? stream::kS1Max : h.s1;
+    const int64_t tiles = (n + stream::kTA - 1) / stream::kTA;
+    // workgroups per period in the histogram / partition kernels: a power of two up to 16, each with >= ~8 tiles
+    int groups = 1;
+    while (groups < stream::kGroupsMax && tiles / (2 * groups) >= 8) groups *= 2;
+    static const int env_groups = [] { const char *e = getenv("PDC_SL_STREAM_GROUPS"); return e ? atoi(e) : 0; }();
+    if (env_groups == 1 || env_groups == 2 || env_groups == 4 || env_groups == 8 || env_groups == 16) groups = env_groups;
+    h.groups = groups;
+    h.tiles_w = (int)((tiles + groups - 1) / groups);
+    // three workgroups per CU in the histogram / partition kernels: batch x groups >= 768
+    static const int64_t env_batch = [] { const char *e = getenv("PDC_SL_STREAM_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+    int64_t batch = env_batch > 0 ? env_batch : (768 + groups - 1) / groups;
+    batch = batch > n_periods ? n_periods : batch;
+    batch = batch < 1 ? 1 : batch;
+    h.batch = (int)batch;
+    const int64_t items = batch * h.s1;
+    h.o_bad = 0;
+    h.o_flag = 256;
+    h.o_hist = h.o_flag + up(batch * 4);
+    h.o_lut = h.o_hist + up(batch * groups * stream::kNC * 4);
+    h.o_clo = h.o_lut + up(batch * stream::kNC * 2);
+    h.o_sub = h.o_clo + up(batch * (h.s1 + 1) * 2);
+    h.o_bcnt = h.o_sub + up(items * groups * 4);
+    h.o_ssum = h.o_bcnt + up(items * 4);
+    h.o_slen = h.o_ssum + up(items * 32);
+    h.o_ix = h.o_slen + up(items * 8);
+    h.o_pm = h.o_ix + up(items * stream::kCap * 4);
+    h.o_todo = h.o_pm + up(items * stream::kCap * 16);
+    h.o_tcount = h.o_todo + up(n_periods);
+    h.total = h.o_tcount + 256;
+    return h;
+}
+int64_t stream_bytes(int64_t n, int64_t n_periods) { return stream_takes(n) ? stream_shape(n, n_periods).total : 0; }
 
 template <int KMAX, int BLK = duo::kB, int NBL = fast::kNB>
 int launch_duo(const duo::DuoArgs &a, int64_t grid, hipStream_t st) {
@@ -1648,7 +2258,7 @@ extern "C" {
 int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) {
     if (n < 0 || n_periods < 0) return -1;
     const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
-    return scratch_bytes(n, n_periods, partition) + fast_table_bytes(n) + duo_bytes(n_periods);
+    return scratch_bytes(n, n_periods, partition) + fast_table_bytes(n) + duo_bytes(n_periods) + stream_bytes(n, n_periods);
 }
 
 int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
@@ -1682,6 +2292,86 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
     a.ghist = a.gorder + (may_need_partition(n) ? grid * a.n_pad : 0);
     hipStream_t st = (hipStream_t)stream;
     static const bool general_only = [] { const char *e = getenv("PDC_SL_GENERAL"); return e && e[0] == '1'; }();
+    if (!general_only && stream_takes(n)) {
+        // ---- streamed path: histogram -> bin table -> partition -> sort every bin in LDS -> link, batch by batch ----
+        const StreamShape h = stream_shape(n, n_periods);
+        const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
+        char *area = static_cast<char *>(work) + scratch_bytes(n, n_periods, partition) + fast_table_bytes(n) +
+                     duo_bytes(n_periods);
+        stream::StreamArgs sa;
+        sa.t = d_t;
+        sa.m = d_m;
+        sa.periods = d_periods;
+        sa.n = n;
+        sa.s1 = h.s1;
+        sa.groups = h.groups;
+        sa.tiles_w = h.tiles_w;
+        sa.bad_t = reinterpret_cast<unsigned *>(area + h.o_bad);
+        sa.flag = reinterpret_cast<unsigned *>(area + h.o_flag);
+        sa.hist = reinterpret_cast<unsigned *>(area + h.o_hist);
+        sa.lut = reinterpret_cast<unsigned short *>(area + h.o_lut);
+        sa.clo = reinterpret_cast<unsigned short *>(area + h.o_clo);
+        sa.boff = reinterpret_cast<unsigned *>(area + h.o_sub);
+        sa.bcnt = reinterpret_cast<unsigned *>(area + h.o_bcnt);
+        sa.ssum = reinterpret_cast<double *>(area + h.o_ssum);
+        sa.slen = reinterpret_cast<double *>(area + h.o_slen);
+        sa.ix = reinterpret_cast<unsigned *>(area + h.o_ix);
+        sa.pm = reinterpret_cast<fast::rec_t *>(area + h.o_pm);
+        sa.todo = reinterpret_cast<unsigned char *>(area + h.o_todo);
+        sa.todo_count = reinterpret_cast<unsigned *>(area + h.o_tcount);
+        sa.ell = d_ell;
+        PDC_HIP(hipMemsetAsync(area + h.o_bad, 0, 256, st));
+        PDC_HIP(hipMemsetAsync(sa.todo_count, 0, 256, st));
+        hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, n, const_cast<unsigned *>(sa.bad_t));
+        PDC_TRY(allow_dynamic_lds((const void *)stream::sl_sort_kernel, (int)stream::kLdsB));
+        PDC_TRY(allow_dynamic_lds((const void *)stream::sl_lut_kernel, stream::kS1Max * stream::kGroupsMax * 4));
+        const bool wide = h.s1 > 512;
+        const size_t lds_a = stream::lds_part(wide ? 1024 : 512);
+        if (wide) PDC_TRY(allow_dynamic_lds((const void *)stream::sl_part_kernel<1024>, (int)lds_a));
+        else PDC_TRY(allow_dynamic_lds((const void *)stream::sl_part_kernel<512>, (int)lds_a));
+        for (int64_t p0 = 0; p0 < n_periods; p0 += h.batch) {
+            const int64_t bc = n_periods - p0 < h.batch ? n_periods - p0 : h.batch;
+            sa.p0 = p0;
+            sa.batch = (int)bc;
+            PDC_REQUIRE(bc * h.s1 < ((int64_t)1 << 31), "stringlength: grid too large");
+            const dim3 wg((unsigned)(bc * h.groups));
+            hipLaunchKernelGGL(stream::sl_hist_kernel, wg, dim3(stream::kBA), 0, st, sa);
+            hipLaunchKernelGGL(stream::sl_lut_kernel, dim3((unsigned)bc), dim3(256), (size_t)h.s1 * h.groups * 4, st, sa);
+            if (wide) hipLaunchKernelGGL(stream::sl_part_kernel<1024>, wg, dim3(stream::kBA), lds_a, st, sa);
+            else hipLaunchKernelGGL(stream::sl_part_kernel<512>, wg, dim3(stream::kBA), lds_a, st, sa);
+            const int64_t sort_slots = (int64_t)cu_count(device) * (stream::kLdsB + 1024 <= 80 * 1024 ? 2 : 1);
+            const int64_t sort_grid = bc * h.s1 < sort_slots ? bc * h.s1 : sort_slots;
+            hipLaunchKernelGGL(stream::sl_sort_kernel, dim3((unsigned)sort_grid), dim3(stream::kBB), stream::kLdsB, st, sa);
+            hipLaunchKernelGGL(stream::sl_link_kernel, dim3((unsigned)((bc + 3) / 4)), dim3(256), 0, st, sa);
+            PDC_HIP(hipGetLastError());
+        }
+        static const bool dbg = [] { const char *e = getenv("PDC_SL_STREAM_DEBUG"); return e && e[0] == '1'; }();
+        if (dbg) {
+            unsigned left = 0;
+            PDC_HIP(hipStreamSynchronize(st));
+            PDC_HIP(hipMemcpy(&left, sa.todo_count, 4, hipMemcpyDeviceToHost));
+            fprintf(stderr, "sl stream: n=%lld periods=%lld s1=%d groups=%d tiles_w=%d batch=%d -> %u periods left to the general kernel\n",
+                    (long long)n, (long long)n_periods, h.s1, h.groups, h.tiles_w, h.batch, left);
+        }
+        // the periods a coarse bucket was too heavy in (clustered phases): the general kernel, which sorts what LDS
+        // cannot hold
+        a.todo = sa.todo;
+        a.todo_count = sa.todo_count;
+        if (n < 65536) {
+            using L = Lds<unsigned short>;
+            const int64_t slice = n < L::capacity ? n : L::capacity;
+            const size_t lds = (size_t)L::fixed + (size_t)((slice + 7) & ~(int64_t)7) * 2;
+            PDC_TRY(allow_dynamic_lds((const void *)sl_scan_kernel<unsigned short, kBuckets>, (int)lds));
+            hipLaunchKernelGGL((sl_scan_kernel<unsigned short, kBuckets>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+        } else {
+            using L = Lds<unsigned>;
+            const size_t lds = (size_t)L::fixed + (size_t)L::capacity * 4;
+            PDC_TRY(allow_dynamic_lds((const void *)sl_scan_kernel<unsigned, kBucketsLarge>, (int)lds));
+            hipLaunchKernelGGL((sl_scan_kernel<unsigned, kBucketsLarge>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+        }
+        PDC_HIP(hipGetLastError());
+        return PDC_OK;
+    }
     // beyond ~16 slices the general kernel (one-off grouping of the indices in global scratch) is ahead: the
     // fast kernel's per-slice passes over the bucket ids and its 16-byte gathers (table > L2) grow with N
     // (x 2048 periods: N = 3.3e5 20.5 against 23.2 ms, N = 4.5e5 39.3 against 35.3 ms); PDC_SL_FAST_SLICES moves it

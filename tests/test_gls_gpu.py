@@ -156,8 +156,11 @@ def test_bootstrap_by_index_equals_the_expanded_batch(n_boot, with_dy):
                                              f0, delta, nf, shared_t=True, want_power=False, want_peaks=True)
     amax, arg = _cabi.gls_bootstrap(t, y, dy, picks, f0, delta, nf)
     assert np.array_equal(amax, want) and np.array_equal(arg, want_arg)
-    amax2, arg2 = _cabi.gls_bootstrap(t, y, dy, picks, f0, delta, nf, devices=(0, 0, 0))     # three slots
-    assert np.array_equal(amax2, want) and np.array_equal(arg2, want_arg)
+    # three device slots: a slot's group may fall below the 96 curves of the shared-trigonometry kernel and take
+    # the per-curve one - same sums in another order
+    amax2, arg2 = _cabi.gls_bootstrap(t, y, dy, picks, f0, delta, nf, devices=(0, 0, 0))
+    np.testing.assert_allclose(amax2, want, rtol=1e-12)
+    assert np.array_equal(arg2, want_arg)
     # one replicate against the long-double oracle on the resampled curve
     b = n_boot // 2
     exact = np.asarray(co.gls_power_exact(t, y[picks[b]], None if dy is None else dy[picks[b]], freq))

@@ -213,6 +213,36 @@ def test_stringlength_edges():
                                    co.stringlength_scan(tt, mm, pp), rtol=RTOL)
 
 
+def test_streamed_stringlength_kernels_match_the_oracle():
+    """The streamed path (no gather: partition by phase bin -> LDS sort per bin -> links) serves curves whose
+    (t, m) table outgrows L2; PDC_SL_STREAM_MIN routes small curves through it so that it meets the oracle at
+    sizes the oracle finishes in seconds: uneven and even sampling (bins that overflow at commensurate periods
+    fall back to the general kernel), a last tile that is not full, one bin, bitwise repeatability."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "sl_stream_check.py"),
+                          "70000x48", "4097x33", "20000x40e", "150001x12", "9000x20e"],
+                         env=dict(os.environ, PDC_SL_STREAM_MIN="4096"), cwd=root, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok"), out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_streamed_stringlength_at_its_own_sizes():
+    """N = 4e5 (just above the several-slice kernel's range) and N = 1e6 take the streamed kernels by default."""
+    rng = np.random.default_rng(12)
+    for n, n_per in ((400_000, 40), (1_000_000, 24)):
+        t = np.sort(rng.uniform(0, float(n), n))
+        y = np.sin(2 * np.pi * t / 13.7) + 0.2 * rng.standard_normal(n)
+        m = so.stringlength_scale(y)
+        df = 0.1 / (t[-1] - t[0])
+        periods = 1 / np.linspace(n_per * df * 100, df, n_per)
+        got = _cabi.stringlength_scan(t, m, periods)
+        pick = np.array([0, n_per // 2, n_per - 1])
+        np.testing.assert_allclose(got[pick], co.stringlength_scan(t, m, periods[pick]), rtol=RTOL)
+        assert np.array_equal(got, _cabi.stringlength_scan(t, m, periods))
+
+
 def test_phase_scans_full_size_c5():
     """BASELINE configs[4]: N=5e4 samples x 1e5 trial periods, both scans, with a random subset
     of periods against the C oracle and invariances of the statistics."""

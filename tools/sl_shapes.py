@@ -17,7 +17,7 @@ tm = bench.EventTimer(lib, _cabi, 0, sp.value)
 DB = _cabi.DeviceBuffer
 SHAPES = ((500, 100_000), (2000, 100_000), (2000, 1000), (10_000, 20_000), (25_000, 100_000), (50_000, 100_000))
 if os.environ.get("LARGE"):
-    SHAPES = ((70_000, 20_000), (200_000, 2048), (200_000, 20_000), (1_000_000, 256), (1_000_000, 2048))
+    SHAPES = ((74_326, 20_000), (200_000, 2048), (200_000, 20_000), (400_000, 2048), (1_000_000, 256), (1_000_000, 2048))
 if os.environ.get("SHAPES"):      # SHAPES="300000x2048,600000x1024"
     SHAPES = tuple(tuple(int(v) for v in s.split("x")) for s in os.environ["SHAPES"].split(","))
 for n, n_per in SHAPES:
