@@ -453,6 +453,33 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
                              "frac_of_8TBps": round(pairs * SL_MODEL_BYTES_PER_PAIR / ms / 1e9 / HBM_PEAK_TBS, 3),
                              "note": "SURVEY 8d's HBM bucket-pass model (48 B/pair); the kernel sorts in LDS "
                                      "and moves none of these bytes through HBM, so this may exceed 1"}}
+    # -- StringLength where real data lives: the reference's bundled SunSpots curve has 74 326 samples (several LDS
+    # slices per period), and N = 1e6 takes the streamed kernels (counting sort by phase bin through HBM, no gathers)
+    for key, n_l, np_l, kern, what in (
+            ("sl_sunspots_size", 74_326, 20_000, "sl_fast_kernel", "the several-slice kernel (N > 52 112: one period no longer fits one LDS slice)"),
+            ("sl_streamed_1e6", 1_000_000, 2048, "sl_sort_kernel", "the streamed kernels: histogram -> bin table -> LDS-staged partition -> LDS sort per bin -> links")):
+        tl, yl, _ = synth_curve(n_l, 5, period=13.7)
+        ml = (yl - yl.max()) / (2 * (yl.max() - yl.min())) + 0.25
+        dfl = 0.1 / (tl[-1] - tl[0])
+        pl = 1 / np.linspace(np_l * dfl, dfl, np_l)
+        bl = [DB.from_array(a_, dev) for a_ in (tl, ml, pl)]
+        bel = DB(np_l * 8, dev)
+        wbl = lib.pdc_stringlength_work_bytes(n_l, np_l)
+        wl = DB(wbl, dev)
+        ms = tm.ms(lambda: cabi.check(lib.pdc_stringlength_scan_dev(dev, stream, bl[0].ptr, bl[1].ptr, n_l, bl[2].ptr, np_l,
+                                                                    bel.ptr, wl.ptr, wbl)), reps=3)
+        pairs_l = float(n_l) * np_l
+        entry = {"ms": round(ms, 3), "Gpair_per_s": round(pairs_l / ms / 1e6, 1), "n_samples": n_l, "n_periods": np_l,
+                 "per_pair_vs_c5": round((ms / pairs_l) / (out["c5_stringlength"]["ms"] / pairs), 3), "note": what}
+        if key == "sl_streamed_1e6":
+            gbps = pairs_l * 40.0 / ms / 1e6
+            fr, _ = two_fracs(kern, ms, gbps / (HBM_PEAK_TBS * 1000), "40 B per pair (20 written + 20 read, sequential) vs 8 TB/s HBM")
+            entry.update(fr)
+            entry["roofline"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s",
+                                 "frac": round(gbps / (HBM_PEAK_TBS * 1000), 4), "algorithmic_bytes_per_pair": 40}
+        out[key] = entry
+        for b in bl + [bel, wl]:
+            b.free()
     if with_cpu:
         # the reference's per-period work on the host (never inside a timed GPU region): numpy restatement
         # of PDM._pdm / _stringlength on ONE core as upstream's Pool worker runs it, the same under

@@ -476,7 +476,9 @@ def test_full_size_c3_batch_peaks_only():
     found = 1 / freq[argmax]
     # the injected periods are recovered to the grid resolution dP = P^2 df
     assert np.mean(np.abs(found - per[:, 0]) < 1.5 * per[:, 0] ** 2 * df) > 0.99
-    assert np.array_equal(idx, argmax) or np.mean(idx == argmax) > 0.999
+    # the highest find_peaks() maximum is the global maximum unless that sits on an edge bin (edges are never peaks)
+    differ = idx != argmax
+    assert np.all((argmax[differ] == 0) | (argmax[differ] == nf - 1))
     for b in rng.integers(0, B, 5):
         single = _cabi.gls_scan(t[b], y[b], dy[b], f0, delta, nf)
         # (a lone curve picks another tile shape than the 4096-curve batch: equal to rounding)
@@ -501,19 +503,21 @@ def test_full_size_c3_batch_peaks_only():
                                 by_prominence=True)
     assert np.array_equal(top["indices"][:, 0], idx)
     assert np.all(top["count"] > 100) and np.all(pro["prominences"][:, 0] >= pro["prominences"][:, 1])
-    for b in rng.integers(0, B, 3):
-        single = _cabi.gls_scan(t[b], y[b], dy[b], f0, delta, nf)
-        pk, res = find_peaks(single, prominence=0.0)
-        order = np.lexsort((pk, -single[pk]))[:4]
-        # (batch and single-curve spectra agree to rounding, so ranks of near-equal peaks may swap:
-        # compare the winner exactly and the rest as sets of bins)
-        assert top["indices"][b, 0] == pk[order][0]
-        assert abs(top["count"][b] - pk.size) <= 2
+    # against the batch's OWN spectra (same kernel, same tile shape: no rounding slack) every figure is exact:
+    # scipy on rows of the power array the batched scan wrote
+    power, _, _ = _cabi.gls_scan_batch(t.ravel(), y.ravel(), dy.ravel(), offsets, f0, delta, nf,
+                                       want_power=True, want_peaks=False)
+    for b in np.unique(np.concatenate([[0, B - 1], rng.integers(0, B, 200)])):
+        pk, res = find_peaks(power[b], prominence=0.0)
+        assert top["count"][b] == pk.size == pro["count"][b]
+        order = np.lexsort((pk, -power[b][pk]))[:4]
+        assert np.array_equal(top["indices"][b], pk[order]) and np.array_equal(top["heights"][b], power[b][pk[order]])
         order_p = np.lexsort((pk, -res["prominences"]))[:4]
-        assert pro["indices"][b, 0] == pk[order_p][0]
-        assert abs(pro["prominences"][b, 0] / res["prominences"][order_p][0] - 1) < 1e-9
+        assert np.array_equal(pro["indices"][b], pk[order_p])
+        assert np.array_equal(pro["prominences"][b], res["prominences"][order_p])
         lo, hi = top["half_lo"][b, 0], top["half_hi"][b, 0]
         assert 0 <= hi < idx[b] <= lo < nf and lo - hi < 40       # the half-maximum width of the main peak
+    del power
 
 
 def test_c1_exactly_as_baseline_defines_it():
