@@ -2437,7 +2437,11 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
             f.todo = todo;   // the periods the duo kernel marked (clustered phases) go through the one-slice kernel
             f.todo_count = d.ticket + 1;
         }
-        if (n > fast::kCapacity) PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true>(f, grid, st)));
+        if (n > fast::kCapacity && n < 65536) {
+            // (sample indices still fit 16 bits: slices of 52 112 instead of 23 976 - two slices, not three)
+            f.slice_cap = fast::FL<unsigned short>::capacity;
+            PDC_TRY((launch_fast<4, unsigned short, fast::kNBLarge, true>(f, grid, st)));
+        } else if (n > fast::kCapacity) PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true>(f, grid, st)));
         else if (k <= 8) PDC_TRY(launch_fast<8>(f, grid, st));
         else if (k <= 20) PDC_TRY(launch_fast<20>(f, grid, st));
         else if (k <= 36) PDC_TRY(launch_fast<36>(f, grid, st));

@@ -168,7 +168,7 @@ def test_stringlength_large_n_runs_in_phase_slices():
     # more samples than one LDS slice holds (52112 with 16-bit indices): up to 16 slices of ~24k the fast
     # kernel reads every sample's bucket id back per slice and keeps that slice's; beyond, the general kernel groups
     # the samples by coarse bucket once per period in global scratch and sorts slice after slice
-    t6, y6 = synth(60_000, 78)                              # three slices
+    t6, y6 = synth(60_000, 78)                              # two slices of 16-bit indices (N < 65536)
     m6 = so.stringlength_scale(y6)
     p6 = np.array([0.9, 13.7, 4000.0])
     np.testing.assert_allclose(_cabi.stringlength_scan(t6, m6, p6),
@@ -183,7 +183,8 @@ def test_stringlength_large_n_runs_in_phase_slices():
     pe = np.array([1.0, 2.5, 7.3])
     np.testing.assert_allclose(_cabi.stringlength_scan(te, me, pe),
                                co.stringlength_scan(te, me, pe), rtol=RTOL)
-    for n_big, seed in ((380_000, 79), (400_000, 80)):      # last size of the fast kernel's range / general kernel
+    # 2e5: nine slices of 32-bit indices (the several-slice kernel's upper range); 380k / 400k: the streamed kernels
+    for n_big, seed in ((200_000, 81), (380_000, 79), (400_000, 80)):
         tb, yb = synth(n_big, seed)
         mb = so.stringlength_scale(yb)
         pb = np.array([0.7, 13.7, 2.0, 51_234.5])
