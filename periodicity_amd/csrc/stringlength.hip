@@ -750,6 +750,9 @@ struct FL {
     static constexpr int capacity = ((((kLdsTotal - fixed - kStatic) / (int)sizeof(IdxT)) & ~7) - 64);   // (+ 64 dummy slots)
 };
 constexpr int kCapacity = FL<unsigned short>::capacity;   // samples the one-slice instances take
+// P17 slices: 16 bits per entry + one plane bit, beside the 32-bit instance's wave scratch
+constexpr int kCapacity17 = ((((kLdsTotal - FL<unsigned>::fixed - kStatic) * 8 / 17) & ~31) - 64 - 32);
+static_assert(kCapacity17 < 65536 && kCapacity17 > 40000, "slice positions are 16-bit");
 static_assert(kCapacity / kFWin + 2 <= kRanges, "range table too small");
 static_assert(kFine + 16 <= (kWFine + 4) * 4, "byte counters live in the general kernel's counter area");
 static_assert(kCapacity <= kKMax * kBlock, "P1 keeps one bucket id per sample in registers");
@@ -916,8 +919,13 @@ __device__ __forceinline__ void phases4(const double (&t)[4], double period, dou
 // then the period is worked off in slices of consecutive buckets that fit LDS - the bucket ids read back
 // and this slice's samples scattered into order[],
 // range table, P3a, P3b - with 32-bit indices and NB = 8192 coarse buckets.
-template <int KMAX, typename IdxT = unsigned short, int NB = kNB, bool MULTI = false>
+// P17 (several slices, 65 536 <= N < 131 072): the permutation keeps 16 bits of a sample index per entry plus ONE
+// bit in a plane beside it (an LDS atomic OR for the upper half of the samples): 2.125 bytes per entry instead of
+// 4, i.e. slices of ~45 000 samples instead of 23 976 - the reference's SunSpots curve (74 326) takes two slices
+// instead of four.
+template <int KMAX, typename IdxT = unsigned short, int NB = kNB, bool MULTI = false, bool P17 = false>
 __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
+    static_assert(!P17 || (MULTI && sizeof(IdxT) == 4), "the bit plane belongs to the several-slice instance");
     constexpr int kWaveBytes = FL<IdxT>::wave_bytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char *wbuf = lds_raw;                                                  // P3a: per-wave scratch
@@ -928,6 +936,14 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
     unsigned short *bnds = bndb + kRanges + 8;
     unsigned *defer = reinterpret_cast<unsigned *>(bnds + kRanges + 8);             // [16]
     IdxT *order = reinterpret_cast<IdxT *>(defer + 16);                             // [slice + 64]
+    unsigned short *order16 = reinterpret_cast<unsigned short *>(defer + 16);       // P17: low 16 bits per entry ...
+    const int plane_words = P17 ? (a.slice_cap + 64 + 31) / 32 : 0;
+    unsigned *plane = reinterpret_cast<unsigned *>(order16 + ((a.slice_cap + 64 + 7) & ~7));   // ... + bit 16
+    auto order_get = [&](int pos) -> unsigned {
+        if constexpr (P17) return (unsigned)order16[pos] | (((plane[pos >> 5] >> (pos & 31)) & 1u) << 16);
+        else return (unsigned)order[pos];
+    };
+#define PDC_ORDER_GET(pos) order_get(pos)
     __shared__ unsigned wave_tot[kWaves];
     __shared__ double red[kWaves];
     __shared__ unsigned s_fill;
@@ -1152,6 +1168,10 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             slice_n = end_of(b1 - 1) - consumed;
             __syncthreads();   // every thread has read what it needs from the start offsets
             if (tid < 16) defer[tid] = tid == 15 ? (unsigned)kWaves : 0u;
+            if constexpr (P17) {
+                for (int x = tid; x < plane_words; x += kBlock) plane[x] = 0u;
+                __syncthreads();
+            }
             {
                 // hist[b] still holds the START of every bucket: every sample's bucket id is read back (2
                 // bytes, coalesced) and this slice's samples go to order[].  (Grouping all samples once in
@@ -1169,7 +1189,15 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                     for (int u = 0; u < 8; ++u) {
                         const int i = i0 + u * kBlock;
                         const int b = (int)bk[u];
-                        if (i < n && b >= b0 && b < b1) order[atomicAdd(&hist[b], 1u) - (unsigned)consumed] = (IdxT)i;
+                        if (i < n && b >= b0 && b < b1) {
+                            const unsigned pos = atomicAdd(&hist[b], 1u) - (unsigned)consumed;
+                            if constexpr (P17) {
+                                order16[pos] = (unsigned short)i;
+                                if (i >> 16) atomicOr(&plane[pos >> 5], 1u << (pos & 31));
+                            } else {
+                                order[pos] = (IdxT)i;
+                            }
+                        }
                     }
                 }
             }
@@ -1219,7 +1247,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 if (cnt <= kDCap) {
                     for (int s = tid; s < P; s += kBlock) {
                         if (s < cnt) {
-                            const IdxT id = order[s_lo + s];
+                            const IdxT id = (IdxT)PDC_ORDER_GET(s_lo + s);
                             bkeys[s] = phase_key(fast_phase(a.t[id], period, y, safe));
                             bidx[s] = id;
                         } else {
@@ -1237,7 +1265,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 } else {
                     for (int s = tid; s < P; s += kBlock) {
                         if (s < cnt) {
-                            const unsigned id = order[s_lo + s];
+                            const unsigned id = PDC_ORDER_GET(s_lo + s);
                             gk[s] = phase_key(fast_phase(a.t[id], period, y, safe));
                             gi[s] = id;
                         } else {
@@ -1302,6 +1330,8 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         __syncthreads();
     }
 }
+
+#undef PDC_ORDER_GET
 
 // AoS (t, m) table + the "every t is tame" flag (one workgroup; N <= 52k)
 __global__ __launch_bounds__(kBlock) void sl_prep_kernel(const double *t, const double *m, int n,
@@ -1511,7 +1541,9 @@ __global__ __launch_bounds__(BLK, 4) void sl_duo_kernel(DuoArgs a) {
         // ---- P3a: wave-autonomous ranges (the same code as sl_fast_kernel's, on this workgroup's 8 waves) --
         constexpr int NB = NBL;
         const int r_base = 0;
+#define PDC_ORDER_GET(pos) ((unsigned)order[pos])
 #include "sl_ranges.inc"
+#undef PDC_ORDER_GET
         if (wave < nranges) request(wave);
         for (int r = wave; r < nranges; r = r_next) {
             if (n_cnt > 192) process(r, std::true_type{});
@@ -2242,12 +2274,15 @@ int cu_count(int device) {
     return cached[device];
 }
 
-template <int KMAX, typename IdxT = unsigned short, int NB = fast::kNB, bool MULTI = false>
+template <int KMAX, typename IdxT = unsigned short, int NB = fast::kNB, bool MULTI = false, bool P17 = false>
 int launch_fast(const fast::FastArgs &a, int64_t grid, hipStream_t st) {
     const int64_t slice = MULTI ? a.slice_cap : a.n;
-    const size_t lds = (size_t)fast::FL<IdxT>::fixed + (size_t)((slice + 64 + 7) & ~(int64_t)7) * sizeof(IdxT);
-    PDC_TRY(allow_dynamic_lds((const void *)fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI>, fast::kLdsTotalDyn));
-    hipLaunchKernelGGL((fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    const int64_t entries = (slice + 64 + 7) & ~(int64_t)7;
+    const size_t lds = (size_t)fast::FL<IdxT>::fixed +
+                       (P17 ? (size_t)entries * 2 + (size_t)((slice + 64 + 31) / 32) * 4 + 16 : (size_t)entries * sizeof(IdxT));
+    PDC_REQUIRE(lds <= (size_t)fast::kLdsTotalDyn, "stringlength: slice of %lld samples does not fit LDS", (long long)slice);
+    PDC_TRY(allow_dynamic_lds((const void *)fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI, P17>, fast::kLdsTotalDyn));
+    hipLaunchKernelGGL((fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI, P17>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     return PDC_OK;
 }
 
@@ -2441,6 +2476,15 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
             // (sample indices still fit 16 bits: slices of 52 112 instead of 23 976 - two slices, not three)
             f.slice_cap = fast::FL<unsigned short>::capacity;
             PDC_TRY((launch_fast<4, unsigned short, fast::kNBLarge, true>(f, grid, st)));
+        } else if (n > fast::kCapacity && n < 131072) {
+            // (17-bit sample indices: 16 bits per entry + a bit plane - slices of ~45 000)
+            static const bool p17_on = [] { const char *e = getenv("PDC_SL_P17"); return !(e && e[0] == '0'); }();
+            if (p17_on) {
+                f.slice_cap = fast::kCapacity17;
+                PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true, true>(f, grid, st)));
+            } else {
+                PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true>(f, grid, st)));
+            }
         } else if (n > fast::kCapacity) PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true>(f, grid, st)));
         else if (k <= 8) PDC_TRY(launch_fast<8>(f, grid, st));
         else if (k <= 20) PDC_TRY(launch_fast<20>(f, grid, st));
