@@ -750,9 +750,10 @@ struct FL {
     static constexpr int capacity = ((((kLdsTotal - fixed - kStatic) / (int)sizeof(IdxT)) & ~7) - 64);   // (+ 64 dummy slots)
 };
 constexpr int kCapacity = FL<unsigned short>::capacity;   // samples the one-slice instances take
-// P17 slices: 16 bits per entry + one plane bit, beside the 32-bit instance's wave scratch
+// slices with bit planes: 16 bits per entry + one / two plane bits, beside the 32-bit instance's wave scratch
 constexpr int kCapacity17 = ((((kLdsTotal - FL<unsigned>::fixed - kStatic) * 8 / 17) & ~31) - 64 - 32);
-static_assert(kCapacity17 < 65536 && kCapacity17 > 40000, "slice positions are 16-bit");
+constexpr int kCapacity18 = ((((kLdsTotal - FL<unsigned>::fixed - kStatic) * 8 / 18) & ~31) - 64 - 32);
+static_assert(kCapacity17 < 65536 && kCapacity18 > 40000, "slice positions are 16-bit");
 static_assert(kCapacity / kFWin + 2 <= kRanges, "range table too small");
 static_assert(kFine + 16 <= (kWFine + 4) * 4, "byte counters live in the general kernel's counter area");
 static_assert(kCapacity <= kKMax * kBlock, "P1 keeps one bucket id per sample in registers");
@@ -919,13 +920,14 @@ __device__ __forceinline__ void phases4(const double (&t)[4], double period, dou
 // then the period is worked off in slices of consecutive buckets that fit LDS - the bucket ids read back
 // and this slice's samples scattered into order[],
 // range table, P3a, P3b - with 32-bit indices and NB = 8192 coarse buckets.
-// P17 (several slices, 65 536 <= N < 131 072): the permutation keeps 16 bits of a sample index per entry plus ONE
-// bit in a plane beside it (an LDS atomic OR for the upper half of the samples): 2.125 bytes per entry instead of
-// 4, i.e. slices of ~45 000 samples instead of 23 976 - the reference's SunSpots curve (74 326) takes two slices
-// instead of four.
-template <int KMAX, typename IdxT = unsigned short, int NB = kNB, bool MULTI = false, bool P17 = false>
+// PL = 1 or 2 (several slices, 65 536 <= N < 131 072 / 262 144): the permutation keeps 16 bits of a sample index per
+// entry plus PL bits in planes beside it (an LDS atomic OR per set bit): 2.125 / 2.25 bytes per entry instead of 4,
+// i.e. slices of ~45 000 / ~42 700 samples instead of 23 976 - the reference's SunSpots curve (74 326) takes two
+// slices instead of four.
+template <int KMAX, typename IdxT = unsigned short, int NB = kNB, bool MULTI = false, int PL = 0>
 __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
-    static_assert(!P17 || (MULTI && sizeof(IdxT) == 4), "the bit plane belongs to the several-slice instance");
+    constexpr bool P17 = PL > 0;
+    static_assert(PL >= 0 && PL <= 2 && (!P17 || (MULTI && sizeof(IdxT) == 4)), "the bit planes belong to the several-slice instance");
     constexpr int kWaveBytes = FL<IdxT>::wave_bytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned char *wbuf = lds_raw;                                                  // P3a: per-wave scratch
@@ -937,11 +939,16 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
     unsigned *defer = reinterpret_cast<unsigned *>(bnds + kRanges + 8);             // [16]
     IdxT *order = reinterpret_cast<IdxT *>(defer + 16);                             // [slice + 64]
     unsigned short *order16 = reinterpret_cast<unsigned short *>(defer + 16);       // P17: low 16 bits per entry ...
-    const int plane_words = P17 ? (a.slice_cap + 64 + 31) / 32 : 0;
-    unsigned *plane = reinterpret_cast<unsigned *>(order16 + ((a.slice_cap + 64 + 7) & ~7));   // ... + bit 16
+    const int plane_words = P17 ? (a.slice_cap + 64 + 31) / 32 : 0;                 // per plane
+    unsigned *plane = reinterpret_cast<unsigned *>(order16 + ((a.slice_cap + 64 + 7) & ~7));   // ... + bits 16 (, 17)
     auto order_get = [&](int pos) -> unsigned {
-        if constexpr (P17) return (unsigned)order16[pos] | (((plane[pos >> 5] >> (pos & 31)) & 1u) << 16);
-        else return (unsigned)order[pos];
+        if constexpr (P17) {
+            unsigned v = (unsigned)order16[pos] | (((plane[pos >> 5] >> (pos & 31)) & 1u) << 16);
+            if constexpr (PL > 1) v |= ((plane[plane_words + (pos >> 5)] >> (pos & 31)) & 1u) << 17;
+            return v;
+        } else {
+            return (unsigned)order[pos];
+        }
     };
 #define PDC_ORDER_GET(pos) order_get(pos)
     __shared__ unsigned wave_tot[kWaves];
@@ -1169,7 +1176,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
             __syncthreads();   // every thread has read what it needs from the start offsets
             if (tid < 16) defer[tid] = tid == 15 ? (unsigned)kWaves : 0u;
             if constexpr (P17) {
-                for (int x = tid; x < plane_words; x += kBlock) plane[x] = 0u;
+                for (int x = tid; x < PL * plane_words; x += kBlock) plane[x] = 0u;
                 __syncthreads();
             }
             {
@@ -1193,7 +1200,9 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                             const unsigned pos = atomicAdd(&hist[b], 1u) - (unsigned)consumed;
                             if constexpr (P17) {
                                 order16[pos] = (unsigned short)i;
-                                if (i >> 16) atomicOr(&plane[pos >> 5], 1u << (pos & 31));
+                                if ((i >> 16) & 1) atomicOr(&plane[pos >> 5], 1u << (pos & 31));
+                                if constexpr (PL > 1)
+                                    if ((i >> 17) & 1) atomicOr(&plane[plane_words + (pos >> 5)], 1u << (pos & 31));
                             } else {
                                 order[pos] = (IdxT)i;
                             }
@@ -2274,15 +2283,16 @@ int cu_count(int device) {
     return cached[device];
 }
 
-template <int KMAX, typename IdxT = unsigned short, int NB = fast::kNB, bool MULTI = false, bool P17 = false>
+template <int KMAX, typename IdxT = unsigned short, int NB = fast::kNB, bool MULTI = false, int PL = 0>
 int launch_fast(const fast::FastArgs &a, int64_t grid, hipStream_t st) {
+    constexpr bool P17 = PL > 0;
     const int64_t slice = MULTI ? a.slice_cap : a.n;
     const int64_t entries = (slice + 64 + 7) & ~(int64_t)7;
     const size_t lds = (size_t)fast::FL<IdxT>::fixed +
-                       (P17 ? (size_t)entries * 2 + (size_t)((slice + 64 + 31) / 32) * 4 + 16 : (size_t)entries * sizeof(IdxT));
+                       (P17 ? (size_t)entries * 2 + (size_t)PL * ((slice + 64 + 31) / 32) * 4 + 16 : (size_t)entries * sizeof(IdxT));
     PDC_REQUIRE(lds <= (size_t)fast::kLdsTotalDyn, "stringlength: slice of %lld samples does not fit LDS", (long long)slice);
-    PDC_TRY(allow_dynamic_lds((const void *)fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI, P17>, fast::kLdsTotalDyn));
-    hipLaunchKernelGGL((fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI, P17>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    PDC_TRY(allow_dynamic_lds((const void *)fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI, PL>, fast::kLdsTotalDyn));
+    hipLaunchKernelGGL((fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI, PL>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     return PDC_OK;
 }
 
@@ -2476,12 +2486,15 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
             // (sample indices still fit 16 bits: slices of 52 112 instead of 23 976 - two slices, not three)
             f.slice_cap = fast::FL<unsigned short>::capacity;
             PDC_TRY((launch_fast<4, unsigned short, fast::kNBLarge, true>(f, grid, st)));
-        } else if (n > fast::kCapacity && n < 131072) {
-            // (17-bit sample indices: 16 bits per entry + a bit plane - slices of ~45 000)
+        } else if (n > fast::kCapacity && n < 262144) {
+            // (17- / 18-bit sample indices: 16 bits per entry + one / two bit planes - slices of ~45 000 / ~42 700)
             static const bool p17_on = [] { const char *e = getenv("PDC_SL_P17"); return !(e && e[0] == '0'); }();
-            if (p17_on) {
+            if (p17_on && n < 131072) {
                 f.slice_cap = fast::kCapacity17;
-                PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true, true>(f, grid, st)));
+                PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true, 1>(f, grid, st)));
+            } else if (p17_on) {
+                f.slice_cap = fast::kCapacity18;
+                PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true, 2>(f, grid, st)));
             } else {
                 PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true>(f, grid, st)));
             }
