@@ -210,6 +210,14 @@ def test_aov_and_entropy_host_rules(oracle_backend):
     assert so.cond_entropy(t, np.zeros_like(t), 7.0, 8, 4) == 0.0
 
 
+def test_one_precedence_rule_for_device_and_devices():
+    """`devices`, when given, wins over `device` everywhere (GLS.__call__ and bootstrap used to disagree)."""
+    assert _cabi.pick_device(None, None) is None
+    assert _cabi.pick_device(3, None) == 3
+    assert _cabi.pick_device(0, (1,)) == 1 and _cabi.pick_device(None, (2, 5)) == 2
+    assert _cabi.pick_device(4, ()) == 4
+
+
 def test_package_imports_and_runs_host_logic_without_torch():
     """Nothing in the package needs torch (the one-rank-per-GPU launcher glue lives in tools/torchrun_sharded.py):
     the callables, the containers and the ctypes binding import with torch made unimportable."""

@@ -224,6 +224,56 @@ def test_transient_streams_do_not_grow_the_scratch_table():
         b.free()
 
 
+def test_scratch_table_never_frees_a_block_in_use():
+    """the per-(device, stream) scratch table is true LRU with a per-device cap of 64, its entries
+    are pinned from the look-up until the caller's launches are enqueued, and only entries whose stream has run
+    dry are evicted.  90 live streams (more than the cap) used round-robin, then four host threads hammering
+    their own streams at once: every result must be the single-stream one."""
+    import threading
+    lib = _cabi.lib()
+    t, x, _ = phase_inputs(30_000, 5)
+    periods = np.linspace(0.7, 30.0, 48)                     # few periods x many samples: split mode (uses the table)
+    bufs = [_cabi.DeviceBuffer.from_array(a) for a in (t, x, periods)]
+    sigma = float(np.var(x, ddof=1))
+    want = _cabi.pdm_scan(t, x, periods, 5, 2, sigma)
+    streams, outs = [], []
+    for _ in range(90):
+        s = C.c_void_p()
+        _cabi.check(lib.pdc_stream_create(0, C.byref(s)))
+        streams.append(s)
+        outs.append(_cabi.DeviceBuffer(periods.size * 8))
+    for rnd in range(2):
+        for s, o in zip(streams, outs):                      # enqueue on all of them, then look
+            _cabi.check(lib.pdc_pdm_scan_dev(0, s, bufs[0].ptr, bufs[1].ptr, t.size, bufs[2].ptr, periods.size, 5, 2,
+                                             sigma, o.ptr))
+        _cabi.check(lib.pdc_device_sync(0))
+        for o in outs:
+            assert np.array_equal(o.to_array(np.float64, periods.size), want), rnd
+    bad = []
+
+    def hammer(k):
+        try:
+            for _ in range(25):
+                for s, o in list(zip(streams, outs))[k::4]:
+                    _cabi.check(lib.pdc_pdm_scan_dev(0, s, bufs[0].ptr, bufs[1].ptr, t.size, bufs[2].ptr, periods.size,
+                                                     5, 2, sigma, o.ptr))
+        except Exception as exc:                              # pragma: no cover
+            bad.append(exc)
+    threads = [threading.Thread(target=hammer, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not bad, bad
+    _cabi.check(lib.pdc_device_sync(0))
+    for o in outs:
+        assert np.array_equal(o.to_array(np.float64, periods.size), want)
+    for s in streams:
+        _cabi.check(lib.pdc_stream_destroy(0, s))
+    for b in bufs + outs:
+        b.free()
+
+
 def test_cond_entropy_dev_entry_ignores_out_of_range_bins():
     """the kernel used the caller's double as an LDS index unchecked.  Through the `_dev` entry
     a NaN / negative / too large magnitude bin now counts nowhere (as if the sample were absent); the host
