@@ -375,3 +375,187 @@ def stringlength(time, values, dphi=0.1, n_periods=1000):
     freq = 1 / periods
     order = np.argsort(freq, kind="stable")
     return freq[order], ell[order]
+
+
+# ---- Supersmoother period search (the TODO at spectral.py:8: "check out Supersmoother (Reimann 1994)") -----------
+# The reference has no implementation: what follows restates the PUBLISHED algorithm - Friedman's variable span
+# smoother (J. H. Friedman 1984, "A variable span smoother", SLAC PUB-3477 / LCS TR 5; the Fortran `supsmu` /
+# `smooth` distributed with it and shipped as R's stats::supsmu, periodic = TRUE) applied to the phase-folded
+# curve, with Reimann's statistic (J. D. Reimann 1994, PhD thesis, UC Berkeley): the absolute residuals about
+# the smooth.  PARITY UNPINNED BY THE REFERENCE.
+SS_SPANS = (0.05, 0.2, 0.5)          # tweeter, midrange, woofer
+SS_BIG, SS_SML, SS_EPS = 1.0e20, 1.0e-7, 1.0e-3
+
+
+def ss_half_width(n, span):
+    """Points on either side of the centre of a running-lines window (`smooth`: ibw)."""
+    ibw = int(0.5 * span * n + 0.5)
+    return max(ibw, 2)
+
+
+def ss_smooth_incremental(x, y, span, vsmlsq, cv):
+    """Literal restatement of Friedman's `smooth` for periodic x in [0, 1) (jper = 2), unit weights: the running
+    window of 2 ibw + 1 points is slid with the updating formulas, one point out, one point in; pure Python loops,
+    small n only - it exists to pin the vectorised form below."""
+    n = len(x)
+    ibw = ss_half_width(n, span)
+    it = min(2 * ibw + 1, n)
+    xm = ym = var = cvar = fbw = 0.0
+    for i in range(1, it + 1):
+        j = i - ibw - 1
+        xti = x[j - 1] if j >= 1 else x[n + j - 1] - 1.0
+        yj = y[j - 1] if j >= 1 else y[n + j - 1]
+        fbo = fbw
+        fbw = fbw + 1.0
+        xm = (fbo * xm + xti) / fbw
+        ym = (fbo * ym + yj) / fbw
+        tmp = fbw * (xti - xm) / fbo if fbo > 0.0 else 0.0
+        var += tmp * (xti - xm)
+        cvar += tmp * (yj - ym)
+    smo = np.empty(n)
+    acvr = np.zeros(n)
+    for j in range(1, n + 1):
+        out, inn = j - ibw - 1, j + ibw
+        if out < 1:
+            out = n + out
+            xto, xti = x[out - 1] - 1.0, x[inn - 1]
+        elif inn > n:
+            inn = inn - n
+            xti, xto = x[inn - 1] + 1.0, x[out - 1]
+        else:
+            xto, xti = x[out - 1], x[inn - 1]
+        fbo = fbw
+        fbw = fbw - 1.0
+        tmp = fbo * (xto - xm) / fbw if fbw > 0.0 else 0.0
+        var -= tmp * (xto - xm)
+        cvar -= tmp * (y[out - 1] - ym)
+        if fbw > 0.0:
+            xm = (fbo * xm - xto) / fbw
+            ym = (fbo * ym - y[out - 1]) / fbw
+        fbo = fbw
+        fbw = fbw + 1.0
+        xm = (fbo * xm + xti) / fbw
+        ym = (fbo * ym + y[inn - 1]) / fbw
+        tmp = fbw * (xti - xm) / fbo if fbo > 0.0 else 0.0
+        var += tmp * (xti - xm)
+        cvar += tmp * (y[inn - 1] - ym)
+        a = cvar / var if var > vsmlsq else 0.0
+        smo[j - 1] = a * (x[j - 1] - xm) + ym
+        if cv:
+            h = 1.0 / fbw
+            if var > vsmlsq:
+                h += (x[j - 1] - xm) ** 2 / var
+            a1 = 1.0 - h
+            if a1 > 0.0:
+                acvr[j - 1] = abs(y[j - 1] - smo[j - 1]) / a1
+            elif j > 1:
+                acvr[j - 1] = acvr[j - 2]
+    return ss_average_ties(x, smo), acvr
+
+
+def ss_average_ties(x, smo):
+    """`smooth`, label 90-110: fitted values of equal abscissae are replaced by their mean."""
+    smo = np.array(smo, dtype=float)
+    n = len(x)
+    j = 0
+    while j < n:
+        j0 = j
+        while j + 1 < n and x[j + 1] <= x[j]:
+            j += 1
+        if j > j0:
+            smo[j0:j + 1] = smo[j0:j + 1].sum() / (j - j0 + 1)
+        j += 1
+    return smo
+
+
+def ss_smooth(x, y, span, vsmlsq, cv):
+    """The same smoother from window sums (long-double prefix sums over the periodic extension x - 1, x, x + 1):
+    window of sample j = the 2 ibw + 1 points j - ibw .. j + ibw, mean line through them evaluated at x[j], and -
+    `cv` - the absolute leave-one-out residual |y - smo| / (1 - 1/fbw - (x - xm)^2 / var)."""
+    x = np.asarray(x, dtype=float)
+    y = np.asarray(y, dtype=float)
+    n = x.size
+    ibw = ss_half_width(n, span)
+    if 2 * ibw + 1 > n:
+        raise ValueError("supersmoother: too few samples for the span")
+    L = np.longdouble
+    xe = np.concatenate([x - 1.0, x, x + 1.0]).astype(L)
+    ye = np.concatenate([y, y, y]).astype(L)
+    def win(v):
+        c = np.concatenate([[L(0)], np.cumsum(v)])
+        j = np.arange(n) + n
+        return c[j + ibw + 1] - c[j - ibw]
+    fbw = L(2 * ibw + 1)
+    sx, sy, sxx, sxy = win(xe), win(ye), win(xe * xe), win(xe * ye)
+    xm, ym = sx / fbw, sy / fbw
+    var = sxx - fbw * xm * xm
+    cvar = sxy - fbw * xm * ym
+    a = np.where(var > vsmlsq, cvar / np.where(var > vsmlsq, var, 1), 0)
+    xl = x.astype(L)
+    smo = a * (xl - xm) + ym
+    acvr = np.zeros(n)
+    if cv:
+        h = 1 / fbw + np.where(var > vsmlsq, (xl - xm) ** 2 / np.where(var > vsmlsq, var, 1), 0)
+        a1 = 1 - h
+        ok = a1 > 0
+        acvr = np.where(ok, np.abs(y.astype(L) - smo) / np.where(ok, a1, 1), 0).astype(float)
+        for j in np.nonzero(~ok)[0]:                    # (`smooth`, label 70: carried over from the point before)
+            if j > 0:
+                acvr[j] = acvr[j - 1]
+    return ss_average_ties(x, smo.astype(float)), acvr
+
+
+def supersmoother(x, y, alpha=0.0, smooth=ss_smooth):
+    """Friedman's `supsmu` for periodic x in [0, 1), sorted ascending, unit weights, automatic span: three
+    running-lines smooths (tweeter / midrange / woofer) with cross-validated residuals; the residuals smoothed
+    with the midrange span; per point the span with the smallest smoothed residual (pulled towards the woofer by
+    the bass control `alpha` in (0, 10]); those spans smoothed (midrange); the two neighbouring smooths
+    interpolated at the smoothed span; the result smoothed with the tweeter span."""
+    x = np.asarray(x, dtype=float)
+    y = np.asarray(y, dtype=float)
+    n = x.size
+    i, j = n // 4, 3 * (n // 4)                     # (1-based in the Fortran: x(i), x(j))
+    scale = x[j - 1] - x[max(i, 1) - 1]
+    while scale <= 0.0:                             # (`supsmu`, label 30: widen until the abscissae differ)
+        if j < n:
+            j += 1
+        if i > 1:
+            i -= 1
+        if j >= n and i <= 1:
+            break
+        scale = x[j - 1] - x[i - 1]
+    vsmlsq = (SS_EPS * scale) ** 2
+    sm = np.empty((3, n))
+    res = np.empty((3, n))
+    for k, span in enumerate(SS_SPANS):
+        sm[k], acvr = smooth(x, y, span, vsmlsq, True)
+        res[k], _ = smooth(x, acvr, SS_SPANS[1], vsmlsq, False)
+    best = np.argmin(res, axis=0)                   # (first minimum: `if (sc(j,2i) < resmin)`)
+    resmin = res[best, np.arange(n)]
+    span_j = np.asarray(SS_SPANS)[best]
+    if 0.0 < alpha <= 10.0:
+        pull = (resmin < res[2]) & (res[2] > 0)
+        ratio = np.maximum(SS_SML, resmin / np.where(res[2] > 0, res[2], 1.0))
+        span_j = np.where(pull, span_j + (SS_SPANS[2] - span_j) * ratio ** (10.0 - alpha), span_j)
+    span_s, _ = smooth(x, span_j, SS_SPANS[1], vsmlsq, False)
+    span_s = np.clip(span_s, SS_SPANS[0], SS_SPANS[2])
+    f = span_s - SS_SPANS[1]
+    up = f >= 0.0
+    fu = f / (SS_SPANS[2] - SS_SPANS[1])
+    fd = -f / (SS_SPANS[1] - SS_SPANS[0])
+    mixed = np.where(up, (1.0 - fu) * sm[1] + fu * sm[2], (1.0 - fd) * sm[1] + fd * sm[0])
+    out, _ = smooth(x, mixed, SS_SPANS[0], vsmlsq, False)
+    return out
+
+
+def supersmoother_stat(t, y, period, alpha=0.0):
+    """Mean absolute residual of the folded curve about its supersmoother fit (Reimann 1994): the fold and the
+    stable sort by phase are the reference's (core.py:543-544, 473-477), as for StringLength."""
+    phi = (np.asarray(t, dtype=float) - 0.0) / period % 1
+    order = np.argsort(phi, kind="stable")
+    xs, ys = phi[order], np.asarray(y, dtype=float)[order]
+    return float(np.mean(np.abs(ys - supersmoother(xs, ys, alpha))))
+
+
+def supersmoother_scan(t, y, periods, alpha=0.0):
+    return np.array([supersmoother_stat(t, y, p, alpha) for p in np.asarray(periods, dtype=float)])
