@@ -350,6 +350,21 @@ int pdc_stringlength_scan_multi(const double *t, const double *m, int64_t n,
                                 const double *periods, int64_t n_periods,
                                 double *ell_out, const int *devices, int n_devices);
 
+/* Supersmoother period search - the reference names it in one line ("TODO: check out Supersmoother (Reimann
+ * 1994)", spectral.py:8) and has no code.  Built from the published algorithm: per trial period the curve is
+ * folded and sorted by phase exactly as for StringLength (core.py:543-544, 473-477), Friedman's variable span
+ * smoother (Friedman 1984, SLAC PUB-3477: `supsmu` with periodic abscissae, spans 0.05 / 0.2 / 0.5, bass
+ * control `alpha` in [0, 10], 0 = off) is fitted to (phase, y), and stat_out[p] = the mean absolute residual
+ * about the fit (Reimann 1994): minimal at the period.  Needs n >= 5.  Parity unpinned by the reference; the
+ * oracle restates the published Fortran (oracle/scan_oracle.py: supersmoother*).
+ * The device form takes resident inputs and a workspace of pdc_supersmoother_work_bytes(n, n_periods) bytes. */
+int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const double *periods, int64_t n_periods,
+                           double alpha, double *stat_out, int device);
+int64_t pdc_supersmoother_work_bytes(int64_t n, int64_t n_periods);
+int pdc_supersmoother_scan_dev(int device, void *stream, const double *d_t, const double *d_y, int64_t n,
+                               const double *d_periods, int64_t n_periods, double alpha, double *d_stat, void *work,
+                               int64_t work_bytes);
+
 #ifdef __cplusplus
 }
 #endif

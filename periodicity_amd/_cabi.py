@@ -100,6 +100,9 @@ PROTOTYPES = {
     "pdc_phase_plan_kernel_ms": (_I, [_VP, C.POINTER(C.c_float)]),
     "pdc_phase_plan_destroy": (_I, [_VP]),
     "pdc_stringlength_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _VP, _VP, _I]),
+    "pdc_supersmoother_scan": (_I, [_VP, _VP, _L, _VP, _L, _D, _VP, _I]),
+    "pdc_supersmoother_work_bytes": (_L, [_L, _L]),
+    "pdc_supersmoother_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _D, _VP, _VP, _L]),
 }
 
 
@@ -576,6 +579,20 @@ def stringlength_scan(t, m, periods, device=None, devices=None):
 
 
 PHASE_KINDS = {"pdm": 0, "aov": 1, "cond_entropy": 2, "stringlength": 3, "gregory_loredo": 4}
+
+
+def supersmoother_scan(t, y, periods, alpha=0.0, device=None, devices=None):
+    """Mean absolute residual of the folded curve about its supersmoother fit at every trial period
+    (``pdc_supersmoother_scan``; Friedman 1984 + Reimann 1994, a TODO upstream)."""
+    t, y = _f64(t, "t"), _f64(y, "y")
+    periods = _f64(periods, "periods")
+    if y.size != t.size:
+        raise ValueError("Input arrays have incompatible lengths.")
+    out = np.empty(periods.size, dtype=np.float64)
+    device = pick_device(device, devices)
+    dev = default_device() if device is None else device
+    check(lib().pdc_supersmoother_scan(_ptr(t), _ptr(y), t.size, _ptr(periods), periods.size, float(alpha), _ptr(out), dev))
+    return out
 
 
 class PhasePlan:

@@ -1701,6 +1701,8 @@ struct StreamArgs {
     unsigned *boff;             // [batch][s1][W]    where group w's records start in the bin's list (exact: from
                                 //                   the groups' own histograms - no slack, no overflow)
     unsigned *bcnt;             // [batch][s1]       records of every bin
+    unsigned *bstart;           // [batch][s1]       sorted position of every bin's first record
+    rec_t *sorted;              // NULL, or [batch][n]: every period's (phase, m) in sorted order (Supersmoother)
     unsigned *flag;             // [batch]           != 0: left to the general kernel
     rec_t *pm;                  // [batch][s1][kCap] (phase, m)
     unsigned *ix;               // [batch][s1][kCap] sample index (ties)
@@ -1838,6 +1840,31 @@ __global__ __launch_bounds__(256) void sl_lut_kernel(StreamArgs a) {
             at += gcnt[b * W + w];
         }
         a.bcnt[(int64_t)q * a.s1 + b] = at;
+    }
+    // sorted position of every bin's first record (the Supersmoother path lays the sorted curve out in one piece)
+    __syncthreads();
+    {
+        constexpr int kBins = kS1Max / 256;   // consecutive bins per thread
+        unsigned c[kBins], tot = 0u;
+#pragma unroll
+        for (int x = 0; x < kBins; ++x) {
+            const int b = tid * kBins + x;
+            c[x] = 0u;
+            if (b < a.s1)
+                for (int w = 0; w < W; ++w) c[x] += gcnt[b * W + w];
+            tot += c[x];
+        }
+        const unsigned inc = wave_scan_add(tot);
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        unsigned at = inc - tot;
+        for (int x = 0; x < wave; ++x) at += wave_tot[x];
+#pragma unroll
+        for (int x = 0; x < kBins; ++x) {
+            const int b = tid * kBins + x;
+            if (b < a.s1) a.bstart[(int64_t)q * a.s1 + b] = at;
+            at += c[x];
+        }
     }
 }
 
@@ -2105,6 +2132,12 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             pphi = lane_below(phi, pphi);
             pmm = lane_below(mm, pmm);
             if (live && p > 0) acc += short_hypot(mm - pmm, phi - pphi);
+            if (a.sorted && live) {
+                rec_t r;
+                r.x = phi;
+                r.y = mm;
+                a.sorted[(int64_t)q * a.n + a.bstart[item] + p] = r;
+            }
             if (live && p == 0) {
                 a.ssum[item * 4 + 0] = phi;
                 a.ssum[item * 4 + 1] = mm;
@@ -2179,6 +2212,8 @@ __global__ __launch_bounds__(256) void sl_link_kernel(StreamArgs a) {
 
 }  // namespace stream
 
+#include "supersmoother.inc"
+
 int64_t pad_pow2(int64_t n) {
     int64_t p = 2;
     while (p < n) p <<= 1;
@@ -2223,7 +2258,7 @@ bool stream_takes(int64_t n) { return n >= stream_min_n() && n >= 4096 && n <= k
 
 struct StreamShape {
     int s1, batch, groups, tiles_w;
-    int64_t o_bad, o_flag, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_ssum, o_slen, o_ix, o_pm, o_todo, o_tcount, total;
+    int64_t o_bad, o_flag, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_ix, o_pm, o_todo, o_tcount, total;
 };
 StreamShape stream_shape(int64_t n, int64_t n_periods) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
@@ -2252,7 +2287,8 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     h.o_clo = h.o_lut + up(batch * stream::kNC * 2);
     h.o_sub = h.o_clo + up(batch * (h.s1 + 1) * 2);
     h.o_bcnt = h.o_sub + up(items * groups * 4);
-    h.o_ssum = h.o_bcnt + up(items * 4);
+    h.o_bstart = h.o_bcnt + up(items * 4);
+    h.o_ssum = h.o_bstart + up(items * 4);
     h.o_slen = h.o_ssum + up(items * 32);
     h.o_ix = h.o_slen + up(items * 8);
     h.o_pm = h.o_ix + up(items * stream::kCap * 4);
@@ -2281,6 +2317,99 @@ int cu_count(int device) {
         cached[device] = v;
     }
     return cached[device];
+}
+
+
+stream::StreamArgs stream_args(const StreamShape &h, char *area, const double *d_t, const double *d_m,
+                               const double *d_periods, int64_t n, double *d_ell) {
+    stream::StreamArgs sa;
+    sa.t = d_t;
+    sa.m = d_m;
+    sa.periods = d_periods;
+    sa.n = n;
+    sa.s1 = h.s1;
+    sa.groups = h.groups;
+    sa.tiles_w = h.tiles_w;
+    sa.bad_t = reinterpret_cast<unsigned *>(area + h.o_bad);
+    sa.flag = reinterpret_cast<unsigned *>(area + h.o_flag);
+    sa.hist = reinterpret_cast<unsigned *>(area + h.o_hist);
+    sa.lut = reinterpret_cast<unsigned short *>(area + h.o_lut);
+    sa.clo = reinterpret_cast<unsigned short *>(area + h.o_clo);
+    sa.boff = reinterpret_cast<unsigned *>(area + h.o_sub);
+    sa.bcnt = reinterpret_cast<unsigned *>(area + h.o_bcnt);
+    sa.bstart = reinterpret_cast<unsigned *>(area + h.o_bstart);
+    sa.sorted = nullptr;
+    sa.ssum = reinterpret_cast<double *>(area + h.o_ssum);
+    sa.slen = reinterpret_cast<double *>(area + h.o_slen);
+    sa.ix = reinterpret_cast<unsigned *>(area + h.o_ix);
+    sa.pm = reinterpret_cast<fast::rec_t *>(area + h.o_pm);
+    sa.todo = reinterpret_cast<unsigned char *>(area + h.o_todo);
+    sa.todo_count = reinterpret_cast<unsigned *>(area + h.o_tcount);
+    sa.ell = d_ell;
+    return sa;
+}
+
+// the four launches that counting-sort one batch of periods by phase bin and sort every bin (no link kernel)
+int stream_sort_batch(int device, hipStream_t st, const StreamShape &h, stream::StreamArgs &sa, int64_t p0, int64_t bc) {
+    sa.p0 = p0;
+    sa.batch = (int)bc;
+    PDC_REQUIRE(bc * h.s1 < ((int64_t)1 << 31), "stringlength: grid too large");
+    const bool wide = h.s1 > 512;
+    const size_t lds_a = stream::lds_part(wide ? 1024 : 512);
+    const dim3 wg((unsigned)(bc * h.groups));
+    hipLaunchKernelGGL(stream::sl_hist_kernel, wg, dim3(stream::kBA), 0, st, sa);
+    hipLaunchKernelGGL(stream::sl_lut_kernel, dim3((unsigned)bc), dim3(256), (size_t)h.s1 * h.groups * 4, st, sa);
+    if (wide) hipLaunchKernelGGL(stream::sl_part_kernel<1024>, wg, dim3(stream::kBA), lds_a, st, sa);
+    else hipLaunchKernelGGL(stream::sl_part_kernel<512>, wg, dim3(stream::kBA), lds_a, st, sa);
+    const int64_t sort_slots = (int64_t)cu_count(device) * (stream::kLdsB + 1024 <= 80 * 1024 ? 2 : 1);
+    const int64_t sort_grid = bc * h.s1 < sort_slots ? bc * h.s1 : sort_slots;
+    hipLaunchKernelGGL(stream::sl_sort_kernel, dim3((unsigned)sort_grid), dim3(stream::kBB), stream::kLdsB, st, sa);
+    PDC_HIP(hipGetLastError());
+    return PDC_OK;
+}
+
+int stream_allow_lds(const StreamShape &h) {
+    PDC_TRY(allow_dynamic_lds((const void *)stream::sl_sort_kernel, (int)stream::kLdsB));
+    PDC_TRY(allow_dynamic_lds((const void *)stream::sl_lut_kernel, stream::kS1Max * stream::kGroupsMax * 4));
+    if (h.s1 > 512) PDC_TRY(allow_dynamic_lds((const void *)stream::sl_part_kernel<1024>, (int)stream::lds_part(1024)));
+    else PDC_TRY(allow_dynamic_lds((const void *)stream::sl_part_kernel<512>, (int)stream::lds_part(512)));
+    return PDC_OK;
+}
+
+// ---- Supersmoother: workspace -----------------------------------------------------------------------------
+struct SsShape {
+    StreamShape h;
+    bool streamed;
+    int batch, grid_ss, grid_fb;
+    int64_t stride, n_pad, o_sorted, o_scratch, o_gk, o_gi, o_bad, total;
+};
+SsShape ss_shape(int64_t n, int64_t n_periods) {
+    auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+    SsShape z;
+    z.streamed = n >= 4096 && n <= kStreamMaxN;
+    int64_t at = 0;
+    if (z.streamed) {
+        z.h = stream_shape(n, n_periods);
+        z.batch = z.h.batch;
+        at = up(z.h.total);
+    } else {
+        z.h = StreamShape{};
+        int64_t b = n_periods < 256 ? n_periods : 256;
+        z.batch = (int)(b < 1 ? 1 : b);
+    }
+    z.stride = (n + 8 + 7) & ~(int64_t)7;
+    int64_t g = ((int64_t)4 << 30) / (ss::kArrays * z.stride * 8);
+    g = g < 1 ? 1 : (g > 256 ? 256 : g);
+    z.grid_ss = (int)(g < z.batch ? g : z.batch);
+    z.grid_fb = z.batch < 256 ? z.batch : 256;
+    z.n_pad = pad_pow2(n);
+    z.o_sorted = at;
+    z.o_scratch = z.o_sorted + up((int64_t)z.batch * n * 16);
+    z.o_gk = z.o_scratch + up((int64_t)z.grid_ss * ss::kArrays * z.stride * 8);
+    z.o_gi = z.o_gk + up((int64_t)z.grid_fb * z.n_pad * 8);
+    z.o_bad = z.o_gi + up((int64_t)z.grid_fb * z.n_pad * 4);
+    z.total = z.o_bad + 256;
+    return z;
 }
 
 template <int KMAX, typename IdxT = unsigned short, int NB = fast::kNB, bool MULTI = false, int PL = 0>
@@ -2343,50 +2472,14 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
         const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
         char *area = static_cast<char *>(work) + scratch_bytes(n, n_periods, partition) + fast_table_bytes(n) +
                      duo_bytes(n_periods);
-        stream::StreamArgs sa;
-        sa.t = d_t;
-        sa.m = d_m;
-        sa.periods = d_periods;
-        sa.n = n;
-        sa.s1 = h.s1;
-        sa.groups = h.groups;
-        sa.tiles_w = h.tiles_w;
-        sa.bad_t = reinterpret_cast<unsigned *>(area + h.o_bad);
-        sa.flag = reinterpret_cast<unsigned *>(area + h.o_flag);
-        sa.hist = reinterpret_cast<unsigned *>(area + h.o_hist);
-        sa.lut = reinterpret_cast<unsigned short *>(area + h.o_lut);
-        sa.clo = reinterpret_cast<unsigned short *>(area + h.o_clo);
-        sa.boff = reinterpret_cast<unsigned *>(area + h.o_sub);
-        sa.bcnt = reinterpret_cast<unsigned *>(area + h.o_bcnt);
-        sa.ssum = reinterpret_cast<double *>(area + h.o_ssum);
-        sa.slen = reinterpret_cast<double *>(area + h.o_slen);
-        sa.ix = reinterpret_cast<unsigned *>(area + h.o_ix);
-        sa.pm = reinterpret_cast<fast::rec_t *>(area + h.o_pm);
-        sa.todo = reinterpret_cast<unsigned char *>(area + h.o_todo);
-        sa.todo_count = reinterpret_cast<unsigned *>(area + h.o_tcount);
-        sa.ell = d_ell;
+        stream::StreamArgs sa = stream_args(h, area, d_t, d_m, d_periods, n, d_ell);
         PDC_HIP(hipMemsetAsync(area + h.o_bad, 0, 256, st));
         PDC_HIP(hipMemsetAsync(sa.todo_count, 0, 256, st));
         hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, n, const_cast<unsigned *>(sa.bad_t));
-        PDC_TRY(allow_dynamic_lds((const void *)stream::sl_sort_kernel, (int)stream::kLdsB));
-        PDC_TRY(allow_dynamic_lds((const void *)stream::sl_lut_kernel, stream::kS1Max * stream::kGroupsMax * 4));
-        const bool wide = h.s1 > 512;
-        const size_t lds_a = stream::lds_part(wide ? 1024 : 512);
-        if (wide) PDC_TRY(allow_dynamic_lds((const void *)stream::sl_part_kernel<1024>, (int)lds_a));
-        else PDC_TRY(allow_dynamic_lds((const void *)stream::sl_part_kernel<512>, (int)lds_a));
+        PDC_TRY(stream_allow_lds(h));
         for (int64_t p0 = 0; p0 < n_periods; p0 += h.batch) {
             const int64_t bc = n_periods - p0 < h.batch ? n_periods - p0 : h.batch;
-            sa.p0 = p0;
-            sa.batch = (int)bc;
-            PDC_REQUIRE(bc * h.s1 < ((int64_t)1 << 31), "stringlength: grid too large");
-            const dim3 wg((unsigned)(bc * h.groups));
-            hipLaunchKernelGGL(stream::sl_hist_kernel, wg, dim3(stream::kBA), 0, st, sa);
-            hipLaunchKernelGGL(stream::sl_lut_kernel, dim3((unsigned)bc), dim3(256), (size_t)h.s1 * h.groups * 4, st, sa);
-            if (wide) hipLaunchKernelGGL(stream::sl_part_kernel<1024>, wg, dim3(stream::kBA), lds_a, st, sa);
-            else hipLaunchKernelGGL(stream::sl_part_kernel<512>, wg, dim3(stream::kBA), lds_a, st, sa);
-            const int64_t sort_slots = (int64_t)cu_count(device) * (stream::kLdsB + 1024 <= 80 * 1024 ? 2 : 1);
-            const int64_t sort_grid = bc * h.s1 < sort_slots ? bc * h.s1 : sort_slots;
-            hipLaunchKernelGGL(stream::sl_sort_kernel, dim3((unsigned)sort_grid), dim3(stream::kBB), stream::kLdsB, st, sa);
+            PDC_TRY(stream_sort_batch(device, st, h, sa, p0, bc));
             hipLaunchKernelGGL(stream::sl_link_kernel, dim3((unsigned)((bc + 3) / 4)), dim3(256), 0, st, sa);
             PDC_HIP(hipGetLastError());
         }
@@ -2540,6 +2633,94 @@ int pdc_stringlength_scan(const double *t, const double *m, int64_t n, const dou
     PDC_TRY(pdc_stringlength_scan_dev(device, st, (double *)d_t, (double *)d_m, n, (double *)d_p,
                                       n_periods, (double *)d_e, d_w, wb));
     PDC_HIP(hipMemcpyAsync(ell_out, d_e, n_periods * 8, hipMemcpyDeviceToHost, st));
+    PDC_HIP(hipStreamSynchronize(st));
+    return PDC_OK;
+}
+
+// ---- Supersmoother period search (spectral.py:8, a TODO upstream; Friedman 1984 + Reimann 1994) -----------------
+int64_t pdc_supersmoother_work_bytes(int64_t n, int64_t n_periods) {
+    if (n < 0 || n_periods < 0) return -1;
+    return ss_shape(n, n_periods).total;
+}
+
+int pdc_supersmoother_scan_dev(int device, void *stream, const double *d_t, const double *d_y, int64_t n,
+                               const double *d_periods, int64_t n_periods, double alpha, double *d_stat, void *work,
+                               int64_t work_bytes) {
+    PDC_REQUIRE(d_t && d_y && (d_periods || n_periods == 0) && (d_stat || n_periods == 0), "supersmoother: NULL argument");
+    PDC_REQUIRE(n >= 5 && n < ((int64_t)1 << 30), "supersmoother: between 5 and 2^30 samples (the woofer window spans "
+                                                  "half the curve)");
+    PDC_REQUIRE(n_periods >= 0, "supersmoother: negative size");
+    PDC_REQUIRE(alpha >= 0.0 && alpha <= 10.0, "supersmoother: the bass control alpha lies in [0, 10] (0 = off)");
+    const SsShape z = ss_shape(n, n_periods);
+    PDC_REQUIRE(work && work_bytes >= z.total, "supersmoother: workspace too small (%lld < %lld bytes)",
+                (long long)work_bytes, (long long)z.total);
+    if (n_periods == 0) return PDC_OK;
+    PDC_TRY(use_device(device));
+    hipStream_t st = (hipStream_t)stream;
+    char *base = static_cast<char *>(work);
+    fast::rec_t *sorted = reinterpret_cast<fast::rec_t *>(base + z.o_sorted);
+    unsigned *bad = reinterpret_cast<unsigned *>(base + (z.streamed ? z.h.o_bad : z.o_bad));
+    PDC_HIP(hipMemsetAsync(bad, 0, 256, st));
+    hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, n, bad);
+    stream::StreamArgs sa;
+    if (z.streamed) {
+        sa = stream_args(z.h, base, d_t, d_y, d_periods, n, nullptr);
+        sa.sorted = sorted;
+        PDC_TRY(stream_allow_lds(z.h));
+    }
+    ss::SsSortArgs fa;
+    fa.t = d_t;
+    fa.y = d_y;
+    fa.periods = d_periods;
+    fa.bad_t = bad;
+    fa.n = n;
+    fa.n_pad = z.n_pad;
+    fa.flag = z.streamed ? sa.flag : nullptr;
+    fa.gkeys = reinterpret_cast<unsigned long long *>(base + z.o_gk);
+    fa.gidx = reinterpret_cast<unsigned *>(base + z.o_gi);
+    fa.sorted = sorted;
+    ss::SsArgs ka;
+    ka.sorted = sorted;
+    ka.n = n;
+    ka.stride = z.stride;
+    ka.alpha = alpha;
+    ka.scratch = reinterpret_cast<double *>(base + z.o_scratch);
+    ka.stat = d_stat;
+    for (int64_t p0 = 0; p0 < n_periods; p0 += z.batch) {
+        const int64_t bc = n_periods - p0 < z.batch ? n_periods - p0 : z.batch;
+        if (z.streamed) PDC_TRY(stream_sort_batch(device, st, z.h, sa, p0, bc));
+        fa.p0 = p0;
+        fa.batch = (int)bc;
+        hipLaunchKernelGGL(ss::ss_sort_fallback_kernel, dim3((unsigned)(bc < z.grid_fb ? bc : z.grid_fb)), dim3(kBlock), 0,
+                           st, fa);
+        ka.p0 = p0;
+        ka.batch = (int)bc;
+        hipLaunchKernelGGL(ss::ss_smooth_kernel, dim3((unsigned)(bc < z.grid_ss ? bc : z.grid_ss)), dim3(ss::kB), 0, st, ka);
+        PDC_HIP(hipGetLastError());
+    }
+    return PDC_OK;
+}
+
+int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const double *periods, int64_t n_periods,
+                           double alpha, double *stat_out, int device) {
+    PDC_REQUIRE(t && y && (periods || n_periods == 0) && (stat_out || n_periods == 0), "supersmoother: NULL argument");
+    PDC_REQUIRE(n >= 0 && n_periods >= 0, "supersmoother: negative size");
+    PDC_TRY(use_device(device));
+    DeviceLock lock(device);
+    const int64_t wb = pdc_supersmoother_work_bytes(n, n_periods);
+    void *d_t, *d_y, *d_p, *d_s, *d_w;
+    PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
+    PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_y));
+    PDC_TRY(cached(device, SLOT_IN2, n_periods * 8, &d_p));
+    PDC_TRY(cached(device, SLOT_OUT0, n_periods * 8, &d_s));
+    PDC_TRY(cached(device, SLOT_WORK, wb, &d_w));
+    hipStream_t st = nullptr;
+    PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemcpyAsync(d_p, periods, n_periods * 8, hipMemcpyHostToDevice, st));
+    PDC_TRY(pdc_supersmoother_scan_dev(device, st, (double *)d_t, (double *)d_y, n, (double *)d_p, n_periods, alpha,
+                                       (double *)d_s, d_w, wb));
+    PDC_HIP(hipMemcpyAsync(stat_out, d_s, n_periods * 8, hipMemcpyDeviceToHost, st));
     PDC_HIP(hipStreamSynchronize(st));
     return PDC_OK;
 }

@@ -21,7 +21,7 @@ from .core import FSeries, TSeries
 
 MAX_CORES = cpu_count()
 
-__all__ = ["StringLength", "PDM", "AOV", "ConditionalEntropy", "GregoryLoredo"]
+__all__ = ["StringLength", "PDM", "AOV", "ConditionalEntropy", "GregoryLoredo", "SuperSmoother"]
 
 
 # ---- host-side grid / scaling rules (O(N) or O(n_periods) numpy, as upstream) -----------------------
@@ -215,6 +215,47 @@ class AOV(object):
         theta = _cabi.aov_scan(self.t, self.x, self.periods, self.n_bins, device=self.device,
                                devices=self.devices)
         self.periodogram = FSeries(1 / self.periods, theta)
+        return self.periodogram
+
+
+class SuperSmoother(object):
+    """Supersmoother period search - the reference only names it (``spectral.py:8``: "TODO: check out
+    Supersmoother (Reimann 1994)"); shaped like :class:`PDM`.  Per trial period the curve is folded and sorted by
+    phase, Friedman's variable span smoother (Friedman 1984: three running-lines smooths with spans 0.05 / 0.2 /
+    0.5 of the curve, periodic in phase, the span chosen per point by leave-one-out residuals) is fitted to it,
+    and the periodogram is the mean absolute residual about that fit (Reimann 1994): minimal at the period.
+
+    Parameters
+    ----------
+    alpha: float, optional
+        Friedman's bass control in [0, 10]: larger values pull the chosen spans towards the widest one
+        (smoother fits); 0 (the default) switches it off.
+    p_min, p_max, n_periods, oversample, cores:
+        The trial-period grid, exactly as for :class:`PDM` (``phase.py:167-180``).
+    device / devices: keyword-only
+        GPU ordinal (of a ``devices`` list the first entry is used: this scan runs on one GPU).
+    """
+
+    def __init__(self, alpha=0.0, p_min=None, p_max=None, n_periods=1000, oversample=1, cores=None,
+                 *, device=None, devices=None):
+        self.alpha = alpha
+        self.p_min, self.p_max = p_min, p_max
+        self.n_periods = n_periods
+        self.oversample = oversample
+        self.cores = cores
+        self.device = device
+        self.devices = None if devices is None else tuple(devices)
+
+    def __call__(self, signal):
+        signal = _coerce(signal)
+        self.signal = signal
+        self.t = np.asarray(signal.time, dtype=float)
+        self.x = np.asarray(signal.values, dtype=float)
+        self.periods, _, _ = _pdm_periods(signal, self.p_min, self.p_max, self.n_periods,
+                                          self.oversample)
+        stat = _cabi.supersmoother_scan(self.t, self.x, self.periods, self.alpha, device=self.device,
+                                        devices=self.devices)
+        self.periodogram = FSeries(1 / self.periods, stat)
         return self.periodogram
 
 

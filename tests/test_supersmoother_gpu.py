@@ -1,0 +1,72 @@
+"""The Supersmoother period search (a one-line TODO upstream, spectral.py:8) through the C ABI against the oracle's
+restatement of the published algorithm (Friedman 1984 `supsmu`, periodic; Reimann 1994).  PARITY UNPINNED BY THE
+REFERENCE: the oracle is pinned to a literal restatement of the Fortran's updating formulas (CPU test below)."""
+import numpy as np
+import pytest
+
+from oracle import scan_oracle as so
+from periodicity_amd import _cabi
+from periodicity_amd.core import TSeries
+from periodicity_amd.phase import SuperSmoother
+
+RTOL = 1e-9
+
+
+def curve(n, seed, even=False, period=7.3):
+    rng = np.random.default_rng(seed)
+    t = np.arange(float(n)) * 0.1 if even else np.sort(rng.uniform(0, 0.1 * n, n))
+    y = np.sin(2 * np.pi * t / period) + 0.3 * np.cos(4 * np.pi * t / period) + 0.2 * rng.standard_normal(n)
+    return t, y
+
+
+def test_oracle_window_sums_equal_the_literal_updating_formulas():
+    """CPU: the vectorised smoother (window sums) against the literal restatement of Friedman's `smooth` (one point
+    out, one point in), ties included, and the whole of `supsmu` built on either."""
+    rng = np.random.default_rng(1)
+    for n in (40, 101, 400):
+        x = np.sort(rng.uniform(0, 1, n))
+        y = np.sin(2 * np.pi * x) + 0.3 * rng.standard_normal(n)
+        if n == 101:
+            x[10] = x[11]
+            x[50:53] = x[50]
+        v = (1e-3 * (x[3 * (n // 4) - 1] - x[n // 4 - 1])) ** 2
+        for span in so.SS_SPANS:
+            a, ra = so.ss_smooth_incremental(x, y, span, v, True)
+            b, rb = so.ss_smooth(x, y, span, v, True)
+            np.testing.assert_allclose(b, a, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(rb, ra, rtol=0, atol=1e-12)
+        for alpha in (0.0, 4.0):
+            np.testing.assert_allclose(so.supersmoother(x, y, alpha), so.supersmoother(x, y, alpha, so.ss_smooth_incremental),
+                                       rtol=0, atol=1e-12)
+    t, y = curve(2000, 3)
+    per = np.linspace(5.0, 10.0, 21)
+    assert abs(per[np.argmin(so.supersmoother_scan(t, y, per))] - 7.3) < 0.26
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,even,alpha", [(300, False, 0.0), (5000, False, 0.0), (5000, False, 5.0), (9000, False, 0.0),
+                                          (4000, True, 0.0), (6000, True, 2.0)])
+def test_supersmoother_scan_matches_the_oracle(n, even, alpha):
+    """Below 4096 samples every period is sorted by the fallback kernel, above by the streamed kernels; even
+    sampling at commensurate periods gives tied phases (averaged fits) and clustered bins (fallback sort)."""
+    t, y = curve(n, n + 1, even)
+    periods = np.concatenate([np.linspace(2.1, 40.0, 24), [7.3, 10.0, 0.5, 25.0, 3.7 * t[-1]]])
+    got = _cabi.supersmoother_scan(t, y, periods, alpha)
+    want = so.supersmoother_scan(t, y, periods, alpha)
+    np.testing.assert_allclose(got, want, rtol=RTOL)
+    assert np.array_equal(got, _cabi.supersmoother_scan(t, y, periods, alpha))      # bitwise repeatable
+
+
+@pytest.mark.gpu
+def test_supersmoother_class_finds_the_period_and_edges():
+    t, y = curve(6000, 11)
+    res = SuperSmoother(p_min=5.0, p_max=10.0, n_periods=201)(TSeries(t, y))
+    assert res.size == 201 and abs(res.period[np.argmin(res.values)] - 7.3) < 0.03
+    assert np.all(np.diff(res.frequency) > 0)
+    with pytest.raises(ValueError):
+        _cabi.supersmoother_scan(t[:4], y[:4], [1.0])                  # the woofer window needs five points
+    with pytest.raises(ValueError):
+        _cabi.supersmoother_scan(t, y, [1.0], alpha=11.0)
+    assert _cabi.supersmoother_scan(t, y, []).size == 0
+    five = _cabi.supersmoother_scan(t[:5], y[:5], [0.3, 1.7])
+    np.testing.assert_allclose(five, so.supersmoother_scan(t[:5], y[:5], [0.3, 1.7]), rtol=RTOL)
