@@ -119,7 +119,8 @@ def c5_inputs():
 KERNEL_SOURCES = {
     "gls_": ("gls.hip", "gls_epilogue.h", "pdc_device.h"),
     "pdm_": ("pdm.hip", "pdc_device.h"),
-    "sl_": ("stringlength.hip", "sl_ranges.inc", "pdc_device.h"),
+    "sl_": ("stringlength.hip", "sl_ranges.inc", "supersmoother.inc", "pdc_device.h"),
+    "ss_": ("stringlength.hip", "supersmoother.inc", "pdc_device.h"),
     "fft_": ("glsfft.hip", "pdc_device.h"),
     "glsfft_": ("glsfft.hip", "gls_epilogue.h", "pdc_device.h"),
     "peak": ("peaks.hip", "pdc_device.h"),
@@ -497,6 +498,18 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
                                                                 10, 5, bth.ptr)), reps=5, warm=2)
     fr, _ = two_fracs(("pdm_scan_kernel<", ", 2> grid"), ms, pdm_algorithmic_frac(pairs, ms), "40 flop/pair vs 78.6 TFLOP/s")
     out["c5_cond_entropy"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), "cells": "10 x 5", **fr}
+    # Supersmoother (a one-line TODO upstream, spectral.py:8): streamed sort + prefix-sum smoother, 4096 of C5's periods
+    n_ss = 4096
+    wss = lib.pdc_supersmoother_work_bytes(n, n_ss)
+    bss = DB(wss, dev)
+    ms = tm.ms(lambda: cabi.check(lib.pdc_supersmoother_scan_dev(dev, stream, bt5.ptr, bx.ptr, n, bp.ptr, n_ss, 0.0, bth.ptr,
+                                                                 bss.ptr, wss)), reps=3)
+    out["c5_supersmoother"] = {"ms": round(ms, 3), "Gpair_per_s": round(float(n) * n_ss / ms / 1e6, 2), "n_periods": n_ss,
+                               "executed_issue_frac": None, "algorithmic_frac": None,
+                               "note": "Friedman's variable span smoother on the phase-sorted curve, mean absolute residual "
+                                       "(Reimann 1994); parity unpinned by the reference; ~15 passes over 15 N-element arrays "
+                                       "per period in global scratch: latency-bound, no roofline claimed"}
+    bss.free()
     for b in (bt5, bx, bp, bth, bm, bsp, be, swork, bmag):
         b.free()
 

@@ -2394,12 +2394,13 @@ SsShape ss_shape(int64_t n, int64_t n_periods) {
         at = up(z.h.total);
     } else {
         z.h = StreamShape{};
-        int64_t b = n_periods < 256 ? n_periods : 256;
+        int64_t b = n_periods < 512 ? n_periods : 512;
         z.batch = (int)(b < 1 ? 1 : b);
     }
     z.stride = (n + 8 + 7) & ~(int64_t)7;
-    int64_t g = ((int64_t)4 << 30) / (ss::kArrays * z.stride * 8);
-    g = g < 1 ? 1 : (g > 256 ? 256 : g);
+    // two smoother workgroups per CU (their passes over the period's arrays are latency chains), within 6 GB of scratch
+    int64_t g = ((int64_t)6 << 30) / (ss::kArrays * z.stride * 8);
+    g = g < 1 ? 1 : (g > 512 ? 512 : g);
     z.grid_ss = (int)(g < z.batch ? g : z.batch);
     z.grid_fb = z.batch < 256 ? z.batch : 256;
     z.n_pad = pad_pow2(n);
