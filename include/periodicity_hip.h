@@ -360,6 +360,8 @@ int pdc_stringlength_scan_multi(const double *t, const double *m, int64_t n,
  * The device form takes resident inputs and a workspace of pdc_supersmoother_work_bytes(n, n_periods) bytes. */
 int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const double *periods, int64_t n_periods,
                            double alpha, double *stat_out, int device);
+int pdc_supersmoother_scan_multi(const double *t, const double *y, int64_t n, const double *periods, int64_t n_periods,
+                                 double alpha, double *stat_out, const int *devices, int n_devices);
 int64_t pdc_supersmoother_work_bytes(int64_t n, int64_t n_periods);
 int pdc_supersmoother_scan_dev(int device, void *stream, const double *d_t, const double *d_y, int64_t n,
                                const double *d_periods, int64_t n_periods, double alpha, double *d_stat, void *work,

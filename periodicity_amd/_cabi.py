@@ -101,6 +101,7 @@ PROTOTYPES = {
     "pdc_phase_plan_destroy": (_I, [_VP]),
     "pdc_stringlength_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _VP, _VP, _I]),
     "pdc_supersmoother_scan": (_I, [_VP, _VP, _L, _VP, _L, _D, _VP, _I]),
+    "pdc_supersmoother_scan_multi": (_I, [_VP, _VP, _L, _VP, _L, _D, _VP, _VP, _I]),
     "pdc_supersmoother_work_bytes": (_L, [_L, _L]),
     "pdc_supersmoother_scan_dev": (_I, [_I, _VP, _VP, _VP, _L, _VP, _L, _D, _VP, _VP, _L]),
 }
@@ -578,7 +579,7 @@ def stringlength_scan(t, m, periods, device=None, devices=None):
     return out
 
 
-PHASE_KINDS = {"pdm": 0, "aov": 1, "cond_entropy": 2, "stringlength": 3, "gregory_loredo": 4}
+PHASE_KINDS = {"pdm": 0, "aov": 1, "cond_entropy": 2, "stringlength": 3, "gregory_loredo": 4, "supersmoother": 5}
 
 
 def supersmoother_scan(t, y, periods, alpha=0.0, device=None, devices=None):
@@ -589,6 +590,11 @@ def supersmoother_scan(t, y, periods, alpha=0.0, device=None, devices=None):
     if y.size != t.size:
         raise ValueError("Input arrays have incompatible lengths.")
     out = np.empty(periods.size, dtype=np.float64)
+    if devices is not None and len(devices) > 1:
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        check(lib().pdc_supersmoother_scan_multi(_ptr(t), _ptr(y), t.size, _ptr(periods), periods.size, float(alpha),
+                                                 _ptr(out), _ptr(devs), devs.size))
+        return out
     device = pick_device(device, devices)
     dev = default_device() if device is None else device
     check(lib().pdc_supersmoother_scan(_ptr(t), _ptr(y), t.size, _ptr(periods), periods.size, float(alpha), _ptr(out), dev))

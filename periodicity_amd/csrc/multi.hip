@@ -597,8 +597,8 @@ int phase_scan_enqueue(PhasePlan *p, int kind, const double *periods, int64_t n_
 // A scan counts as pending only once EVERY slot has been enqueued: a failure half-way drains what is in
 // flight (copies from / into the staging blocks) and leaves the plan with nothing to download.
 int phase_scan(PhasePlan *p, int kind, const double *periods, int64_t n_periods, int nb, int nc, double sigma) {
-    PDC_REQUIRE(kind >= 0 && kind <= 4, "phase_plan_scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional "
-                                        "entropy), 3 (StringLength) or 4 (Gregory-Loredo)");
+    PDC_REQUIRE(kind >= 0 && kind <= 5, "phase_plan_scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional "
+                                        "entropy), 3 (StringLength), 4 (Gregory-Loredo) or 5 (Supersmoother)");
     PDC_REQUIRE((periods || n_periods == 0) && n_periods >= 0, "phase_plan_scan: bad period grid");
     PDC_TRY(phase_wait(p));   // the period / result staging blocks of the previous scan are free after this
     p->scanned = false;
@@ -770,6 +770,12 @@ int pdc_gl_scan_multi(const double *t, int64_t n, const double *periods, int64_t
     PDC_REQUIRE(m >= 1 && n_offsets >= 1 && (int64_t)m * n_offsets <= 190, "gregory_loredo: m * n_offsets must be 1..190");
     return phase_multi_entry(4, "gl_multi", t, nullptr, n, periods, n_periods, m * n_offsets, m, 1.0, log_s_out,
                              devices, n_devices);
+}
+
+int pdc_supersmoother_scan_multi(const double *t, const double *y, int64_t n, const double *periods, int64_t n_periods,
+                                 double alpha, double *stat_out, const int *devices, int n_devices) {
+    return phase_multi_entry(5, "supersmoother_multi", t, y, n, periods, n_periods, 1, 1, alpha, stat_out, devices,
+                             n_devices);
 }
 
 int pdc_stringlength_scan_multi(const double *t, const double *m, int64_t n,

@@ -718,14 +718,17 @@ extern "C" {
 
 int64_t pdc_phase_work_bytes(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
     if (kind == 3) return pdc_stringlength_work_bytes(n, n_periods);
+    if (kind == 5) return pdc_supersmoother_work_bytes(n, n_periods);
     return phase_stat_work_bytes(kind, n, n_periods, nb, nc);
 }
 
 int pdc_phase_scan_dev(int kind, int device, void *stream, const double *d_t, const double *d_v, int64_t n,
                        const double *d_periods, int64_t n_periods, int nb, int nc, double sigma, double *d_out,
                        void *work, int64_t work_bytes) {
-    PDC_REQUIRE(kind >= 0 && kind <= 4, "phase scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional entropy), 3 "
-                                        "(StringLength) or 4 (Gregory-Loredo)");
+    PDC_REQUIRE(kind >= 0 && kind <= 5, "phase scan: kind must be 0 (PDM), 1 (AoV), 2 (conditional entropy), 3 "
+                                        "(StringLength), 4 (Gregory-Loredo) or 5 (Supersmoother; sigma = alpha)");
+    if (kind == 5)
+        return pdc_supersmoother_scan_dev(device, stream, d_t, d_v, n, d_periods, n_periods, sigma, d_out, work, work_bytes);
     if (kind == 3)
         return pdc_stringlength_scan_dev(device, stream, d_t, d_v, n, d_periods, n_periods, d_out, work, work_bytes);
     const int64_t need = phase_stat_work_bytes(kind, n, n_periods, nb, nc);

@@ -233,7 +233,7 @@ class SuperSmoother(object):
     p_min, p_max, n_periods, oversample, cores:
         The trial-period grid, exactly as for :class:`PDM` (``phase.py:167-180``).
     device / devices: keyword-only
-        GPU ordinal (of a ``devices`` list the first entry is used: this scan runs on one GPU).
+        GPU ordinal / several GPUs of this node, one contiguous slab of the period grid each.
     """
 
     def __init__(self, alpha=0.0, p_min=None, p_max=None, n_periods=1000, oversample=1, cores=None,

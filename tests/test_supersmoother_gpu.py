@@ -70,3 +70,15 @@ def test_supersmoother_class_finds_the_period_and_edges():
     assert _cabi.supersmoother_scan(t, y, []).size == 0
     five = _cabi.supersmoother_scan(t[:5], y[:5], [0.3, 1.7])
     np.testing.assert_allclose(five, so.supersmoother_scan(t[:5], y[:5], [0.3, 1.7]), rtol=RTOL)
+
+
+@pytest.mark.gpu
+def test_supersmoother_over_device_slots_equals_one_launch():
+    """`devices=(...)` cuts the period grid into one slab per listed slot (the phase plan, kind 5): same values."""
+    t, y = curve(5000, 21)
+    periods = np.linspace(3.0, 30.0, 50)
+    one = _cabi.supersmoother_scan(t, y, periods, 3.0)
+    many = _cabi.supersmoother_scan(t, y, periods, 3.0, devices=(0, 0, 0))
+    assert np.array_equal(one, many)
+    res = SuperSmoother(alpha=3.0, p_min=3.0, p_max=30.0, n_periods=50, devices=(0, 0))(TSeries(t, y))
+    assert np.array_equal(res.values[::-1], one)
