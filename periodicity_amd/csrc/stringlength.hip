@@ -1702,6 +1702,7 @@ struct StreamArgs {
                                 //                   the groups' own histograms - no slack, no overflow)
     unsigned *bcnt;             // [batch][s1]       records of every bin
     unsigned *bstart;           // [batch][s1]       sorted position of every bin's first record
+    unsigned *nbins;            // [batch]           bins the period's table uses (0: left to the general kernel)
     rec_t *sorted;              // NULL, or [batch][n]: every period's (phase, m) in sorted order (Supersmoother)
     unsigned *flag;             // [batch]           != 0: left to the general kernel
     rec_t *pm;                  // [batch][s1][kCap] (phase, m)
@@ -1810,6 +1811,7 @@ __global__ __launch_bounds__(256) void sl_lut_kernel(StreamArgs a) {
     __syncthreads();
     for (int c = tid; c < kNC; c += 256) a.lut[(int64_t)q * kNC + c] = lut[c + 1];
     for (int b = tid; b <= a.s1; b += 256) a.clo[(int64_t)q * (a.s1 + 1) + b] = clo[b];
+    if (tid == 0) a.nbins[q] = general ? 0u : (unsigned)lut[kNC] + 1u;
     // how many records every group contributes to every bin - from the groups' own histograms, so the partition
     // kernel's runs are packed exactly
     const int W = a.groups;
@@ -1991,10 +1993,8 @@ __global__ __launch_bounds__(kBA) void sl_part_kernel(StreamArgs a) {
     if (tid == 0 && s_over) atomicOr(&a.flag[q], 2u);
 }
 
-// Persistent: a workgroup per CU walks the (period, bin) items.  (A second register set for the NEXT item's
-// records, requested under the current item's LDS work, was built and measured: no gain - the kernel waits on
-// its own LDS round trips, not on HBM; so was reading the first four members of every record's fine bucket
-// side by side instead of the data-dependent loop: no gain either.)
+// Persistent: a workgroup per CU walks the (period, bin) items.  (Reading the first four members of every record's
+// fine bucket side by side instead of the data-dependent loop was built and measured: no gain.)
 __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long *key_t = reinterpret_cast<unsigned long long *>(lds_raw);   // [kCap] by fine bucket, then sorted
@@ -2005,36 +2005,95 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     __shared__ double red[kBB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s1 = a.s1;
-    const int64_t n_items = (int64_t)a.batch * s1;
-    // records of an item; 0 for empty bins and for periods the general kernel takes
-    auto count_of = [&](int64_t it) -> int {
-        if (it >= n_items) return 0;
-        const unsigned c = a.bcnt[it];
-        return a.flag[it / s1] != 0u ? 0 : (int)c;
+    // The items of the batch = the bins every period's table actually uses (about half of the s1 reserved per
+    // period), numbered consecutively through a prefix over the periods kept in LDS: the walk touches no empty
+    // bin and reads nothing from global memory to find its next item.  (The first version walked all batch x s1
+    // slots and read two dependent words per slot to find out whether it was empty: 2.4 us per slot, a third of
+    // the kernel's time.)
+    __shared__ unsigned pre[kS1Max + 1];   // (a batch holds at most 768 periods)
+    {
+        unsigned v = 0u;
+        if (tid < a.batch) v = a.flag[tid] != 0u ? 0u : a.nbins[tid];
+        const unsigned inc = wave_scan_add(v);
+        if (lane == 63) wave_tot[wave] = inc;
+        __syncthreads();
+        unsigned at = inc - v;
+        for (int x = 0; x < wave; ++x) at += wave_tot[x];
+        if (tid < a.batch) pre[tid] = at;
+        if (tid == a.batch - 1) pre[a.batch] = at + v;
+        __syncthreads();
+    }
+    const int64_t n_items = (int64_t)pre[a.batch];
+    int walk_q = 0;                                       // (the walk only moves forward)
+    auto item_of = [&](int64_t k) -> int64_t {           // slot (period, bin) of the k-th live item
+        if (k >= n_items) return -1;
+        while (walk_q + 1 < a.batch && (int64_t)pre[walk_q + 1] <= k) ++walk_q;
+        return (int64_t)walk_q * s1 + (k - (int64_t)pre[walk_q]);
     };
-    int64_t it0 = blockIdx.x, it1 = it0 + gridDim.x;
-    int n0 = count_of(it0);
-    for (; it0 < n_items; it0 = it1, it1 += gridDim.x) {
-        const int64_t item = it0;
+    auto count_of = [&](int64_t slot) -> int { return slot >= 0 ? (int)a.bcnt[slot] : 0; };
+    // The NEXT item's records are requested (a second register set) before the current one is worked off.  Two
+    // things make that prefetch real: vector loads return in order, so whatever else the current item reads from
+    // global memory (its bin's coarse range, the count two items ahead) is requested BEFORE it - a younger load's
+    // wait would drain the prefetch -, and a scheduling barrier pins the requests where they are written (their
+    // results are first used one trip later; the compiler otherwise sinks them down to that use).  It needs a kernel
+    // without register spills: a scratch reload is a vector load too.  (Measured: the lists come from the Infinity
+    // Cache the partition kernel just wrote them through, so the prefetch itself buys little - 6 us of 445.)
+    rec_t rn[kPerB];
+    unsigned idn[kPerB];
+    auto request = [&](int64_t slot, int n) {
+        if (n > 0 && n <= kCap) {   // (workgroup-uniform)
+#pragma unroll
+            for (int e = 0; e < kPerB; ++e) {
+                const int j = tid + e * kBB < n ? tid + e * kBB : n - 1;
+                rn[e] = a.pm[slot * kCap + j];
+                idn[e] = a.ix[slot * kCap + j];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // (first / one-past-last coarse bucket of an item's bin, packed in one register)
+    auto coarse_range = [&](int64_t slot) -> unsigned {
+        if (slot < 0) return 0x10000u;
+        const int64_t at = (slot / s1) * (s1 + 1) + slot % s1;
+        return (unsigned)a.clo[at] | ((unsigned)a.clo[at + 1] << 16);
+    };
+    int64_t k2 = (int64_t)blockIdx.x;
+    int64_t sl0 = item_of(k2);
+    k2 += gridDim.x;
+    int64_t sl1 = item_of(k2);
+    k2 += gridDim.x;
+    int n0 = count_of(sl0), n1 = count_of(sl1);
+    unsigned c0 = coarse_range(sl0), c1 = coarse_range(sl1);
+    request(sl0, n0);
+    for (; sl0 >= 0; k2 += gridDim.x) {
+        const int64_t item = sl0;
         const int n_s = n0;
-        n0 = count_of(it1);                               // (in flight under this item's work)
+        const double c_lo = (double)(c0 & 0xFFFFu), c_hi = (double)(c0 >> 16);
+        rec_t rec[kPerB];
+        unsigned id[kPerB];
+#pragma unroll
+        for (int e = 0; e < kPerB; ++e) {
+            rec[e] = rn[e];
+            id[e] = idn[e];
+        }
+        const int64_t sl2 = item_of(k2);
+        const int n2 = count_of(sl2);
+        const unsigned c2 = coarse_range(sl2);
+        __builtin_amdgcn_sched_barrier(0);
+        request(sl1, n1);
+        sl0 = sl1;
+        sl1 = sl2;
+        n0 = n1;
+        n1 = n2;
+        c0 = c1;
+        c1 = c2;
         if (n_s <= 0) continue;                           // (workgroup-uniform)
         if (n_s > kCap) {                                 // (cannot happen: the bin table keeps bins below kCap)
             if (tid == 0) atomicOr(&a.flag[item / s1], 4u);
             continue;
         }
-        rec_t rec[kPerB];
-        unsigned id[kPerB];
-#pragma unroll
-        for (int e = 0; e < kPerB; ++e) {
-            const int j = tid + e * kBB < n_s ? tid + e * kBB : n_s - 1;
-            rec[e] = a.pm[item * kCap + j];
-            id[e] = a.ix[item * kCap + j];
-        }
-        const int q = (int)(item / s1), s = (int)(item % s1);
+        const int q = (int)(item / s1);
         for (int x = tid; x < kFineB / 2; x += kBB) fcnt[x] = 0u;
-        const double c_lo = (double)a.clo[(int64_t)q * (s1 + 1) + s];
-        const double c_hi = (double)a.clo[(int64_t)q * (s1 + 1) + s + 1];
         const double fscale = (double)kFineB / (c_hi - c_lo > 0.0 ? c_hi - c_lo : 1.0);
         __syncthreads();
         // fine bucket: a monotone refinement of the coarse bucket (phi * 4096 is exact, the scale positive);
@@ -2117,6 +2176,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         }
         __syncthreads();
         // segments in sorted order: position p against p - 1 (the lane below; lane 0 reads it)
+        const int64_t sorted_at = a.sorted ? (int64_t)q * a.n + a.bstart[item] : 0;
         double acc = 0.0;
 #pragma unroll
         for (int e = 0; e < kPerB; ++e) {
@@ -2136,7 +2196,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
                 rec_t r;
                 r.x = phi;
                 r.y = mm;
-                a.sorted[(int64_t)q * a.n + a.bstart[item] + p] = r;
+                a.sorted[sorted_at + p] = r;
             }
             if (live && p == 0) {
                 a.ssum[item * 4 + 0] = phi;
@@ -2258,7 +2318,7 @@ bool stream_takes(int64_t n) { return n >= stream_min_n() && n >= 4096 && n <= k
 
 struct StreamShape {
     int s1, batch, groups, tiles_w;
-    int64_t o_bad, o_flag, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_ix, o_pm, o_todo, o_tcount, total;
+    int64_t o_bad, o_flag, o_nbins, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_ix, o_pm, o_todo, o_tcount, total;
 };
 StreamShape stream_shape(int64_t n, int64_t n_periods) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
@@ -2277,12 +2337,13 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     static const int64_t env_batch = [] { const char *e = getenv("PDC_SL_STREAM_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
     int64_t batch = env_batch > 0 ? env_batch : (768 + groups - 1) / groups;
     batch = batch > n_periods ? n_periods : batch;
-    batch = batch < 1 ? 1 : batch;
+    batch = batch < 1 ? 1 : (batch > 768 ? 768 : batch);   // (the sort kernel keeps a prefix over the batch's periods in LDS)
     h.batch = (int)batch;
     const int64_t items = batch * h.s1;
     h.o_bad = 0;
     h.o_flag = 256;
-    h.o_hist = h.o_flag + up(batch * 4);
+    h.o_nbins = h.o_flag + up(batch * 4);
+    h.o_hist = h.o_nbins + up(batch * 4);
     h.o_lut = h.o_hist + up(batch * groups * stream::kNC * 4);
     h.o_clo = h.o_lut + up(batch * stream::kNC * 2);
     h.o_sub = h.o_clo + up(batch * (h.s1 + 1) * 2);
@@ -2338,6 +2399,7 @@ stream::StreamArgs stream_args(const StreamShape &h, char *area, const double *d
     sa.boff = reinterpret_cast<unsigned *>(area + h.o_sub);
     sa.bcnt = reinterpret_cast<unsigned *>(area + h.o_bcnt);
     sa.bstart = reinterpret_cast<unsigned *>(area + h.o_bstart);
+    sa.nbins = reinterpret_cast<unsigned *>(area + h.o_nbins);
     sa.sorted = nullptr;
     sa.ssum = reinterpret_cast<double *>(area + h.o_ssum);
     sa.slen = reinterpret_cast<double *>(area + h.o_slen);
