@@ -1234,8 +1234,9 @@ def main():
         why = fr.get("executed_issue_note")
         algo_bytes = 24.0 * n + 8.0 * slab_nf
         if blk:
-            achieved = blk["valu_wave_instr_per_launch"] * 64 * 2 / kernel_s / 1e12
-            frac = round(achieved / PEAK_FP64_VECTOR_TFLOPS, 4)
+            # the issue fraction priced by instruction type (valu_issue_block); `achieved` = that fraction of the peak
+            frac = blk["frac"]
+            achieved = frac * PEAK_FP64_VECTOR_TFLOPS
             traffic = blk.get("hbm_bytes")
         else:
             achieved = frac = traffic = None
@@ -1275,9 +1276,10 @@ def main():
                                          "bytes_per_launch": algo_bytes},
                          "note": "fp64 vector-ALU bound (software sincos + rotation recurrences; no fp64 "
                                  "transcendental unit, not a contraction).  achieved/frac = EXECUTED "
-                                 "issue: SQ_INSTS_VALU wave-instructions per launch x 64 lanes x 2 flop "
-                                 "/ HIP-event time, i.e. wave-instr x 4 cycles / 1024 SIMDs / 2.4 GHz / "
-                                 "time; `algorithmic` prices SURVEY 8d's 50 flop/pair of a direct "
+                                 "issue: VALU issue cycles per launch (fp64/int64 instructions x 4 cycles, all "
+                                 "others x 2, from the typed rocprofv3 counters) / 1024 SIMDs / 2.4 GHz / "
+                                 "HIP-event time, `achieved` = that fraction of the 78.6 TFLOP/s peak; "
+                                 "`algorithmic` prices SURVEY 8d's 50 flop/pair of a direct "
                                  "evaluation and may exceed the roofline; traffic = HBM-side bytes per "
                                  "launch (FETCH_SIZE x 2 + WRITE_SIZE, separate PMC passes) vs "
                                  "24 N + 8 nf algorithmic"
