@@ -507,8 +507,8 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
     out["c5_supersmoother"] = {"ms": round(ms, 3), "Gpair_per_s": round(float(n) * n_ss / ms / 1e6, 2), "n_periods": n_ss,
                                "executed_issue_frac": None, "algorithmic_frac": None,
                                "note": "Friedman's variable span smoother on the phase-sorted curve, mean absolute residual "
-                                       "(Reimann 1994); parity unpinned by the reference; ~15 passes over 15 N-element arrays "
-                                       "per period in global scratch: latency-bound, no roofline claimed"}
+                                       "(Reimann 1994); parity unpinned by the reference; ~70 MB of prefix-scan and window "
+                                       "passes per period through HBM (DESIGN 4.7)"}
     bss.free()
     for b in (bt5, bx, bp, bth, bm, bsp, be, swork, bmag):
         b.free()

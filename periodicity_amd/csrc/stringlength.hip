@@ -2459,9 +2459,9 @@ SsShape ss_shape(int64_t n, int64_t n_periods) {
         int64_t b = n_periods < 512 ? n_periods : 512;
         z.batch = (int)(b < 1 ? 1 : b);
     }
-    z.stride = (n + 8 + 7) & ~(int64_t)7;
-    // two smoother workgroups per CU (their passes over the period's arrays are latency chains), within 6 GB of scratch
-    int64_t g = ((int64_t)6 << 30) / (ss::kArrays * z.stride * 8);
+    z.stride = (n + n / 2 + 24 + 7) & ~(int64_t)7;   // (prefix arrays run over the curve extended by a quarter on either side)
+    // two smoother workgroups per CU, within 12 GB of scratch
+    int64_t g = ((int64_t)12 << 30) / (ss::kArrays * z.stride * 8);
     g = g < 1 ? 1 : (g > 512 ? 512 : g);
     z.grid_ss = (int)(g < z.batch ? g : z.batch);
     z.grid_fb = z.batch < 256 ? z.batch : 256;
