@@ -1684,7 +1684,8 @@ constexpr int kFineB = PDC_SL_FINE; // fine buckets per bin, 16-bit counters pac
 static_assert(kCap % kBB == 0 && kCap < 65536, "slice positions are 16-bit");
 static_assert(kTA == 4 * kBA && kTA < 65536, "four samples per thread");
 constexpr size_t lds_part(int s1p) { return (size_t)kTA * (8 + 8 + 2) + (size_t)kNC * 2 + (size_t)s1p * 4 * 4; }
-constexpr size_t kLdsB = (size_t)kCap * (8 + 8 + 4) + (size_t)kFineB * 2;
+constexpr int kBatchMax = 768;     // periods per batch at most (the sort kernel keeps a prefix over them in LDS)
+constexpr size_t kLdsB = (size_t)kCap * (8 + 8 + 4) + (size_t)kFineB * 2 * 2;
 
 struct StreamArgs {
     const double *t, *m, *periods;
@@ -2000,9 +2001,9 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     unsigned long long *key_t = reinterpret_cast<unsigned long long *>(lds_raw);   // [kCap] by fine bucket, then sorted
     double *m_s = reinterpret_cast<double *>(key_t + kCap);                          // [kCap] m in sorted order
     unsigned *i_t = reinterpret_cast<unsigned *>(m_s + kCap);                        // [kCap] sample index by fine bucket
-    unsigned *fcnt = i_t + kCap;                                                     // [kFineB / 2] packed 16-bit
+    unsigned *fcnt2 = i_t + kCap;                                                    // [2][kFineB / 2] packed 16-bit, by bin parity
     __shared__ unsigned wave_tot[kBB / 64];
-    __shared__ double red[kBB / 64];
+    __shared__ double red[2][kBB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s1 = a.s1;
     // The items of the batch = the bins every period's table actually uses (about half of the s1 reserved per
@@ -2010,7 +2011,8 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     // bin and reads nothing from global memory to find its next item.  (The first version walked all batch x s1
     // slots and read two dependent words per slot to find out whether it was empty: 2.4 us per slot, a third of
     // the kernel's time.)
-    __shared__ unsigned pre[kS1Max + 1];   // (a batch holds at most 768 periods)
+    __shared__ unsigned pre[kBatchMax + 1];
+    for (int x = tid; x < kFineB; x += kBB) fcnt2[x] = 0u;
     {
         unsigned v = 0u;
         if (tid < a.batch) v = a.flag[tid] != 0u ? 0u : a.nbins[tid];
@@ -2044,9 +2046,12 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         if (n > 0 && n <= kCap) {   // (workgroup-uniform)
 #pragma unroll
             for (int e = 0; e < kPerB; ++e) {
-                const int j = tid + e * kBB < n ? tid + e * kBB : n - 1;
-                rn[e] = a.pm[slot * kCap + j];
-                idn[e] = a.ix[slot * kCap + j];
+                // (whole rows past the bin's count are skipped; the last row reads on inside the list's kCap places -
+                // whatever lies there is never used)
+                if (e * kBB < n) {
+                    rn[e] = a.pm[slot * kCap + e * kBB + tid];
+                    idn[e] = a.ix[slot * kCap + e * kBB + tid];
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -2065,6 +2070,17 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     int n0 = count_of(sl0), n1 = count_of(sl1);
     unsigned c0 = coarse_range(sl0), c1 = coarse_range(sl1);
     request(sl0, n0);
+    int par = 0;                  // which half of fcnt2 this bin counts in (the other half is zeroed meanwhile)
+    int64_t pend = -1;            // the bin whose waves' sums wait in red[pend_par] (written out one barrier later)
+    int pend_par = 0;
+    auto flush = [&]() {
+        if (tid == 0 && pend >= 0) {
+            double sum = 0.0;
+            for (int x = 0; x < kBB / 64; ++x) sum += red[pend_par][x];
+            a.slen[pend] = sum;
+        }
+        pend = -1;
+    };
     for (; sl0 >= 0; k2 += gridDim.x) {
         const int64_t item = sl0;
         const int n_s = n0;
@@ -2093,9 +2109,8 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             continue;
         }
         const int q = (int)(item / s1);
-        for (int x = tid; x < kFineB / 2; x += kBB) fcnt[x] = 0u;
+        unsigned *fcnt = fcnt2 + par * (kFineB / 2), *fo = fcnt2 + (par ^ 1) * (kFineB / 2);
         const double fscale = (double)kFineB / (c_hi - c_lo > 0.0 ? c_hi - c_lo : 1.0);
-        __syncthreads();
         // fine bucket: a monotone refinement of the coarse bucket (phi * 4096 is exact, the scale positive);
         // arrival rank from the packed counters
         unsigned long long key[kPerB];
@@ -2114,6 +2129,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             }
         }
         __syncthreads();
+        flush();            // every wave is past the bin before: its sums are complete
         {   // exclusive scan of the fine counters (8 per thread), written back as packed starts
             constexpr int kW = kFineB / 2 / kBB;   // words per thread
             unsigned c[2 * kW], sum = 0u;
@@ -2152,6 +2168,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
                 i_t[st[e] + arr[e]] = id[e];
             }
         }
+        for (int x = tid; x < kFineB / 2; x += kBB) fo[x] = 0u;   // (last read by the bin before; counted in by the next)
         __syncthreads();
         // final position = start of the fine bucket + members that sort before (phase pattern, then sample index)
         unsigned fin[kPerB];
@@ -2208,14 +2225,13 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             }
         }
         acc = wave_sum_fixed(acc);
-        if (lane == 0) red[wave] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            double sum = 0.0;
-            for (int x = 0; x < kBB / 64; ++x) sum += red[x];
-            a.slen[item] = sum;
-        }
+        if (lane == 0) red[par][wave] = acc;
+        pend = item;
+        pend_par = par;
+        par ^= 1;
     }
+    __syncthreads();
+    flush();
 }
 
 // one wave per period of the batch: 64 bins' summaries are fetched side by side, then folded in bin order
@@ -2326,9 +2342,11 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     h.s1 = (int)(n / stream::kMinFill + 2);
     h.s1 = h.s1 > stream::kS1Max ? stream::kS1Max : h.s1;
     const int64_t tiles = (n + stream::kTA - 1) / stream::kTA;
-    // workgroups per period in the histogram / partition kernels: a power of two up to 16, each with >= ~8 tiles
+    // workgroups per period in the histogram / partition kernels: a power of two up to 8, each with >= ~16 tiles
+    // (measured at N = 1e6 / 4e5 / 2.5e5: 16 groups 37.3 / 17.1 / 18.5 ms, 8 groups 35.3 / 13.9 / 18.7, 4 groups
+    // 35.2 / 12.9-14.1 / 17.4; larger batches than 768 / groups change nothing)
     int groups = 1;
-    while (groups < stream::kGroupsMax && tiles / (2 * groups) >= 8) groups *= 2;
+    while (groups < 8 && tiles / (2 * groups) >= 16) groups *= 2;
     static const int env_groups = [] { const char *e = getenv("PDC_SL_STREAM_GROUPS"); return e ? atoi(e) : 0; }();
     if (env_groups == 1 || env_groups == 2 || env_groups == 4 || env_groups == 8 || env_groups == 16) groups = env_groups;
     h.groups = groups;
@@ -2337,7 +2355,7 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     static const int64_t env_batch = [] { const char *e = getenv("PDC_SL_STREAM_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
     int64_t batch = env_batch > 0 ? env_batch : (768 + groups - 1) / groups;
     batch = batch > n_periods ? n_periods : batch;
-    batch = batch < 1 ? 1 : (batch > 768 ? 768 : batch);   // (the sort kernel keeps a prefix over the batch's periods in LDS)
+    batch = batch < 1 ? 1 : (batch > stream::kBatchMax ? stream::kBatchMax : batch);   // (the sort kernel keeps a prefix over the batch's periods in LDS)
     h.batch = (int)batch;
     const int64_t items = batch * h.s1;
     h.o_bad = 0;
