@@ -39,6 +39,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "pdc_internal.h"
 
@@ -1994,8 +1995,23 @@ __global__ __launch_bounds__(kBA) void sl_part_kernel(StreamArgs a) {
     if (tid == 0 && s_over) atomicOr(&a.flag[q], 2u);
 }
 
-// Persistent: a workgroup per CU walks the (period, bin) items.  (Reading the first four members of every record's
-// fine bucket side by side instead of the data-dependent loop was built and measured: no gain.)
+// Persistent: a workgroup per CU walks the (period, bin) items.  Built and measured against this kernel (N = 1e6 x
+// 2048 periods, 802 us per batch of 96 periods before the metadata table below, 745 us with it):
+//  - reading the first four members of every record's fine bucket side by side instead of the data-dependent loop:
+//    no gain;
+//  - nothing rewritten after the scatter - every record finds its rank AND its sorted predecessor (largest smaller
+//    member of its bucket, else the largest member of the nearest non-empty bucket below) and adds its own segment,
+//    four barriers instead of eight: 1010 us (six records per thread each walk three or four dependent LDS
+//    round trips one after the other), and the sum depends on the arrival order of the partition's atomics;
+//  - alternating counter halves + the bin's sum written one barrier later (two barriers fewer): no change - kept;
+//  - the workgroup only groups the bin by 2048 mid buckets and every WAVE ranks and sums ranges of <= 255 records by
+//    itself (the several-slice kernels' sl_ranges.inc on records already in LDS, no barrier in the data-dependent
+//    part): 1055 us, 921 us with a parallel link step and a range table built by the counters' owners - the byte
+//    counters' scan per range and rows filled to two thirds cost ~900 instructions per 170 records, and without a
+//    second register set for the next bin's records every wave waits 6.6 k cycles for them.
+// The cycle stamps taken for the last variant showed what is fixed here: the next bins' counts and coarse ranges
+// were SCALAR loads, and a scalar load comes back with the first LDS wait behind it (one counter for both): 6 - 8 k
+// cycles of every bin's ~27 k.
 __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long *key_t = reinterpret_cast<unsigned long long *>(lds_raw);   // [kCap] by fine bucket, then sorted
@@ -2026,13 +2042,35 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         __syncthreads();
     }
     const int64_t n_items = (int64_t)pre[a.batch];
-    int walk_q = 0;                                       // (the walk only moves forward)
-    auto item_of = [&](int64_t k) -> int64_t {           // slot (period, bin) of the k-th live item
-        if (k >= n_items) return -1;
-        while (walk_q + 1 < a.batch && (int64_t)pre[walk_q + 1] <= k) ++walk_q;
-        return (int64_t)walk_q * s1 + (k - (int64_t)pre[walk_q]);
+    // This workgroup's k-th item is live item blockIdx + k * gridDim.  Slot, record count and coarse range of 64 items
+    // at a time are looked up by 64 threads (a binary search over the prefix, three global loads) and kept in LDS:
+    // the walk itself then reads nothing from global memory.  (Fetched per item they were scalar loads, and a scalar
+    // load comes back with the first LDS wait behind it - they share one counter -: 8 k cycles per bin, measured.)
+    __shared__ int meta_slot[64];
+    __shared__ unsigned meta_n[64], meta_c[64];
+    auto refill = [&](int trip0) {       // items of trips [trip0, trip0 + 64)
+        __syncthreads();
+        if (tid < 64) {
+            const int64_t kk = (int64_t)blockIdx.x + (int64_t)(trip0 + tid) * (int64_t)gridDim.x;
+            int slot = -1;
+            unsigned n = 0u, c = 0x10000u;
+            if (kk < n_items) {
+                int lo = 0, hi = a.batch;     // largest q with pre[q] <= kk
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int64_t)pre[mid] <= kk) lo = mid; else hi = mid;
+                }
+                slot = lo * s1 + (int)(kk - (int64_t)pre[lo]);
+                const int64_t at = (int64_t)lo * (s1 + 1) + (kk - (int64_t)pre[lo]);
+                n = a.bcnt[slot];
+                c = (unsigned)a.clo[at] | ((unsigned)a.clo[at + 1] << 16);
+            }
+            meta_slot[tid] = slot;
+            meta_n[tid] = n;
+            meta_c[tid] = c;
+        }
+        __syncthreads();
     };
-    auto count_of = [&](int64_t slot) -> int { return slot >= 0 ? (int)a.bcnt[slot] : 0; };
     // The NEXT item's records are requested (a second register set) before the current one is worked off.  Two
     // things make that prefetch real: vector loads return in order, so whatever else the current item reads from
     // global memory (its bin's coarse range, the count two items ahead) is requested BEFORE it - a younger load's
@@ -2043,7 +2081,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     rec_t rn[kPerB];
     unsigned idn[kPerB];
     auto request = [&](int64_t slot, int n) {
-        if (n > 0 && n <= kCap) {   // (workgroup-uniform)
+        if (slot >= 0 && n > 0 && n <= kCap) {   // (workgroup-uniform)
 #pragma unroll
             for (int e = 0; e < kPerB; ++e) {
                 // (whole rows past the bin's count are skipped; the last row reads on inside the list's kCap places -
@@ -2056,19 +2094,11 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    // (first / one-past-last coarse bucket of an item's bin, packed in one register)
-    auto coarse_range = [&](int64_t slot) -> unsigned {
-        if (slot < 0) return 0x10000u;
-        const int64_t at = (slot / s1) * (s1 + 1) + slot % s1;
-        return (unsigned)a.clo[at] | ((unsigned)a.clo[at + 1] << 16);
-    };
-    int64_t k2 = (int64_t)blockIdx.x;
-    int64_t sl0 = item_of(k2);
-    k2 += gridDim.x;
-    int64_t sl1 = item_of(k2);
-    k2 += gridDim.x;
-    int n0 = count_of(sl0), n1 = count_of(sl1);
-    unsigned c0 = coarse_range(sl0), c1 = coarse_range(sl1);
+    refill(0);
+    int trip = 0;
+    int64_t sl0 = __builtin_amdgcn_readfirstlane(meta_slot[0]);
+    int n0 = __builtin_amdgcn_readfirstlane((int)meta_n[0]);
+    unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)meta_c[0]);
     request(sl0, n0);
     int par = 0;                  // which half of fcnt2 this bin counts in (the other half is zeroed meanwhile)
     int64_t pend = -1;            // the bin whose waves' sums wait in red[pend_par] (written out one barrier later)
@@ -2081,7 +2111,12 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         }
         pend = -1;
     };
-    for (; sl0 >= 0; k2 += gridDim.x) {
+    for (; sl0 >= 0; ++trip) {
+        // (the thread id goes through an opaque copy once per trip: the LDS addresses built from it are loop-invariant,
+        // and hoisted out of the loop they are spilled - a scratch reload is a vector load, and waiting for it
+        // drains the prefetch)
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
         const int64_t item = sl0;
         const int n_s = n0;
         const double c_lo = (double)(c0 & 0xFFFFu), c_hi = (double)(c0 >> 16);
@@ -2092,20 +2127,15 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             rec[e] = rn[e];
             id[e] = idn[e];
         }
-        const int64_t sl2 = item_of(k2);
-        const int n2 = count_of(sl2);
-        const unsigned c2 = coarse_range(sl2);
+        if (((trip + 1) & 63) == 0) refill(trip + 1);     // (workgroup-uniform)
+        sl0 = __builtin_amdgcn_readfirstlane(meta_slot[(trip + 1) & 63]);
+        n0 = __builtin_amdgcn_readfirstlane((int)meta_n[(trip + 1) & 63]);
+        c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)meta_c[(trip + 1) & 63]);
         __builtin_amdgcn_sched_barrier(0);
-        request(sl1, n1);
-        sl0 = sl1;
-        sl1 = sl2;
-        n0 = n1;
-        n1 = n2;
-        c0 = c1;
-        c1 = c2;
+        request(sl0, n0);
         if (n_s <= 0) continue;                           // (workgroup-uniform)
         if (n_s > kCap) {                                 // (cannot happen: the bin table keeps bins below kCap)
-            if (tid == 0) atomicOr(&a.flag[item / s1], 4u);
+            if (tl == 0) atomicOr(&a.flag[item / s1], 4u);
             continue;
         }
         const int q = (int)(item / s1);
@@ -2123,7 +2153,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             const unsigned f = (unsigned)rel;                                    // (saturating; negative -> 0)
             fb[e] = phi == phi ? (f < (unsigned)(kFineB - 1) ? f : (unsigned)(kFineB - 1)) : (unsigned)(kFineB - 1);
             arr[e] = 0u;
-            if (tid + e * kBB < n_s) {
+            if (tl + e * kBB < n_s) {
                 const unsigned sh = (fb[e] & 1u) * 16u;
                 arr[e] = (atomicAdd(&fcnt[fb[e] >> 1], 1u << sh) >> sh) & 0xFFFFu;
             }
@@ -2135,7 +2165,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             unsigned c[2 * kW], sum = 0u;
 #pragma unroll
             for (int x = 0; x < kW; ++x) {
-                const unsigned v = fcnt[tid * kW + x];
+                const unsigned v = fcnt[tl * kW + x];
                 c[2 * x] = v & 0xFFFFu;
                 c[2 * x + 1] = v >> 16;
                 sum += c[2 * x] + c[2 * x + 1];
@@ -2151,42 +2181,43 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
                 run += c[2 * x];
                 const unsigned hi = run;
                 run += c[2 * x + 1];
-                fcnt[tid * kW + x] = lo | (hi << 16);
+                fcnt[tl * kW + x] = lo | (hi << 16);
             }
         }
         __syncthreads();
         auto start_of = [&](unsigned f) -> unsigned {
             return f < (unsigned)kFineB ? (fcnt[f >> 1] >> ((f & 1u) * 16u)) & 0xFFFFu : (unsigned)n_s;
         };
-        unsigned st[kPerB], en[kPerB];
+        unsigned se[kPerB];   // the fine bucket's first slot | one past its last << 16
 #pragma unroll
         for (int e = 0; e < kPerB; ++e) {
-            st[e] = start_of(fb[e]);
-            en[e] = start_of(fb[e] + 1u);
-            if (tid + e * kBB < n_s) {
-                key_t[st[e] + arr[e]] = key[e];
-                i_t[st[e] + arr[e]] = id[e];
+            const unsigned st = start_of(fb[e]);
+            se[e] = st | (start_of(fb[e] + 1u) << 16);
+            if (tl + e * kBB < n_s) {
+                key_t[st + arr[e]] = key[e];
+                i_t[st + arr[e]] = id[e];
             }
         }
-        for (int x = tid; x < kFineB / 2; x += kBB) fo[x] = 0u;   // (last read by the bin before; counted in by the next)
+        for (int x = tl; x < kFineB / 2; x += kBB) fo[x] = 0u;   // (last read by the bin before; counted in by the next)
         __syncthreads();
         // final position = start of the fine bucket + members that sort before (phase pattern, then sample index)
         unsigned fin[kPerB];
 #pragma unroll
         for (int e = 0; e < kPerB; ++e) {
             unsigned before = 0u;
-            if (tid + e * kBB < n_s) {
-                for (unsigned o = st[e]; o < en[e]; ++o) {
+            const unsigned st = se[e] & 0xFFFFu, en = se[e] >> 16;
+            if (tl + e * kBB < n_s) {
+                for (unsigned o = st; o < en; ++o) {
                     const unsigned long long ko = key_t[o];
                     before += (ko < key[e] || (ko == key[e] && i_t[o] < id[e])) ? 1u : 0u;
                 }
             }
-            fin[e] = st[e] + before;
+            fin[e] = st + before;
         }
         __syncthreads();   // every thread is done reading the bucket-ordered keys: they become the sorted ones
 #pragma unroll
         for (int e = 0; e < kPerB; ++e) {
-            if (tid + e * kBB < n_s) {
+            if (tl + e * kBB < n_s) {
                 key_t[fin[e]] = key[e];
                 m_s[fin[e]] = rec[e].y;
             }
@@ -2197,7 +2228,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         double acc = 0.0;
 #pragma unroll
         for (int e = 0; e < kPerB; ++e) {
-            const int p = tid + e * kBB;
+            const int p = tl + e * kBB;
             const bool live = p < n_s;
             const int pc = live ? p : 0;
             const double phi = __longlong_as_double((long long)key_t[pc]), mm = m_s[pc];
@@ -2242,7 +2273,7 @@ __global__ __launch_bounds__(256) void sl_link_kernel(StreamArgs a) {
     const int64_t p = a.p0 + q;
     if (a.flag[q] != 0u) {
         if (lane == 0) {
-            a.todo[p] = 1;
+            a.todo[p] = (unsigned char)(a.flag[q] | 0x80u);   // (non-zero; the low bits say which kernel gave up - debug print)
             atomicAdd(a.todo_count, 1u);
         }
         return;
@@ -2571,6 +2602,17 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
             PDC_HIP(hipMemcpy(&left, sa.todo_count, 4, hipMemcpyDeviceToHost));
             fprintf(stderr, "sl stream: n=%lld periods=%lld s1=%d groups=%d tiles_w=%d batch=%d -> %u periods left to the general kernel\n",
                     (long long)n, (long long)n_periods, h.s1, h.groups, h.tiles_w, h.batch, left);
+            if (left) {
+                std::vector<unsigned char> td((size_t)n_periods);
+                std::vector<double> pp((size_t)n_periods);
+                PDC_HIP(hipMemcpy(td.data(), sa.todo, (size_t)n_periods, hipMemcpyDeviceToHost));
+                PDC_HIP(hipMemcpy(pp.data(), d_periods, (size_t)n_periods * 8, hipMemcpyDeviceToHost));
+                for (int64_t p = 0, shown = 0; p < n_periods && shown < 16; ++p)
+                    if (td[p]) {
+                        fprintf(stderr, "   period %lld = %.17g: flag bits 0x%x\n", (long long)p, pp[p], td[p] & 0x7f);
+                        ++shown;
+                    }
+            }
         }
         // the periods a coarse bucket was too heavy in (clustered phases): the general kernel, which sorts what LDS
         // cannot hold
