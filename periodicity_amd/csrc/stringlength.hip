@@ -1685,8 +1685,10 @@ constexpr int kFineB = PDC_SL_FINE; // fine buckets per bin, 16-bit counters pac
 static_assert(kCap % kBB == 0 && kCap < 65536, "slice positions are 16-bit");
 static_assert(kTA == 4 * kBA && kTA < 65536, "four samples per thread");
 constexpr size_t lds_part(int s1p) { return (size_t)kTA * (8 + 8 + 2) + (size_t)kNC * 2 + (size_t)s1p * 4 * 4; }
+constexpr int kCycS = 512;         // slices mode: entries per row of a period's boundary table = cycles the period may span + 1
+constexpr int kMinSlice = 16;      // slices mode: samples per (cycle, bin) cell on average, at least
 constexpr int kBatchMax = 768;     // periods per batch at most (the sort kernel keeps a prefix over them in LDS)
-constexpr size_t kLdsB = (size_t)kCap * (8 + 8 + 4) + (size_t)kFineB * 2 * 2;
+constexpr size_t kLdsB = (size_t)kCap * (8 + 8 + 4) + (size_t)kFineB * 2;
 
 struct StreamArgs {
     const double *t, *m, *periods;
@@ -1694,9 +1696,10 @@ struct StreamArgs {
     int64_t p0;                 // first period of this batch
     int batch;                  // periods in this batch
     int s1;                     // bins reserved per period (the table may use fewer)
+    int slices;                 // != 0: periods whose cells are long enough take the slices mode (PDC_SL_SLICES=0: none)
     int groups;                 // W: workgroups per period in the histogram / partition kernels
     int tiles_w;                // tiles of kTA samples per group
-    const unsigned *bad_t;      // [0] != 0: some |t| outside {0} u [1e-150, 1e150]
+    const unsigned *bad_t;      // [0] != 0: some |t| outside {0} u [1e-150, 1e150]; [1] != 0: t is not non-decreasing
     unsigned *hist;             // [batch][W][kNC]   the groups' histograms
     unsigned short *lut;        // [batch][kNC]      coarse bucket -> bin
     unsigned short *clo;        // [batch][s1 + 1]   first coarse bucket of every bin
@@ -1705,6 +1708,10 @@ struct StreamArgs {
     unsigned *bcnt;             // [batch][s1]       records of every bin
     unsigned *bstart;           // [batch][s1]       sorted position of every bin's first record
     unsigned *nbins;            // [batch]           bins the period's table uses (0: left to the general kernel)
+    int *ncyc;                  // [batch]           slices mode: cycles the samples span at this period (0: lists mode)
+    double *cyc0;               // [batch]           slices mode: floor(t[0] / period)
+    unsigned *bnd;              // [batch][s1][kCycS] slices mode: first sample of cell (cycle c, bin b) at [b][c]; cell
+                                //                   (c, b) ends where (c, b + 1) - or (c + 1, 0) - starts; [0][K] = n
     rec_t *sorted;              // NULL, or [batch][n]: every period's (phase, m) in sorted order (Supersmoother)
     unsigned *flag;             // [batch]           != 0: left to the general kernel
     rec_t *pm;                  // [batch][s1][kCap] (phase, m)
@@ -1717,12 +1724,14 @@ struct StreamArgs {
 };
 
 __global__ __launch_bounds__(256) void sl_tame_kernel(const double *t, int64_t n, unsigned *bad) {
-    bool mine = false;
+    bool mine = false, unsorted = false;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const double at = __builtin_fabs(t[i]);
         mine = mine || !(at == 0.0 || (at >= 1e-150 && at <= 1e150));
+        unsorted = unsorted || (i > 0 && !(t[i - 1] <= t[i]));   // (NaN counts as unsorted)
     }
     if (__any(mine) && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
+    if (__any(unsorted) && (threadIdx.x & 63) == 0) atomicOr(bad + 1, 1u);
 }
 
 // sample index of local position l of tile kappa of group w: every group owns a contiguous run of tiles_w tiles
@@ -1813,7 +1822,24 @@ __global__ __launch_bounds__(256) void sl_lut_kernel(StreamArgs a) {
     __syncthreads();
     for (int c = tid; c < kNC; c += 256) a.lut[(int64_t)q * kNC + c] = lut[c + 1];
     for (int b = tid; b <= a.s1; b += 256) a.clo[(int64_t)q * (a.s1 + 1) + b] = clo[b];
-    if (tid == 0) a.nbins[q] = general ? 0u : (unsigned)lut[kNC] + 1u;
+    if (tid == 0) {
+        const unsigned nb = general ? 0u : (unsigned)lut[kNC] + 1u;
+        a.nbins[q] = nb;
+        // Slices mode: with t non-decreasing the samples of one cycle of the period are consecutive AND in phase
+        // order, so the samples of (cycle c, bin b) are one slice of t[] / m[] and the partition kernel's lists are
+        // not needed - a table of the cells' first samples is (sl_bound_kernel).  Taken when the cells hold >=
+        // kMinSlice samples on average and the table row holds the cycles.
+        const double period = a.periods[a.p0 + q];
+        const bool safe = period_is_safe(period, a.bad_t[0] == 0u);
+        const double y = 1.0 / period;
+        const double c0 = __builtin_floor(exact_quotient(a.t[0], period, y, safe));
+        const double c1 = __builtin_floor(exact_quotient(a.t[a.n - 1], period, y, safe));
+        const double cycles = c1 - c0 + 1.0;
+        const bool slices = a.slices != 0 && a.bad_t[1] == 0u && nb > 0u && cycles >= 1.0 && cycles < (double)kCycS &&
+                            cycles * (double)nb * (double)kMinSlice <= (double)a.n;
+        a.ncyc[q] = slices ? (int)cycles : 0;
+        a.cyc0[q] = c0;
+    }
     // how many records every group contributes to every bin - from the groups' own histograms, so the partition
     // kernel's runs are packed exactly
     const int W = a.groups;
@@ -1886,7 +1912,7 @@ __global__ __launch_bounds__(kBA) void sl_part_kernel(StreamArgs a) {
     __shared__ int s_over;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = (int)(blockIdx.x % (unsigned)a.batch), w = (int)(blockIdx.x / (unsigned)a.batch);
-    if (a.flag[q] != 0u) return;                          // (workgroup-uniform) the general kernel takes this period
+    if (a.flag[q] != 0u || a.ncyc[q] != 0) return;        // (workgroup-uniform) the general kernel, or sl_bound_kernel, takes this period
     const int s1 = a.s1;
     const double period = a.periods[a.p0 + q];
     const double y = 1.0 / period;
@@ -1995,6 +2021,68 @@ __global__ __launch_bounds__(kBA) void sl_part_kernel(StreamArgs a) {
     if (tid == 0 && s_over) atomicOr(&a.flag[q], 2u);
 }
 
+// Slices mode, in place of the partition kernel: the table of the cells' first samples.  With t non-decreasing
+// key(i) = (cycle of sample i) * bins + (bin of its phase) never falls along i, so every cell (cycle, bin) is one run
+// of consecutive samples and the table is written where the key steps up (a step over several keys = empty cells,
+// all starting at the same sample).  Same groups of tiles as the histogram kernel; nothing but t is read (8 bytes a
+// sample, from the caches) and one word per cell written - the partition kernel moves 36 bytes a sample.
+__global__ __launch_bounds__(kBA) void sl_bound_kernel(StreamArgs a) {
+    __shared__ unsigned short lut[kNC];
+    __shared__ int last[kBA];
+    const int tid = threadIdx.x;
+    const int q = (int)(blockIdx.x % (unsigned)a.batch), w = (int)(blockIdx.x / (unsigned)a.batch);
+    const int K = a.ncyc[q];
+    if (a.flag[q] != 0u || K == 0) return;                // (workgroup-uniform)
+    const int nb = (int)a.nbins[q];
+    const double cyc0 = a.cyc0[q];
+    const double period = a.periods[a.p0 + q];
+    const double y = 1.0 / period;
+    const bool safe = period_is_safe(period, a.bad_t[0] == 0u);
+    for (int c = tid; c < kNC; c += kBA) lut[c] = a.lut[(int64_t)q * kNC + c];
+    unsigned *tb = a.bnd + (int64_t)q * a.s1 * kCycS;
+    const int key_end = K * nb;                            // (cycle K, bin 0): where the last cell ends
+    auto key_of = [&](double tv) -> int {
+        const double qq = exact_quotient(tv, period, y, safe);
+        const double fl = __builtin_floor(qq);
+        const int c = (int)(fl - cyc0);
+        return c * nb + (int)lut[coarse_of<kNC>(qq - fl)];
+    };
+    auto put = [&](int from, int to, int64_t i) {          // cells (from, to] start at sample i
+        for (int kk = from + 1; kk <= to; ++kk) {
+            const int c = kk / nb, b = kk - c * nb;
+            tb[b * kCycS + c] = (unsigned)i;
+        }
+    };
+    const int64_t g0 = (int64_t)w * a.tiles_w * kTA;
+    if (g0 >= a.n) return;
+    int carry = g0 == 0 ? -1 : 0;                          // key of the sample before this thread's first
+    if (g0 > 0) carry = key_of(a.t[g0 - 1]);
+    __syncthreads();
+    for (int64_t kappa = 0; kappa < a.tiles_w; ++kappa) {
+        const int64_t i0 = g0 + kappa * kTA + (int64_t)tid * 4;   // four consecutive samples per thread
+        if (g0 + kappa * kTA >= a.n) break;                // (workgroup-uniform)
+        int key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = i0 + u < a.n ? key_of(a.t[i0 + u]) : key_end;
+        last[tid] = key[3];
+        __syncthreads();
+        int prev = tid > 0 ? last[tid - 1] : carry;
+        carry = last[kBA - 1];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // (a sample past the end carries the key behind the last cell: the step up to it closes the table at n)
+            if (key[u] > prev && i0 + u <= a.n) put(prev, key[u], i0 + u < a.n ? i0 + u : a.n);
+            prev = key[u] > prev ? key[u] : prev;
+        }
+    }
+    // (n a multiple of the tile: no sample past the end stands in - the last sample's thread closes the table)
+    if ((a.n % kTA) == 0 && g0 + (int64_t)a.tiles_w * kTA >= a.n && g0 < a.n) {
+        const int64_t il = a.n - 1 - g0;                   // the last sample, counted inside this group
+        if ((il % kTA) / 4 == tid) put(key_of(a.t[a.n - 1]), key_end, a.n);
+    }
+}
+
 // Persistent: a workgroup per CU walks the (period, bin) items.  Built and measured against this kernel (N = 1e6 x
 // 2048 periods, 802 us per batch of 96 periods before the metadata table below, 745 us with it):
 //  - reading the first four members of every record's fine bucket side by side instead of the data-dependent loop:
@@ -2017,7 +2105,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     unsigned long long *key_t = reinterpret_cast<unsigned long long *>(lds_raw);   // [kCap] by fine bucket, then sorted
     double *m_s = reinterpret_cast<double *>(key_t + kCap);                          // [kCap] m in sorted order
     unsigned *i_t = reinterpret_cast<unsigned *>(m_s + kCap);                        // [kCap] sample index by fine bucket
-    unsigned *fcnt2 = i_t + kCap;                                                    // [2][kFineB / 2] packed 16-bit, by bin parity
+    unsigned *fcnt = i_t + kCap;                                                     // [kFineB / 2] packed 16-bit
     __shared__ unsigned wave_tot[kBB / 64];
     __shared__ double red[2][kBB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2028,7 +2116,6 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     // slots and read two dependent words per slot to find out whether it was empty: 2.4 us per slot, a third of
     // the kernel's time.)
     __shared__ unsigned pre[kBatchMax + 1];
-    for (int x = tid; x < kFineB; x += kBB) fcnt2[x] = 0u;
     {
         unsigned v = 0u;
         if (tid < a.batch) v = a.flag[tid] != 0u ? 0u : a.nbins[tid];
@@ -2046,14 +2133,17 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     // at a time are looked up by 64 threads (a binary search over the prefix, three global loads) and kept in LDS:
     // the walk itself then reads nothing from global memory.  (Fetched per item they were scalar loads, and a scalar
     // load comes back with the first LDS wait behind it - they share one counter -: 8 k cycles per bin, measured.)
-    __shared__ int meta_slot[64];
-    __shared__ unsigned meta_n[64], meta_c[64];
+    constexpr int kRing = 128;         // two halves of 64: the walk looks two items ahead
+    __shared__ int meta_slot[kRing], meta_k[kRing];
+    __shared__ unsigned meta_n[kRing], meta_c[kRing];
+    __shared__ double meta_per[kRing];
     auto refill = [&](int trip0) {       // items of trips [trip0, trip0 + 64)
         __syncthreads();
         if (tid < 64) {
             const int64_t kk = (int64_t)blockIdx.x + (int64_t)(trip0 + tid) * (int64_t)gridDim.x;
-            int slot = -1;
+            int slot = -1, cyc = 0;
             unsigned n = 0u, c = 0x10000u;
+            double per = 1.0;
             if (kk < n_items) {
                 int lo = 0, hi = a.batch;     // largest q with pre[q] <= kk
                 while (hi - lo > 1) {
@@ -2064,10 +2154,15 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
                 const int64_t at = (int64_t)lo * (s1 + 1) + (kk - (int64_t)pre[lo]);
                 n = a.bcnt[slot];
                 c = (unsigned)a.clo[at] | ((unsigned)a.clo[at + 1] << 16);
+                cyc = a.ncyc[lo];
+                per = a.periods[a.p0 + lo];
             }
-            meta_slot[tid] = slot;
-            meta_n[tid] = n;
-            meta_c[tid] = c;
+            const int at = (trip0 + tid) & (kRing - 1);
+            meta_slot[at] = slot;
+            meta_n[at] = n;
+            meta_c[at] = c;
+            meta_k[at] = cyc;
+            meta_per[at] = per;
         }
         __syncthreads();
     };
@@ -2094,13 +2189,73 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    // Slices mode (the period's ncyc > 0): the bin's records are K slices of t[] / m[], one per cycle - [vs, ve) of the
+    // table rows fetched a trip ahead by the first K threads.  An exclusive prefix over the slices' lengths goes to
+    // LDS, every thread finds the slice of each of its records by a binary search over it (K is the same for all:
+    // a uniform loop) and requests t and m there; the phase is computed when the records are taken up.
+    __shared__ unsigned short sl_pre[kCycS];
+    __shared__ unsigned sl_start[kCycS];
+    __shared__ unsigned sl_wtot[kCycS / 64];
+    unsigned vs = 0u, ve = 0u;
+    auto rows_request = [&](int64_t slot, int K) {        // the table rows of an item two trips ahead
+        if (slot >= 0 && K > 0 && tid < K) {
+            const int64_t q = slot / s1, b = slot - q * s1;
+            const unsigned *row = a.bnd + (q * s1 + b) * kCycS;
+            const bool last = b + 1 >= (int64_t)a.nbins[q];
+            vs = row[tid];
+            ve = last ? a.bnd[q * s1 * kCycS + tid + 1] : row[kCycS + tid];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto request_slices = [&](int n, int K) {             // (workgroup-uniform; two barriers)
+        const unsigned len = tid < K ? ve - vs : 0u;
+        const unsigned incl = wave_scan_add(len);
+        if (lane == 63 && wave < kCycS / 64) sl_wtot[wave] = incl;
+        __syncthreads();
+        if (tid < K) {
+            unsigned ex = incl - len;
+            for (int x = 0; x < wave; ++x) ex += sl_wtot[x];
+            sl_pre[tid] = (unsigned short)ex;
+            sl_start[tid] = vs;
+        }
+        __syncthreads();
+        int top = 1;
+        while (top * 2 <= K - 1) top *= 2;                // largest power of two <= K - 1 (no step for K = 1)
+#pragma unroll
+        for (int e = 0; e < kPerB; ++e) {
+            if (e * kBB < n) {
+                const unsigned r = (unsigned)(tid + e * kBB) < (unsigned)n ? (unsigned)(tid + e * kBB) : (unsigned)(n - 1);
+                int sidx = 0;                             // largest s with sl_pre[s] <= r
+                for (int step = K > 1 ? top : 0; step > 0; step >>= 1)
+                    if (sidx + step < K && (unsigned)sl_pre[sidx + step] <= r) sidx += step;
+                unsigned at = sl_start[sidx] + (r - (unsigned)sl_pre[sidx]);
+                at = at < (unsigned)a.n ? at : (unsigned)(a.n - 1);   // (always inside: the table and the count come from the same phases)
+                rec_t v;
+                v.x = a.t[at];
+                v.y = a.m[at];
+                rn[e] = v;
+                idn[e] = at;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const bool t_safe = a.bad_t[0] == 0u;
     refill(0);
+    refill(64);
     int trip = 0;
     int64_t sl0 = __builtin_amdgcn_readfirstlane(meta_slot[0]);
     int n0 = __builtin_amdgcn_readfirstlane((int)meta_n[0]);
     unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)meta_c[0]);
-    request(sl0, n0);
-    int par = 0;                  // which half of fcnt2 this bin counts in (the other half is zeroed meanwhile)
+    int k0 = __builtin_amdgcn_readfirstlane(meta_k[0]);
+    double per0 = meta_per[0];
+    if (k0 > 0) {
+        rows_request(sl0, k0);
+        request_slices(sl0 >= 0 ? n0 : 0, k0);
+    } else {
+        request(sl0, n0);
+    }
+    rows_request(__builtin_amdgcn_readfirstlane(meta_slot[1]), __builtin_amdgcn_readfirstlane(meta_k[1]));
+    int par = 0;                  // which half of red[] this bin's waves sum into
     int64_t pend = -1;            // the bin whose waves' sums wait in red[pend_par] (written out one barrier later)
     int pend_par = 0;
     auto flush = [&]() {
@@ -2127,19 +2282,31 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             rec[e] = rn[e];
             id[e] = idn[e];
         }
-        if (((trip + 1) & 63) == 0) refill(trip + 1);     // (workgroup-uniform)
-        sl0 = __builtin_amdgcn_readfirstlane(meta_slot[(trip + 1) & 63]);
-        n0 = __builtin_amdgcn_readfirstlane((int)meta_n[(trip + 1) & 63]);
-        c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)meta_c[(trip + 1) & 63]);
+        if (k0 > 0) {   // (workgroup-uniform) slices mode: what came is t, not the phase
+            const double y = 1.0 / per0;
+            const bool safe = period_is_safe(per0, t_safe);
+#pragma unroll
+            for (int e = 0; e < kPerB; ++e) rec[e].x = fast_phase(rec[e].x, per0, y, safe);
+        }
+        if (((trip + 2) & 63) == 0) refill(trip + 2);     // (workgroup-uniform)
+        const int r1 = (trip + 1) & (kRing - 1), r2 = (trip + 2) & (kRing - 1);
+        sl0 = __builtin_amdgcn_readfirstlane(meta_slot[r1]);
+        n0 = __builtin_amdgcn_readfirstlane((int)meta_n[r1]);
+        c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)meta_c[r1]);
+        k0 = __builtin_amdgcn_readfirstlane(meta_k[r1]);
+        per0 = meta_per[r1];
         __builtin_amdgcn_sched_barrier(0);
-        request(sl0, n0);
+        if (k0 > 0) request_slices(sl0 >= 0 ? n0 : 0, k0);
+        else request(sl0, n0);
+        rows_request(__builtin_amdgcn_readfirstlane(meta_slot[r2]), __builtin_amdgcn_readfirstlane(meta_k[r2]));
         if (n_s <= 0) continue;                           // (workgroup-uniform)
         if (n_s > kCap) {                                 // (cannot happen: the bin table keeps bins below kCap)
             if (tl == 0) atomicOr(&a.flag[item / s1], 4u);
             continue;
         }
         const int q = (int)(item / s1);
-        unsigned *fcnt = fcnt2 + par * (kFineB / 2), *fo = fcnt2 + (par ^ 1) * (kFineB / 2);
+        for (int x = tl; x < kFineB / 2; x += kBB) fcnt[x] = 0u;
+        __syncthreads();
         const double fscale = (double)kFineB / (c_hi - c_lo > 0.0 ? c_hi - c_lo : 1.0);
         // fine bucket: a monotone refinement of the coarse bucket (phi * 4096 is exact, the scale positive);
         // arrival rank from the packed counters
@@ -2198,7 +2365,6 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
                 i_t[st + arr[e]] = id[e];
             }
         }
-        for (int x = tl; x < kFineB / 2; x += kBB) fo[x] = 0u;   // (last read by the bin before; counted in by the next)
         __syncthreads();
         // final position = start of the fine bucket + members that sort before (phase pattern, then sample index)
         unsigned fin[kPerB];
@@ -2365,7 +2531,7 @@ bool stream_takes(int64_t n) { return n >= stream_min_n() && n >= 4096 && n <= k
 
 struct StreamShape {
     int s1, batch, groups, tiles_w;
-    int64_t o_bad, o_flag, o_nbins, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_ix, o_pm, o_todo, o_tcount, total;
+    int64_t o_bad, o_flag, o_nbins, o_ncyc, o_cyc0, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_bnd, o_ix, o_pm, o_todo, o_tcount, total;
 };
 StreamShape stream_shape(int64_t n, int64_t n_periods) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
@@ -2392,7 +2558,9 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     h.o_bad = 0;
     h.o_flag = 256;
     h.o_nbins = h.o_flag + up(batch * 4);
-    h.o_hist = h.o_nbins + up(batch * 4);
+    h.o_ncyc = h.o_nbins + up(batch * 4);
+    h.o_cyc0 = h.o_ncyc + up(batch * 4);
+    h.o_hist = h.o_cyc0 + up(batch * 8);
     h.o_lut = h.o_hist + up(batch * groups * stream::kNC * 4);
     h.o_clo = h.o_lut + up(batch * stream::kNC * 2);
     h.o_sub = h.o_clo + up(batch * (h.s1 + 1) * 2);
@@ -2400,7 +2568,8 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     h.o_bstart = h.o_bcnt + up(items * 4);
     h.o_ssum = h.o_bstart + up(items * 4);
     h.o_slen = h.o_ssum + up(items * 32);
-    h.o_ix = h.o_slen + up(items * 8);
+    h.o_bnd = h.o_slen + up(items * 8);
+    h.o_ix = h.o_bnd + up(items * stream::kCycS * 4);
     h.o_pm = h.o_ix + up(items * stream::kCap * 4);
     h.o_todo = h.o_pm + up(items * stream::kCap * 16);
     h.o_tcount = h.o_todo + up(n_periods);
@@ -2449,6 +2618,11 @@ stream::StreamArgs stream_args(const StreamShape &h, char *area, const double *d
     sa.bcnt = reinterpret_cast<unsigned *>(area + h.o_bcnt);
     sa.bstart = reinterpret_cast<unsigned *>(area + h.o_bstart);
     sa.nbins = reinterpret_cast<unsigned *>(area + h.o_nbins);
+    sa.ncyc = reinterpret_cast<int *>(area + h.o_ncyc);
+    sa.cyc0 = reinterpret_cast<double *>(area + h.o_cyc0);
+    sa.bnd = reinterpret_cast<unsigned *>(area + h.o_bnd);
+    static const bool slices = [] { const char *e = getenv("PDC_SL_SLICES"); return !(e && e[0] == '0'); }();
+    sa.slices = slices ? 1 : 0;
     sa.sorted = nullptr;
     sa.ssum = reinterpret_cast<double *>(area + h.o_ssum);
     sa.slen = reinterpret_cast<double *>(area + h.o_slen);
@@ -2470,8 +2644,10 @@ int stream_sort_batch(int device, hipStream_t st, const StreamShape &h, stream::
     const dim3 wg((unsigned)(bc * h.groups));
     hipLaunchKernelGGL(stream::sl_hist_kernel, wg, dim3(stream::kBA), 0, st, sa);
     hipLaunchKernelGGL(stream::sl_lut_kernel, dim3((unsigned)bc), dim3(256), (size_t)h.s1 * h.groups * 4, st, sa);
+    // (every period takes one of the two: a workgroup of the other kernel returns at once)
     if (wide) hipLaunchKernelGGL(stream::sl_part_kernel<1024>, wg, dim3(stream::kBA), lds_a, st, sa);
     else hipLaunchKernelGGL(stream::sl_part_kernel<512>, wg, dim3(stream::kBA), lds_a, st, sa);
+    if (sa.slices) hipLaunchKernelGGL(stream::sl_bound_kernel, wg, dim3(stream::kBA), 0, st, sa);
     const int64_t sort_slots = (int64_t)cu_count(device) * (stream::kLdsB + 1024 <= 80 * 1024 ? 2 : 1);
     const int64_t sort_grid = bc * h.s1 < sort_slots ? bc * h.s1 : sort_slots;
     hipLaunchKernelGGL(stream::sl_sort_kernel, dim3((unsigned)sort_grid), dim3(stream::kBB), stream::kLdsB, st, sa);
