@@ -2175,15 +2175,15 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     // Cache the partition kernel just wrote them through, so the prefetch itself buys little - 6 us of 445.)
     rec_t rn[kPerB];
     unsigned idn[kPerB];
-    auto request = [&](int64_t slot, int n) {
+    auto request = [&](const int tt, int64_t slot, int n) {
         if (slot >= 0 && n > 0 && n <= kCap) {   // (workgroup-uniform)
 #pragma unroll
             for (int e = 0; e < kPerB; ++e) {
                 // (whole rows past the bin's count are skipped; the last row reads on inside the list's kCap places -
                 // whatever lies there is never used)
                 if (e * kBB < n) {
-                    rn[e] = a.pm[slot * kCap + e * kBB + tid];
-                    idn[e] = a.ix[slot * kCap + e * kBB + tid];
+                    rn[e] = a.pm[slot * kCap + e * kBB + tt];
+                    idn[e] = a.ix[slot * kCap + e * kBB + tt];
                 }
             }
         }
@@ -2197,47 +2197,63 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     __shared__ unsigned sl_start[kCycS];
     __shared__ unsigned sl_wtot[kCycS / 64];
     unsigned vs = 0u, ve = 0u;
-    auto rows_request = [&](int64_t slot, int K) {        // the table rows of an item two trips ahead
-        if (slot >= 0 && K > 0 && tid < K) {
+    auto rows_request = [&](const int tt, int64_t slot, int K) {        // the table rows of an item two trips ahead
+        if (slot >= 0 && K > 0 && tt < K) {
             const int64_t q = slot / s1, b = slot - q * s1;
             const unsigned *row = a.bnd + (q * s1 + b) * kCycS;
             const bool last = b + 1 >= (int64_t)a.nbins[q];
-            vs = row[tid];
-            ve = last ? a.bnd[q * s1 * kCycS + tid + 1] : row[kCycS + tid];
+            vs = row[tt];
+            ve = last ? a.bnd[q * s1 * kCycS + tt + 1] : row[kCycS + tt];
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto request_slices = [&](int n, int K) {             // (workgroup-uniform; two barriers)
-        const unsigned len = tid < K ? ve - vs : 0u;
+    auto request_slices = [&](const int tt, int n, int K) {             // (workgroup-uniform; two barriers)
+        const unsigned len = tt < K ? ve - vs : 0u;
         const unsigned incl = wave_scan_add(len);
         if (lane == 63 && wave < kCycS / 64) sl_wtot[wave] = incl;
         __syncthreads();
-        if (tid < K) {
+        if (tt < K) {
             unsigned ex = incl - len;
             for (int x = 0; x < wave; ++x) ex += sl_wtot[x];
-            sl_pre[tid] = (unsigned short)ex;
-            sl_start[tid] = vs;
+            sl_pre[tt] = (unsigned short)ex;
+            sl_start[tt] = vs;
         }
         __syncthreads();
         int top = 1;
         while (top * 2 <= K - 1) top *= 2;                // largest power of two <= K - 1 (no step for K = 1)
+        // (three searches side by side - a step of each between two LDS waits -, their loads out, then the other
+        // three: six at once spill)
 #pragma unroll
-        for (int e = 0; e < kPerB; ++e) {
-            if (e * kBB < n) {
-                const unsigned r = (unsigned)(tid + e * kBB) < (unsigned)n ? (unsigned)(tid + e * kBB) : (unsigned)(n - 1);
-                int sidx = 0;                             // largest s with sl_pre[s] <= r
-                for (int step = K > 1 ? top : 0; step > 0; step >>= 1)
-                    if (sidx + step < K && (unsigned)sl_pre[sidx + step] <= r) sidx += step;
-                unsigned at = sl_start[sidx] + (r - (unsigned)sl_pre[sidx]);
-                at = at < (unsigned)a.n ? at : (unsigned)(a.n - 1);   // (always inside: the table and the count come from the same phases)
-                rec_t v;
-                v.x = a.t[at];
-                v.y = a.m[at];
-                rn[e] = v;
-                idn[e] = at;
+        for (int g = 0; g < kPerB; g += 3) {
+            unsigned r[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const unsigned rr = (unsigned)(tt + (g + e) * kBB);
+                r[e] = rr < (unsigned)n ? rr : (unsigned)(n > 0 ? n - 1 : 0);
+                idn[g + e] = 0u;                           // largest s with sl_pre[s] <= r
             }
+            for (int step = K > 1 ? top : 0; step > 0; step >>= 1) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const unsigned probe = idn[g + e] + (unsigned)step;
+                    const unsigned pv = sl_pre[probe < (unsigned)K ? probe : 0u];
+                    if (probe < (unsigned)K && pv <= r[e]) idn[g + e] = probe;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                if ((g + e) * kBB < n) {
+                    unsigned at = sl_start[idn[g + e]] + (r[e] - (unsigned)sl_pre[idn[g + e]]);
+                    at = at < (unsigned)a.n ? at : (unsigned)(a.n - 1);   // (always inside: the table and the count come from the same phases)
+                    rec_t v;
+                    v.x = a.t[at];
+                    v.y = a.m[at];
+                    rn[g + e] = v;
+                    idn[g + e] = at;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     };
     const bool t_safe = a.bad_t[0] == 0u;
     refill(0);
@@ -2247,14 +2263,13 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     int n0 = __builtin_amdgcn_readfirstlane((int)meta_n[0]);
     unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)meta_c[0]);
     int k0 = __builtin_amdgcn_readfirstlane(meta_k[0]);
-    double per0 = meta_per[0];
     if (k0 > 0) {
-        rows_request(sl0, k0);
-        request_slices(sl0 >= 0 ? n0 : 0, k0);
+        rows_request(tid, sl0, k0);
+        request_slices(tid, sl0 >= 0 ? n0 : 0, k0);
     } else {
-        request(sl0, n0);
+        request(tid, sl0, n0);
     }
-    rows_request(__builtin_amdgcn_readfirstlane(meta_slot[1]), __builtin_amdgcn_readfirstlane(meta_k[1]));
+    rows_request(tid, __builtin_amdgcn_readfirstlane(meta_slot[1]), __builtin_amdgcn_readfirstlane(meta_k[1]));
     int par = 0;                  // which half of red[] this bin's waves sum into
     int64_t pend = -1;            // the bin whose waves' sums wait in red[pend_par] (written out one barrier later)
     int pend_par = 0;
@@ -2283,22 +2298,29 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             id[e] = idn[e];
         }
         if (k0 > 0) {   // (workgroup-uniform) slices mode: what came is t, not the phase
-            const double y = 1.0 / per0;
-            const bool safe = period_is_safe(per0, t_safe);
+            const double per = meta_per[trip & (kRing - 1)];
+            const double y = 1.0 / per;
+            const bool safe = period_is_safe(per, t_safe);
 #pragma unroll
-            for (int e = 0; e < kPerB; ++e) rec[e].x = fast_phase(rec[e].x, per0, y, safe);
+            for (int e = 0; e < kPerB; ++e) rec[e].x = fast_phase(rec[e].x, per, y, safe);
         }
-        if (((trip + 2) & 63) == 0) refill(trip + 2);     // (workgroup-uniform)
-        const int r1 = (trip + 1) & (kRing - 1), r2 = (trip + 2) & (kRing - 1);
-        sl0 = __builtin_amdgcn_readfirstlane(meta_slot[r1]);
-        n0 = __builtin_amdgcn_readfirstlane((int)meta_n[r1]);
-        c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)meta_c[r1]);
-        k0 = __builtin_amdgcn_readfirstlane(meta_k[r1]);
-        per0 = meta_per[r1];
-        __builtin_amdgcn_sched_barrier(0);
-        if (k0 > 0) request_slices(sl0 >= 0 ? n0 : 0, k0);
-        else request(sl0, n0);
-        rows_request(__builtin_amdgcn_readfirstlane(meta_slot[r2]), __builtin_amdgcn_readfirstlane(meta_k[r2]));
+        // The NEXT item's records are requested once this item's have been scattered to LDS (its phases, keys and
+        // indices are dead by then: two full register sets side by side - the request used to go out up here - do
+        // not fit 128 registers together with the slices mode's state, and a scratch reload is a vector load whose
+        // wait drains the prefetch).  Ranking, rewriting and the segments lie between the request and its use.
+        auto advance = [&]() {
+            if (((trip + 2) & 63) == 0) refill(trip + 2);     // (workgroup-uniform)
+            const int r1 = (trip + 1) & (kRing - 1), r2 = (trip + 2) & (kRing - 1);
+            sl0 = __builtin_amdgcn_readfirstlane(meta_slot[r1]);
+            n0 = __builtin_amdgcn_readfirstlane((int)meta_n[r1]);
+            c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)meta_c[r1]);
+            k0 = __builtin_amdgcn_readfirstlane(meta_k[r1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 > 0) request_slices(tl, sl0 >= 0 ? n0 : 0, k0);
+            else request(tl, sl0, n0);
+            rows_request(tl, __builtin_amdgcn_readfirstlane(meta_slot[r2]), __builtin_amdgcn_readfirstlane(meta_k[r2]));
+        };
+        advance();
         if (n_s <= 0) continue;                           // (workgroup-uniform)
         if (n_s > kCap) {                                 // (cannot happen: the bin table keeps bins below kCap)
             if (tl == 0) atomicOr(&a.flag[item / s1], 4u);

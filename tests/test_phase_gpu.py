@@ -229,6 +229,28 @@ def test_streamed_stringlength_kernels_match_the_oracle():
     assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok"), out.stdout[-1500:] + out.stderr[-1500:]
 
 
+def test_streamed_stringlength_slices_mode_equals_the_lists_bit_for_bit(tmp_path):
+    """With t non-decreasing the samples of (cycle of the period, phase bin) are one slice of t[] / m[]: the sort
+    kernel fetches a bin's records from those slices (a table of first samples, sl_bound_kernel) instead of from the
+    partition kernel's lists.  Both feed the same sort, so PDC_SL_SLICES=0 must give the same bits - over grids that
+    mix the two modes (short periods keep the lists), duplicate time stamps, gaps of many periods (cycles with no
+    sample), a negative start, even sampling; samples in random order make the slices mode step aside."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    specs = ["70000x48", "150001x12", "90000x40d", "4097x33d", "20000x40e", "60000x24u"]
+    got = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / f"slices{mode}.npz")
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "sl_stream_check.py"), *specs],
+                             env=dict(os.environ, PDC_SL_STREAM_MIN="4096", PDC_SL_SLICES=mode, SL_CHECK_SAVE=path),
+                             cwd=root, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok"), out.stdout[-1500:] + out.stderr[-1500:]
+        got[mode] = np.load(path)
+    for spec in specs:
+        assert np.array_equal(got["1"][spec], got["0"][spec]), spec
+
+
 def test_streamed_stringlength_at_its_own_sizes():
     """N = 4e5 (just above the several-slice kernel's range) and N = 1e6 take the streamed kernels by default."""
     rng = np.random.default_rng(12)
