@@ -2134,7 +2134,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     // the walk itself then reads nothing from global memory.  (Fetched per item they were scalar loads, and a scalar
     // load comes back with the first LDS wait behind it - they share one counter -: 8 k cycles per bin, measured.)
     constexpr int kRing = 128;         // two halves of 64: the walk looks two items ahead
-    __shared__ int meta_slot[kRing], meta_k[kRing];
+    __shared__ int meta_slot[kRing], meta_k[kRing];   // (meta_k: cycles, negative when the item is its period's last bin)
     __shared__ unsigned meta_n[kRing], meta_c[kRing];
     __shared__ double meta_per[kRing];
     auto refill = [&](int trip0) {       // items of trips [trip0, trip0 + 64)
@@ -2155,6 +2155,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
                 n = a.bcnt[slot];
                 c = (unsigned)a.clo[at] | ((unsigned)a.clo[at + 1] << 16);
                 cyc = a.ncyc[lo];
+                if (kk + 1 == (int64_t)pre[lo + 1]) cyc = -cyc;   // the period's last bin: its slices end where the next cycle's first bin starts
                 per = a.periods[a.p0 + lo];
             }
             const int at = (trip0 + tid) & (kRing - 1);
@@ -2175,15 +2176,18 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     // Cache the partition kernel just wrote them through, so the prefetch itself buys little - 6 us of 445.)
     rec_t rn[kPerB];
     unsigned idn[kPerB];
+    // (a wave takes kPerB CONSECUTIVE rows of 64 records: record rb + 64 e of the list, rb = the wave's first + lane -
+    // in slices mode the slice of row e + 1 is then a step or two behind that of row e, no second search)
     auto request = [&](const int tt, int64_t slot, int n) {
         if (slot >= 0 && n > 0 && n <= kCap) {   // (workgroup-uniform)
+            const int w0 = __builtin_amdgcn_readfirstlane((tt >> 6) * (kPerB * 64));
 #pragma unroll
             for (int e = 0; e < kPerB; ++e) {
                 // (whole rows past the bin's count are skipped; the last row reads on inside the list's kCap places -
                 // whatever lies there is never used)
-                if (e * kBB < n) {
-                    rn[e] = a.pm[slot * kCap + e * kBB + tt];
-                    idn[e] = a.ix[slot * kCap + e * kBB + tt];
+                if (w0 + e * 64 < n) {   // (wave-uniform)
+                    rn[e] = a.pm[slot * kCap + w0 + e * 64 + (tt & 63)];
+                    idn[e] = a.ix[slot * kCap + w0 + e * 64 + (tt & 63)];
                 }
             }
         }
@@ -2197,13 +2201,13 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     __shared__ unsigned sl_start[kCycS];
     __shared__ unsigned sl_wtot[kCycS / 64];
     unsigned vs = 0u, ve = 0u;
-    auto rows_request = [&](const int tt, int64_t slot, int K) {        // the table rows of an item two trips ahead
+    auto rows_request = [&](const int tt, int64_t slot, int Ks) {   // the table rows of an item two trips ahead
+        const int K = Ks < 0 ? -Ks : Ks;
         if (slot >= 0 && K > 0 && tt < K) {
-            const int64_t q = slot / s1, b = slot - q * s1;
-            const unsigned *row = a.bnd + (q * s1 + b) * kCycS;
-            const bool last = b + 1 >= (int64_t)a.nbins[q];
+            const int64_t q = slot / s1;
+            const unsigned *row = a.bnd + slot * kCycS;
             vs = row[tt];
-            ve = last ? a.bnd[q * s1 * kCycS + tt + 1] : row[kCycS + tt];
+            ve = Ks < 0 ? a.bnd[q * s1 * kCycS + tt + 1] : row[kCycS + tt];
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -2221,39 +2225,34 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         __syncthreads();
         int top = 1;
         while (top * 2 <= K - 1) top *= 2;                // largest power of two <= K - 1 (no step for K = 1)
-        // (three searches side by side - a step of each between two LDS waits -, their loads out, then the other
-        // three: six at once spill)
-#pragma unroll
-        for (int g = 0; g < kPerB; g += 3) {
-            unsigned r[3];
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const unsigned rr = (unsigned)(tt + (g + e) * kBB);
-                r[e] = rr < (unsigned)n ? rr : (unsigned)(n > 0 ? n - 1 : 0);
-                idn[g + e] = 0u;                           // largest s with sl_pre[s] <= r
-            }
+        const int w0 = __builtin_amdgcn_readfirstlane((tt >> 6) * (kPerB * 64));
+        const unsigned last = (unsigned)(n > 0 ? n - 1 : 0);
+        unsigned sidx = 0u;                                // largest s with sl_pre[s] <= r: searched for the first row ...
+        {
+            const unsigned r = (unsigned)(w0 + (tt & 63)) < last ? (unsigned)(w0 + (tt & 63)) : last;
             for (int step = K > 1 ? top : 0; step > 0; step >>= 1) {
-#pragma unroll
-                for (int e = 0; e < 3; ++e) {
-                    const unsigned probe = idn[g + e] + (unsigned)step;
-                    const unsigned pv = sl_pre[probe < (unsigned)K ? probe : 0u];
-                    if (probe < (unsigned)K && pv <= r[e]) idn[g + e] = probe;
-                }
+                const unsigned probe = sidx + (unsigned)step;
+                const unsigned pv = sl_pre[probe < (unsigned)K ? probe : 0u];
+                if (probe < (unsigned)K && pv <= r) sidx = probe;
             }
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                if ((g + e) * kBB < n) {
-                    unsigned at = sl_start[idn[g + e]] + (r[e] - (unsigned)sl_pre[idn[g + e]]);
-                    at = at < (unsigned)a.n ? at : (unsigned)(a.n - 1);   // (always inside: the table and the count come from the same phases)
-                    rec_t v;
-                    v.x = a.t[at];
-                    v.y = a.m[at];
-                    rn[g + e] = v;
-                    idn[g + e] = at;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int e = 0; e < kPerB; ++e) {
+            if (w0 + e * 64 < n) {   // (wave-uniform)
+                const unsigned rr = (unsigned)(w0 + e * 64 + (tt & 63));
+                const unsigned r = rr < last ? rr : last;
+                // ... and walked up from the row before (64 records further on: a slice or two)
+                while (sidx + 1u < (unsigned)K && (unsigned)sl_pre[sidx + 1u] <= r) ++sidx;
+                unsigned at = sl_start[sidx] + (r - (unsigned)sl_pre[sidx]);
+                at = at < (unsigned)a.n ? at : (unsigned)(a.n - 1);   // (always inside: the table and the count come from the same phases)
+                rec_t v;
+                v.x = a.t[at];
+                v.y = a.m[at];
+                rn[e] = v;
+                idn[e] = at;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
     const bool t_safe = a.bad_t[0] == 0u;
     refill(0);
@@ -2262,10 +2261,10 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     int64_t sl0 = __builtin_amdgcn_readfirstlane(meta_slot[0]);
     int n0 = __builtin_amdgcn_readfirstlane((int)meta_n[0]);
     unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)meta_c[0]);
-    int k0 = __builtin_amdgcn_readfirstlane(meta_k[0]);
-    if (k0 > 0) {
+    int k0 = __builtin_amdgcn_readfirstlane(meta_k[0]);   // (|k0| cycles; 0: lists mode)
+    if (k0 != 0) {
         rows_request(tid, sl0, k0);
-        request_slices(tid, sl0 >= 0 ? n0 : 0, k0);
+        request_slices(tid, sl0 >= 0 ? n0 : 0, k0 < 0 ? -k0 : k0);
     } else {
         request(tid, sl0, n0);
     }
@@ -2287,6 +2286,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         // drains the prefetch)
         int tl = tid;
         asm volatile("" : "+v"(tl));
+        const int rb = (tl >> 6) * (kPerB * 64) + (tl & 63);   // this thread's record of row e: rb + 64 e
         const int64_t item = sl0;
         const int n_s = n0;
         const double c_lo = (double)(c0 & 0xFFFFu), c_hi = (double)(c0 >> 16);
@@ -2297,7 +2297,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             rec[e] = rn[e];
             id[e] = idn[e];
         }
-        if (k0 > 0) {   // (workgroup-uniform) slices mode: what came is t, not the phase
+        if (k0 != 0) {   // (workgroup-uniform) slices mode: what came is t, not the phase
             const double per = meta_per[trip & (kRing - 1)];
             const double y = 1.0 / per;
             const bool safe = period_is_safe(per, t_safe);
@@ -2316,7 +2316,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)meta_c[r1]);
             k0 = __builtin_amdgcn_readfirstlane(meta_k[r1]);
             __builtin_amdgcn_sched_barrier(0);
-            if (k0 > 0) request_slices(tl, sl0 >= 0 ? n0 : 0, k0);
+            if (k0 != 0) request_slices(tl, sl0 >= 0 ? n0 : 0, k0 < 0 ? -k0 : k0);
             else request(tl, sl0, n0);
             rows_request(tl, __builtin_amdgcn_readfirstlane(meta_slot[r2]), __builtin_amdgcn_readfirstlane(meta_k[r2]));
         };
@@ -2342,7 +2342,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
             const unsigned f = (unsigned)rel;                                    // (saturating; negative -> 0)
             fb[e] = phi == phi ? (f < (unsigned)(kFineB - 1) ? f : (unsigned)(kFineB - 1)) : (unsigned)(kFineB - 1);
             arr[e] = 0u;
-            if (tl + e * kBB < n_s) {
+            if (rb + e * 64 < n_s) {
                 const unsigned sh = (fb[e] & 1u) * 16u;
                 arr[e] = (atomicAdd(&fcnt[fb[e] >> 1], 1u << sh) >> sh) & 0xFFFFu;
             }
@@ -2382,7 +2382,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         for (int e = 0; e < kPerB; ++e) {
             const unsigned st = start_of(fb[e]);
             se[e] = st | (start_of(fb[e] + 1u) << 16);
-            if (tl + e * kBB < n_s) {
+            if (rb + e * 64 < n_s) {
                 key_t[st + arr[e]] = key[e];
                 i_t[st + arr[e]] = id[e];
             }
@@ -2394,7 +2394,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         for (int e = 0; e < kPerB; ++e) {
             unsigned before = 0u;
             const unsigned st = se[e] & 0xFFFFu, en = se[e] >> 16;
-            if (tl + e * kBB < n_s) {
+            if (rb + e * 64 < n_s) {
                 for (unsigned o = st; o < en; ++o) {
                     const unsigned long long ko = key_t[o];
                     before += (ko < key[e] || (ko == key[e] && i_t[o] < id[e])) ? 1u : 0u;
@@ -2405,7 +2405,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
         __syncthreads();   // every thread is done reading the bucket-ordered keys: they become the sorted ones
 #pragma unroll
         for (int e = 0; e < kPerB; ++e) {
-            if (tl + e * kBB < n_s) {
+            if (rb + e * 64 < n_s) {
                 key_t[fin[e]] = key[e];
                 m_s[fin[e]] = rec[e].y;
             }
