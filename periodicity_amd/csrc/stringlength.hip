@@ -2055,9 +2055,9 @@ __global__ __launch_bounds__(kBA) void sl_bound_kernel(StreamArgs a) {
     };
     const int64_t g0 = (int64_t)w * a.tiles_w * kTA;
     if (g0 >= a.n) return;
+    __syncthreads();                                       // (the table read by key_of is complete)
     int carry = g0 == 0 ? -1 : 0;                          // key of the sample before this thread's first
     if (g0 > 0) carry = key_of(a.t[g0 - 1]);
-    __syncthreads();
     for (int64_t kappa = 0; kappa < a.tiles_w; ++kappa) {
         const int64_t i0 = g0 + kappa * kTA + (int64_t)tid * 4;   // four consecutive samples per thread
         if (g0 + kappa * kTA >= a.n) break;                // (workgroup-uniform)
@@ -2561,18 +2561,22 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     h.s1 = (int)(n / stream::kMinFill + 2);
     h.s1 = h.s1 > stream::kS1Max ? stream::kS1Max : h.s1;
     const int64_t tiles = (n + stream::kTA - 1) / stream::kTA;
-    // workgroups per period in the histogram / partition kernels: a power of two up to 8, each with >= ~16 tiles
-    // (measured at N = 1e6 / 4e5 / 2.5e5: 16 groups 37.3 / 17.1 / 18.5 ms, 8 groups 35.3 / 13.9 / 18.7, 4 groups
-    // 35.2 / 12.9-14.1 / 17.4; larger batches than 768 / groups change nothing)
+    // workgroups per period in the histogram / partition / boundary kernels: a power of two up to 4, each with >= ~16
+    // tiles, and batches of up to 384 periods as far as 12 GB of lists allow (measured, N = 1e6 / 4e5 / 2.5e5 x 2048 /
+    // 2048 / 4096 periods, slices mode: 8 groups x 96 periods 27.0 / 11.5 / 14.4 ms, 4 x 192 25.7 / 10.5 / 14.2, 2 x 384
+    // 25.4 / 10.2 / 13.7, 4 x 384 25.2 / 10.1 / 13.7, 4 x 96 29.1 / 12.1 / 16.2: the kernels before the sort want >= 768
+    // workgroups, the sort kernel few and long launches; lists mode, 16 / 8 / 4 groups: 37.3 / 35.3 / 35.2 ms at N = 1e6)
     int groups = 1;
-    while (groups < 8 && tiles / (2 * groups) >= 16) groups *= 2;
+    while (groups < 4 && tiles / (2 * groups) >= 16) groups *= 2;
     static const int env_groups = [] { const char *e = getenv("PDC_SL_STREAM_GROUPS"); return e ? atoi(e) : 0; }();
     if (env_groups == 1 || env_groups == 2 || env_groups == 4 || env_groups == 8 || env_groups == 16) groups = env_groups;
     h.groups = groups;
     h.tiles_w = (int)((tiles + groups - 1) / groups);
-    // three workgroups per CU in the histogram / partition kernels: batch x groups >= 768
     static const int64_t env_batch = [] { const char *e = getenv("PDC_SL_STREAM_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
-    int64_t batch = env_batch > 0 ? env_batch : (768 + groups - 1) / groups;
+    const int64_t list_bytes = (int64_t)h.s1 * stream::kCap * 20;                 // one period's lists
+    int64_t batch = ((int64_t)12 << 30) / list_bytes / 32 * 32;
+    batch = batch > 384 ? 384 : (batch < 32 ? 32 : batch);
+    if (env_batch > 0) batch = env_batch;
     batch = batch > n_periods ? n_periods : batch;
     batch = batch < 1 ? 1 : (batch > stream::kBatchMax ? stream::kBatchMax : batch);   // (the sort kernel keeps a prefix over the batch's periods in LDS)
     h.batch = (int)batch;

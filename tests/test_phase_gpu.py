@@ -251,6 +251,25 @@ def test_streamed_stringlength_slices_mode_equals_the_lists_bit_for_bit(tmp_path
         assert np.array_equal(got["1"][spec], got["0"][spec]), spec
 
 
+def test_streamed_stringlength_slices_mode_at_its_own_sizes(tmp_path):
+    """The same equality at the sizes the streamed path serves by default, where a workgroup of the sort kernel walks
+    more than 64 bins (its table of items is refilled) and the boundary kernel runs 1536 workgroups - a barrier missing
+    there showed up as a different period wrong in every other run at exactly these shapes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    specs = ["250000x4096", "1000000x384"]
+    runs = []
+    for mode in ("1", "0", "1"):
+        path = str(tmp_path / f"ab{len(runs)}.npz")
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "sl_slices_ab.py"), path, *specs],
+                             env=dict(os.environ, PDC_SL_SLICES=mode), cwd=root, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        runs.append(np.load(path))
+    for spec in specs:
+        assert np.array_equal(runs[0][spec], runs[1][spec]) and np.array_equal(runs[0][spec], runs[2][spec]), spec
+
+
 def test_streamed_stringlength_at_its_own_sizes():
     """N = 4e5 (just above the several-slice kernel's range) and N = 1e6 take the streamed kernels by default."""
     rng = np.random.default_rng(12)
