@@ -1687,6 +1687,7 @@ static_assert(kTA == 4 * kBA && kTA < 65536, "four samples per thread");
 constexpr size_t lds_part(int s1p) { return (size_t)kTA * (8 + 8 + 2) + (size_t)kNC * 2 + (size_t)s1p * 4 * 4; }
 constexpr int kCycS = 512;         // slices mode: entries per row of a period's boundary table = cycles the period may span + 1
 constexpr int kMinSlice = 16;      // slices mode: samples per (cycle, bin) cell on average, at least
+constexpr unsigned kFlagDirect = 16u; // flag[] value: one cycle, summed as the samples stand
 constexpr int kBatchMax = 768;     // periods per batch at most (the sort kernel keeps a prefix over them in LDS)
 constexpr size_t kLdsB = (size_t)kCap * (8 + 8 + 4) + (size_t)kFineB * 2;
 
@@ -1697,6 +1698,8 @@ struct StreamArgs {
     int batch;                  // periods in this batch
     int s1;                     // bins reserved per period (the table may use fewer)
     int slices;                 // != 0: periods whose cells are long enough take the slices mode (PDC_SL_SLICES=0: none)
+    int direct;                 // != 0: periods that outlast the samples are summed as the samples stand (not when the
+                                //       sorted curve itself is wanted: Supersmoother)
     int groups;                 // W: workgroups per period in the histogram / partition kernels
     int tiles_w;                // tiles of kTA samples per group
     const unsigned *bad_t;      // [0] != 0: some |t| outside {0} u [1e-150, 1e150]; [1] != 0: t is not non-decreasing
@@ -1839,6 +1842,14 @@ __global__ __launch_bounds__(256) void sl_lut_kernel(StreamArgs a) {
                             cycles * (double)nb * (double)kMinSlice <= (double)a.n;
         a.ncyc[q] = slices ? (int)cycles : 0;
         a.cyc0[q] = c0;
+        // One cycle (the period outlasts the samples) and t non-decreasing: the phases are in order as the samples
+        // stand - no sort, one pass (sl_direct_kernel).  These are also the periods whose phases pile up in a few
+        // coarse buckets (p >> baseline), which no bin table can take.
+        if (a.direct != 0 && a.bad_t[1] == 0u && cycles == 1.0) {
+            a.flag[q] = kFlagDirect;
+            a.nbins[q] = 0u;
+            a.ncyc[q] = 0;
+        }
     }
     // how many records every group contributes to every bin - from the groups' own histograms, so the partition
     // kernel's runs are packed exactly
@@ -2453,12 +2464,44 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
     flush();
 }
 
+// One cycle of the period covers all samples and t is non-decreasing: phase order = sample order (equal phases -
+// equal times - stay in index order, as the stable sort leaves them).  A workgroup per such period sums the segments
+// in one pass, every thread the samples i = its id mod 1024, the threads' sums in a fixed order.
+__global__ __launch_bounds__(kBB) void sl_direct_kernel(StreamArgs a) {
+    __shared__ double red[kBB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+    if (a.flag[q] != kFlagDirect) return;                 // (workgroup-uniform)
+    const double period = a.periods[a.p0 + q];
+    const double y = 1.0 / period;
+    const bool safe = period_is_safe(period, a.bad_t[0] == 0u);
+    double acc = 0.0;
+    for (int64_t i = tid + 1; i < a.n; i += kBB) {
+        const double p1 = fast_phase(a.t[i], period, y, safe), p0 = fast_phase(a.t[i - 1], period, y, safe);
+        acc += short_hypot(a.m[i] - a.m[i - 1], p1 - p0);
+    }
+    acc = wave_sum_fixed(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double total = 0.0;
+        for (int x = 0; x < kBB / 64; ++x) total += red[x];
+        // closing segment of np.roll(-1): first minus last, no phase wrap (phase.py:50)
+        total += hypot(a.m[0] - a.m[a.n - 1],
+                       fast_phase(a.t[0], period, y, safe) - fast_phase(a.t[a.n - 1], period, y, safe));
+        a.ell[a.p0 + q] = total;
+    }
+}
+
 // one wave per period of the batch: 64 bins' summaries are fetched side by side, then folded in bin order
 __global__ __launch_bounds__(256) void sl_link_kernel(StreamArgs a) {
     const int lane = threadIdx.x & 63;
     const int q = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (q >= a.batch) return;
     const int64_t p = a.p0 + q;
+    if (a.flag[q] == kFlagDirect) {                       // (sl_direct_kernel wrote its length)
+        if (lane == 0) a.todo[p] = 0;
+        return;
+    }
     if (a.flag[q] != 0u) {
         if (lane == 0) {
             a.todo[p] = (unsigned char)(a.flag[q] | 0x80u);   // (non-zero; the low bits say which kernel gave up - debug print)
@@ -2649,6 +2692,7 @@ stream::StreamArgs stream_args(const StreamShape &h, char *area, const double *d
     sa.bnd = reinterpret_cast<unsigned *>(area + h.o_bnd);
     static const bool slices = [] { const char *e = getenv("PDC_SL_SLICES"); return !(e && e[0] == '0'); }();
     sa.slices = slices ? 1 : 0;
+    sa.direct = sa.slices;
     sa.sorted = nullptr;
     sa.ssum = reinterpret_cast<double *>(area + h.o_ssum);
     sa.slen = reinterpret_cast<double *>(area + h.o_slen);
@@ -2670,7 +2714,8 @@ int stream_sort_batch(int device, hipStream_t st, const StreamShape &h, stream::
     const dim3 wg((unsigned)(bc * h.groups));
     hipLaunchKernelGGL(stream::sl_hist_kernel, wg, dim3(stream::kBA), 0, st, sa);
     hipLaunchKernelGGL(stream::sl_lut_kernel, dim3((unsigned)bc), dim3(256), (size_t)h.s1 * h.groups * 4, st, sa);
-    // (every period takes one of the two: a workgroup of the other kernel returns at once)
+    if (sa.direct) hipLaunchKernelGGL(stream::sl_direct_kernel, dim3((unsigned)bc), dim3(stream::kBB), 0, st, sa);
+    // (every other period takes one of the two: a workgroup of the other kernel returns at once)
     if (wide) hipLaunchKernelGGL(stream::sl_part_kernel<1024>, wg, dim3(stream::kBA), lds_a, st, sa);
     else hipLaunchKernelGGL(stream::sl_part_kernel<512>, wg, dim3(stream::kBA), lds_a, st, sa);
     if (sa.slices) hipLaunchKernelGGL(stream::sl_bound_kernel, wg, dim3(stream::kBA), 0, st, sa);
@@ -2991,6 +3036,7 @@ int pdc_supersmoother_scan_dev(int device, void *stream, const double *d_t, cons
     if (z.streamed) {
         sa = stream_args(z.h, base, d_t, d_y, d_periods, n, nullptr);
         sa.sorted = sorted;
+        sa.direct = 0;
         PDC_TRY(stream_allow_lds(z.h));
     }
     ss::SsSortArgs fa;

