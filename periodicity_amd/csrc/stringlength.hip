@@ -1687,6 +1687,7 @@ static_assert(kTA == 4 * kBA && kTA < 65536, "four samples per thread");
 constexpr size_t lds_part(int s1p) { return (size_t)kTA * (8 + 8 + 2) + (size_t)kNC * 2 + (size_t)s1p * 4 * 4; }
 constexpr int kCycS = 512;         // slices mode: entries per row of a period's boundary table = cycles the period may span + 1
 constexpr int kMinSlice = 16;      // slices mode: samples per (cycle, bin) cell on average, at least
+constexpr int kDirectW = 32;        // workgroups per one-cycle period in sl_direct_kernel
 constexpr unsigned kFlagDirect = 16u; // flag[] value: one cycle, summed as the samples stand
 constexpr int kBatchMax = 768;     // periods per batch at most (the sort kernel keeps a prefix over them in LDS)
 constexpr size_t kLdsB = (size_t)kCap * (8 + 8 + 4) + (size_t)kFineB * 2;
@@ -1721,6 +1722,7 @@ struct StreamArgs {
     unsigned *ix;               // [batch][s1][kCap] sample index (ties)
     double *ssum;               // [batch][s1][4]    first / last (phase, m) of every bin in sorted order
     double *slen;               // [batch][s1]       string length inside every bin
+    double *dpart;              // [batch][kDirectW] one-cycle periods: partial sums of sl_direct_kernel's workgroups
     double *ell;
     unsigned char *todo;        // [n_periods]       1 = left to the general kernel
     unsigned *todo_count;
@@ -2073,8 +2075,17 @@ __global__ __launch_bounds__(kBA) void sl_bound_kernel(StreamArgs a) {
         const int64_t i0 = g0 + kappa * kTA + (int64_t)tid * 4;   // four consecutive samples per thread
         if (g0 + kappa * kTA >= a.n) break;                // (workgroup-uniform)
         int key[4];
+        if (i0 + 4 <= a.n) {   // two 16-byte loads (8-byte aligned: t is the caller's pointer)
+            typedef double pair_t __attribute__((ext_vector_type(2), aligned(8)));
+            const pair_t t01 = *reinterpret_cast<const pair_t *>(a.t + i0), t23 = *reinterpret_cast<const pair_t *>(a.t + i0 + 2);
+            key[0] = key_of(t01.x);
+            key[1] = key_of(t01.y);
+            key[2] = key_of(t23.x);
+            key[3] = key_of(t23.y);
+        } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) key[u] = i0 + u < a.n ? key_of(a.t[i0 + u]) : key_end;
+            for (int u = 0; u < 4; ++u) key[u] = i0 + u < a.n ? key_of(a.t[i0 + u]) : key_end;
+        }
         last[tid] = key[3];
         __syncthreads();
         int prev = tid > 0 ? last[tid - 1] : carry;
@@ -2465,17 +2476,21 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
 }
 
 // One cycle of the period covers all samples and t is non-decreasing: phase order = sample order (equal phases -
-// equal times - stay in index order, as the stable sort leaves them).  A workgroup per such period sums the segments
-// in one pass, every thread the samples i = its id mod 1024, the threads' sums in a fixed order.
+// equal times - stay in index order, as the stable sort leaves them).  kDirectW workgroups per such period sum the
+// segments of one contiguous share of the samples each, every thread the samples i = its id mod 1024 of the share,
+// the threads' sums in a fixed order; sl_link_kernel adds the shares in order and the closing segment.
 __global__ __launch_bounds__(kBB) void sl_direct_kernel(StreamArgs a) {
     __shared__ double red[kBB / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = (int)(blockIdx.x / kDirectW), g = (int)(blockIdx.x % kDirectW);
     if (a.flag[q] != kFlagDirect) return;                 // (workgroup-uniform)
     const double period = a.periods[a.p0 + q];
     const double y = 1.0 / period;
     const bool safe = period_is_safe(period, a.bad_t[0] == 0u);
+    const int64_t share = (a.n + kDirectW - 1) / kDirectW;
+    const int64_t lo = g * share > 1 ? g * share : 1, hi = (g + 1) * share < a.n ? (g + 1) * share : a.n;
     double acc = 0.0;
-    for (int64_t i = tid + 1; i < a.n; i += kBB) {
+    for (int64_t i = lo + tid; i < hi; i += kBB) {        // segment (i - 1, i)
         const double p1 = fast_phase(a.t[i], period, y, safe), p0 = fast_phase(a.t[i - 1], period, y, safe);
         acc += short_hypot(a.m[i] - a.m[i - 1], p1 - p0);
     }
@@ -2485,10 +2500,7 @@ __global__ __launch_bounds__(kBB) void sl_direct_kernel(StreamArgs a) {
     if (tid == 0) {
         double total = 0.0;
         for (int x = 0; x < kBB / 64; ++x) total += red[x];
-        // closing segment of np.roll(-1): first minus last, no phase wrap (phase.py:50)
-        total += hypot(a.m[0] - a.m[a.n - 1],
-                       fast_phase(a.t[0], period, y, safe) - fast_phase(a.t[a.n - 1], period, y, safe));
-        a.ell[a.p0 + q] = total;
+        a.dpart[q * kDirectW + g] = total;
     }
 }
 
@@ -2498,8 +2510,19 @@ __global__ __launch_bounds__(256) void sl_link_kernel(StreamArgs a) {
     const int q = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (q >= a.batch) return;
     const int64_t p = a.p0 + q;
-    if (a.flag[q] == kFlagDirect) {                       // (sl_direct_kernel wrote its length)
-        if (lane == 0) a.todo[p] = 0;
+    if (a.flag[q] == kFlagDirect) {                       // (sl_direct_kernel summed the segments share by share)
+        if (lane == 0) {
+            const double period = a.periods[p];
+            const double y = 1.0 / period;
+            const bool safe = period_is_safe(period, a.bad_t[0] == 0u);
+            double total = 0.0;
+            for (int g = 0; g < kDirectW; ++g) total += a.dpart[q * kDirectW + g];
+            // closing segment of np.roll(-1): first minus last, no phase wrap (phase.py:50)
+            total += hypot(a.m[0] - a.m[a.n - 1],
+                           fast_phase(a.t[0], period, y, safe) - fast_phase(a.t[a.n - 1], period, y, safe));
+            a.ell[p] = total;
+            a.todo[p] = 0;
+        }
         return;
     }
     if (a.flag[q] != 0u) {
@@ -2596,7 +2619,7 @@ bool stream_takes(int64_t n) { return n >= stream_min_n() && n >= 4096 && n <= k
 
 struct StreamShape {
     int s1, batch, groups, tiles_w;
-    int64_t o_bad, o_flag, o_nbins, o_ncyc, o_cyc0, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_bnd, o_ix, o_pm, o_todo, o_tcount, total;
+    int64_t o_bad, o_flag, o_nbins, o_ncyc, o_cyc0, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_dpart, o_bnd, o_ix, o_pm, o_todo, o_tcount, total;
 };
 StreamShape stream_shape(int64_t n, int64_t n_periods) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
@@ -2637,7 +2660,8 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     h.o_bstart = h.o_bcnt + up(items * 4);
     h.o_ssum = h.o_bstart + up(items * 4);
     h.o_slen = h.o_ssum + up(items * 32);
-    h.o_bnd = h.o_slen + up(items * 8);
+    h.o_dpart = h.o_slen + up(items * 8);
+    h.o_bnd = h.o_dpart + up(batch * stream::kDirectW * 8);
     h.o_ix = h.o_bnd + up(items * stream::kCycS * 4);
     h.o_pm = h.o_ix + up(items * stream::kCap * 4);
     h.o_todo = h.o_pm + up(items * stream::kCap * 16);
@@ -2696,6 +2720,7 @@ stream::StreamArgs stream_args(const StreamShape &h, char *area, const double *d
     sa.sorted = nullptr;
     sa.ssum = reinterpret_cast<double *>(area + h.o_ssum);
     sa.slen = reinterpret_cast<double *>(area + h.o_slen);
+    sa.dpart = reinterpret_cast<double *>(area + h.o_dpart);
     sa.ix = reinterpret_cast<unsigned *>(area + h.o_ix);
     sa.pm = reinterpret_cast<fast::rec_t *>(area + h.o_pm);
     sa.todo = reinterpret_cast<unsigned char *>(area + h.o_todo);
@@ -2714,7 +2739,7 @@ int stream_sort_batch(int device, hipStream_t st, const StreamShape &h, stream::
     const dim3 wg((unsigned)(bc * h.groups));
     hipLaunchKernelGGL(stream::sl_hist_kernel, wg, dim3(stream::kBA), 0, st, sa);
     hipLaunchKernelGGL(stream::sl_lut_kernel, dim3((unsigned)bc), dim3(256), (size_t)h.s1 * h.groups * 4, st, sa);
-    if (sa.direct) hipLaunchKernelGGL(stream::sl_direct_kernel, dim3((unsigned)bc), dim3(stream::kBB), 0, st, sa);
+    if (sa.direct) hipLaunchKernelGGL(stream::sl_direct_kernel, dim3((unsigned)(bc * stream::kDirectW)), dim3(stream::kBB), 0, st, sa);
     // (every other period takes one of the two: a workgroup of the other kernel returns at once)
     if (wide) hipLaunchKernelGGL(stream::sl_part_kernel<1024>, wg, dim3(stream::kBA), lds_a, st, sa);
     else hipLaunchKernelGGL(stream::sl_part_kernel<512>, wg, dim3(stream::kBA), lds_a, st, sa);
