@@ -169,6 +169,15 @@ def pmc_for(kernel_substr, measured_ms):
     return dict(best[2], name=best[1]), None
 
 
+def profiled_ms_of(kernel_substr):
+    """Duration of the longest profiled launch of a kernel (None without a summary)."""
+    if not os.path.isfile(PMC_SUMMARY):
+        return None
+    ms = [k["ms"] for name, k in json.load(open(PMC_SUMMARY)).get("kernels", {}).items()
+          if kernel_substr in name and "SQ_INSTS_VALU" in k and k.get("ms")]
+    return max(ms) if ms else None
+
+
 def valu_issue_block(kernel_substr, kernel_ms):
     k, why = pmc_for(kernel_substr, kernel_ms)
     if k is None:
@@ -462,7 +471,7 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
     # slices per period), and N = 1e6 takes the streamed kernels (counting sort by phase bin through HBM, no gathers)
     for key, n_l, np_l, kern, what in (
             ("sl_sunspots_size", 74_326, 20_000, "sl_fast_kernel", "the several-slice kernel (N > 52 112: one period no longer fits one LDS slice)"),
-            ("sl_streamed_1e6", 1_000_000, 2048, "sl_sort_kernel", "the streamed kernels: histogram -> bin table -> LDS-staged partition -> LDS sort per bin -> links")):
+            ("sl_streamed_1e6", 1_000_000, 2048, "sl_sort_kernel", "the streamed kernels, slices mode: histogram -> bin table -> table of the (cycle, bin) cells' first samples -> LDS sort per bin, records fetched as slices of t / m -> links")):
         tl, yl, _ = synth_curve(n_l, 5, period=13.7)
         ml = (yl - yl.max()) / (2 * (yl.max() - yl.min())) + 0.25
         dfl = 0.1 / (tl[-1] - tl[0])
@@ -477,12 +486,22 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
         entry = {"ms": round(ms, 3), "Gpair_per_s": round(pairs_l / ms / 1e6, 1), "n_samples": n_l, "n_periods": np_l,
                  "per_pair_vs_c5": round((ms / pairs_l) / (out["c5_stringlength"]["ms"] / pairs), 3), "note": what}
         if key == "sl_streamed_1e6":
-            gbps = pairs_l * 40.0 / ms / 1e6
-            # (five kernels per batch of periods: no single profiled launch to price an issue fraction on)
-            entry.update({"executed_issue_frac": None, "algorithmic_frac": round(gbps / (HBM_PEAK_TBS * 1000), 4),
-                          "algorithmic_unit": "40 B per pair (20 written + 20 read, sequential) vs 8 TB/s HBM"})
-            entry["roofline"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s",
-                                 "frac": round(gbps / (HBM_PEAK_TBS * 1000), 4), "algorithmic_bytes_per_pair": 40}
+            # Slices mode (t non-decreasing): no record passes through HBM - t is read by the histogram and the boundary
+            # kernel, t and m by the sort kernel, 32 bytes per pair from L2 / the Infinity Cache; the sort kernel (3/4 of
+            # the time) is bound by VALU issue and LDS latency.  Its issue fraction is that of its longest PROFILED launch
+            # (five kernels per batch of periods: no single launch of this run to price).
+            k_ms = profiled_ms_of("sl_sort_kernel")
+            blk, why = valu_issue_block("sl_sort_kernel", k_ms) if k_ms else (None, "no profiled sl_sort_kernel launch")
+            entry.update({"executed_issue_frac": blk["frac"] if blk else None, "algorithmic_frac": None,
+                          "algorithmic_unit": "none: 32 B per pair from L2 / Infinity Cache in slices mode, nothing through HBM "
+                                              "(lists mode, unsorted t: 40 B per pair through HBM)"})
+            if blk:
+                entry["executed_issue"] = {k: blk[k] for k in ("kernel", "valu_wave_instr_per_launch", "priced", "mix",
+                                                               "frac_all_at_4_cycles", "profiled_ms", "source",
+                                                               "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
+                                                               "hbm_bytes") if k in blk}
+            else:
+                entry["executed_issue_note"] = why
         out[key] = entry
         for b in bl + [bel, wl]:
             b.free()

@@ -1745,10 +1745,28 @@ __device__ __forceinline__ int64_t sample_of(int64_t kappa, int l, int w, int ti
     return ((int64_t)w * tiles_w + kappa) * kTA + l;
 }
 
+// Workgroup -> (period q, group w) for the kernels that stream a group's samples (histogram, partition, boundaries).
+// Workgroups go to the eight XCDs round robin by their index, and every XCD has an L2 of its own: with the group a
+// function of the XCD (w = xcd mod W, W <= 8 groups) an L2 only ever sees its group's share of t[] (and m[]) - 2 MB of
+// t at N = 1e6 with four groups - and every period after the first reads it from there.  (Numbered period-major the
+// workgroups of all groups ran side by side on every XCD and t came from the Infinity Cache again and again.)
+__device__ __forceinline__ bool period_and_group(const StreamArgs &a, int &q, int &w) {
+    if (a.groups > 8) {
+        q = (int)(blockIdx.x % (unsigned)a.batch);
+        w = (int)(blockIdx.x / (unsigned)a.batch);
+        return true;
+    }
+    const int per_group = 8 / a.groups, xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
+    w = xcd % a.groups;
+    q = j * per_group + xcd / a.groups;
+    return q < a.batch;
+}
+
 __global__ __launch_bounds__(kBA) void sl_hist_kernel(StreamArgs a) {
     __shared__ unsigned h[kNC];
     const int tid = threadIdx.x;
-    const int q = (int)(blockIdx.x % (unsigned)a.batch), w = (int)(blockIdx.x / (unsigned)a.batch);
+    int q, w;
+    if (!period_and_group(a, q, w)) return;               // (workgroup-uniform)
     const double period = a.periods[a.p0 + q];
     const double y = 1.0 / period;
     const bool safe = period_is_safe(period, a.bad_t[0] == 0u);
@@ -1925,7 +1943,8 @@ __global__ __launch_bounds__(kBA) void sl_part_kernel(StreamArgs a) {
     __shared__ unsigned wave_tot[kBA / 64];
     __shared__ int s_over;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = (int)(blockIdx.x % (unsigned)a.batch), w = (int)(blockIdx.x / (unsigned)a.batch);
+    int q, w;
+    if (!period_and_group(a, q, w)) return;               // (workgroup-uniform)
     if (a.flag[q] != 0u || a.ncyc[q] != 0) return;        // (workgroup-uniform) the general kernel, or sl_bound_kernel, takes this period
     const int s1 = a.s1;
     const double period = a.periods[a.p0 + q];
@@ -2044,7 +2063,8 @@ __global__ __launch_bounds__(kBA) void sl_bound_kernel(StreamArgs a) {
     __shared__ unsigned short lut[kNC];
     __shared__ int last[kBA];
     const int tid = threadIdx.x;
-    const int q = (int)(blockIdx.x % (unsigned)a.batch), w = (int)(blockIdx.x / (unsigned)a.batch);
+    int q, w;
+    if (!period_and_group(a, q, w)) return;               // (workgroup-uniform)
     const int K = a.ncyc[q];
     if (a.flag[q] != 0u || K == 0) return;                // (workgroup-uniform)
     const int nb = (int)a.nbins[q];
@@ -2737,7 +2757,8 @@ int stream_sort_batch(int device, hipStream_t st, const StreamShape &h, stream::
     PDC_REQUIRE(bc * h.s1 < ((int64_t)1 << 31), "stringlength: grid too large");
     const bool wide = h.s1 > 512;
     const size_t lds_a = stream::lds_part(wide ? 1024 : 512);
-    const dim3 wg((unsigned)(bc * h.groups));
+    // (period_and_group(): eight workgroups - one per XCD - per 8 / groups periods)
+    const dim3 wg((unsigned)(h.groups > 8 ? bc * h.groups : 8 * ((bc + 8 / h.groups - 1) / (8 / h.groups))));
     hipLaunchKernelGGL(stream::sl_hist_kernel, wg, dim3(stream::kBA), 0, st, sa);
     hipLaunchKernelGGL(stream::sl_lut_kernel, dim3((unsigned)bc), dim3(256), (size_t)h.s1 * h.groups * 4, st, sa);
     if (sa.direct) hipLaunchKernelGGL(stream::sl_direct_kernel, dim3((unsigned)(bc * stream::kDirectW)), dim3(stream::kBB), 0, st, sa);
