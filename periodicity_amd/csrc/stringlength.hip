@@ -1662,6 +1662,17 @@ __global__ __launch_bounds__(BLK, 4) void sl_duo_kernel(DuoArgs a) {
 //   sl_link_kernel   one wave per period: the bins' lengths in bin order, the links between consecutive
 //                    non-empty bins and the closing segment (phase.py:50, not phase-wrapped).
 // Traffic: 20 bytes written and read per (sample, period) pair, sequential - HBM-bound at ~40 B per pair.
+//
+// SLICES MODE (t non-decreasing, checked on the device): the samples of one cycle of the period are consecutive AND
+// in phase order, so the samples of (cycle c, bin b) are ONE SLICE of t[] / m[] and nothing has to be partitioned:
+//   sl_bound_kernel  in place of sl_part_kernel: a table of the first sample of every (cycle, bin) cell, written
+//                    where key(i) = cycle * bins + bin steps up along i (one word per cell, t read once);
+//   sl_sort_kernel   fetches a bin's records as its K slices (prefix over their lengths in LDS, one search per wave,
+//                    then a walk) and computes the phases itself - from there on the same kernel: the two modes agree
+//                    bit for bit;
+//   sl_direct_kernel periods of ONE cycle: phase order = sample order, the segments are summed as the samples stand.
+// The bin table kernel picks the mode per period (cells of >= 4 samples on average, < 1024 cycles); periods that miss
+// it, or samples in any order, take the lists above.  PDC_SL_SLICES=0 switches the mode off (A/B, tests).
 namespace stream {
 using namespace fast;
 
