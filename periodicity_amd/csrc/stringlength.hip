@@ -1716,6 +1716,8 @@ struct StreamArgs {
     int groups;                 // W: workgroups per period in the histogram / partition kernels
     int tiles_w;                // tiles of kTA samples per group
     const unsigned *bad_t;      // [0] != 0: some |t| outside {0} u [1e-150, 1e150]; [1] != 0: t is not non-decreasing
+    const rec_t *tm;            // [n] (t, m) side by side, written by sl_tame_kernel: the sort kernel's slices come as
+                                //     one 16-byte load per record
     unsigned *hist;             // [batch][W][kNC]   the groups' histograms
     unsigned short *lut;        // [batch][kNC]      coarse bucket -> bin
     unsigned short *clo;        // [batch][s1 + 1]   first coarse bucket of every bin
@@ -1740,9 +1742,15 @@ struct StreamArgs {
     unsigned *todo_count;
 };
 
-__global__ __launch_bounds__(256) void sl_tame_kernel(const double *t, int64_t n, unsigned *bad) {
+__global__ __launch_bounds__(256) void sl_tame_kernel(const double *t, const double *m, rec_t *tm, int64_t n, unsigned *bad) {
     bool mine = false, unsorted = false;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (tm) {
+            rec_t r;
+            r.x = t[i];
+            r.y = m[i];
+            tm[i] = r;
+        }
         const double at = __builtin_fabs(t[i]);
         mine = mine || !(at == 0.0 || (at >= 1e-150 && at <= 1e150));
         unsorted = unsorted || (i > 0 && !(t[i - 1] <= t[i]));   // (NaN counts as unsorted)
@@ -2299,10 +2307,7 @@ __global__ __launch_bounds__(kBB) void sl_sort_kernel(StreamArgs a) {
                 while (sidx + 1u < (unsigned)K && (unsigned)sl_pre[sidx + 1u] <= r) ++sidx;
                 unsigned at = sl_start[sidx] + (r - (unsigned)sl_pre[sidx]);
                 at = at < (unsigned)a.n ? at : (unsigned)(a.n - 1);   // (always inside: the table and the count come from the same phases)
-                rec_t v;
-                v.x = a.t[at];
-                v.y = a.m[at];
-                rn[e] = v;
+                rn[e] = a.tm[at];
                 idn[e] = at;
             }
         }
@@ -2651,7 +2656,7 @@ bool stream_takes(int64_t n) { return n >= stream_min_n() && n >= 4096 && n <= k
 
 struct StreamShape {
     int s1, batch, groups, tiles_w;
-    int64_t o_bad, o_flag, o_nbins, o_ncyc, o_cyc0, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_dpart, o_bnd, o_ix, o_pm, o_todo, o_tcount, total;
+    int64_t o_bad, o_flag, o_nbins, o_ncyc, o_cyc0, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_dpart, o_bnd, o_ix, o_pm, o_tm, o_todo, o_tcount, total;
 };
 StreamShape stream_shape(int64_t n, int64_t n_periods) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
@@ -2696,7 +2701,8 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     h.o_bnd = h.o_dpart + up(batch * stream::kDirectW * 8);
     h.o_ix = h.o_bnd + up(items * stream::kCycS * 4);
     h.o_pm = h.o_ix + up(items * stream::kCap * 4);
-    h.o_todo = h.o_pm + up(items * stream::kCap * 16);
+    h.o_tm = h.o_pm + up(items * stream::kCap * 16);
+    h.o_todo = h.o_tm + up(n * 16);
     h.o_tcount = h.o_todo + up(n_periods);
     h.total = h.o_tcount + 256;
     return h;
@@ -2756,6 +2762,7 @@ stream::StreamArgs stream_args(const StreamShape &h, char *area, const double *d
     sa.ix = reinterpret_cast<unsigned *>(area + h.o_ix);
     sa.pm = reinterpret_cast<fast::rec_t *>(area + h.o_pm);
     sa.todo = reinterpret_cast<unsigned char *>(area + h.o_todo);
+    sa.tm = reinterpret_cast<const fast::rec_t *>(area + h.o_tm);
     sa.todo_count = reinterpret_cast<unsigned *>(area + h.o_tcount);
     sa.ell = d_ell;
     return sa;
@@ -2892,7 +2899,8 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
         stream::StreamArgs sa = stream_args(h, area, d_t, d_m, d_periods, n, d_ell);
         PDC_HIP(hipMemsetAsync(area + h.o_bad, 0, 256, st));
         PDC_HIP(hipMemsetAsync(sa.todo_count, 0, 256, st));
-        hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, n, const_cast<unsigned *>(sa.bad_t));
+        hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, d_m, const_cast<fast::rec_t *>(sa.tm), n,
+                           const_cast<unsigned *>(sa.bad_t));
         PDC_TRY(stream_allow_lds(h));
         for (int64_t p0 = 0; p0 < n_periods; p0 += h.batch) {
             const int64_t bc = n_periods - p0 < h.batch ? n_periods - p0 : h.batch;
@@ -3089,7 +3097,7 @@ int pdc_supersmoother_scan_dev(int device, void *stream, const double *d_t, cons
     fast::rec_t *sorted = reinterpret_cast<fast::rec_t *>(base + z.o_sorted);
     unsigned *bad = reinterpret_cast<unsigned *>(base + (z.streamed ? z.h.o_bad : z.o_bad));
     PDC_HIP(hipMemsetAsync(bad, 0, 256, st));
-    hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, n, bad);
+    hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, d_y, z.streamed ? reinterpret_cast<fast::rec_t *>(base + z.h.o_tm) : nullptr, n, bad);
     stream::StreamArgs sa;
     if (z.streamed) {
         sa = stream_args(z.h, base, d_t, d_y, d_periods, n, nullptr);
