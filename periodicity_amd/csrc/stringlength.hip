@@ -2639,20 +2639,34 @@ int64_t duo_bytes(int64_t n_periods) { return ((n_periods + 255) & ~(int64_t)255
 
 
 // ---- streamed path: batch geometry and workspace ---------------------------------------------------------
-// PDC_SL_STREAM_MIN: smallest N that takes the streamed kernels (default 240 000: measured, N = 2e5 x 8192 periods
-// 19.0 ms through the several-slice kernel against 32.4 streamed, N = 2.5e5 x 4096 22.9 against 19.5);
-// PDC_SL_STREAM=0 switches them off (A/B, tests)
+// The streamed kernels work on ALL of a period's samples with the whole chip; the kernels above give a period to one
+// workgroup and want thousands of periods to fill 256 - 1024 of them.  Which is faster therefore depends on the
+// number of periods as much as on N (same box, reference grid, ms streamed / ms otherwise):
+//   N = 2e5 x 8192: 25.7 / 16.7, x 4096: 11.1 / 10.0, x 2048: 5.2 / 6.5, x 1000: 2.5 / 4.7
+//   N = 131 000 x 8192: 16.0 / 11.1, x 2048: 3.5 / 5.1, x 1000: 1.7 / 4.0      N = 74 326 x 4096: 4.5 / 3.7, x 3000: 3.3 / 3.2,
+//   x 2048: 2.2 / 2.6, x 1000: 1.1 / 2.0, x 500: 0.56 / 1.70                   N = 60 000 x 2048: 1.9 / 1.3, x 1000: 0.92 / 0.86,
+//   x 500: 0.50 / 0.61       N = 52 000 x 256: 0.24 / 1.25       N = 40 000 x 1000: 0.67 / 0.78, x 300: 0.22 / 0.65
+// (slices mode; the lists mode - samples in any order - is a quarter slower and still ahead from 65 536 samples on).
+// Rule: every N >= 240 000; 65 536 <= N < 240 000 up to 2560 periods; 30 000 <= N < 65 536 up to 768 periods.
+// The reference's own defaults (n_periods = 1000, phase.py:38) on its 74 326-sample SunSpots curve land in the
+// second row.  PDC_SL_STREAM_MIN=<n>: every N >= n instead; PDC_SL_STREAM=0 switches the streamed kernels off (A/B,
+// tests).
 int64_t stream_min_n() {
     static const int64_t v = [] {
         const char *on = getenv("PDC_SL_STREAM");
         if (on && on[0] == '0') return (int64_t)1 << 62;
         const char *e = getenv("PDC_SL_STREAM_MIN");
-        return e ? (int64_t)atoll(e) : (int64_t)240000;
+        return e ? (int64_t)atoll(e) : (int64_t)-1;
     }();
     return v;
 }
 constexpr int64_t kStreamMaxN = (int64_t)(stream::kS1Max - 2) * stream::kMinFill;
-bool stream_takes(int64_t n) { return n >= stream_min_n() && n >= 4096 && n <= kStreamMaxN; }
+bool stream_takes(int64_t n, int64_t n_periods) {
+    if (n < 4096 || n > kStreamMaxN) return false;
+    const int64_t forced = stream_min_n();
+    if (forced >= 0) return n >= forced;
+    return n >= 240000 || (n >= 65536 && n_periods <= 2560) || (n >= 30000 && n_periods <= 768);
+}
 
 struct StreamShape {
     int s1, batch, groups, tiles_w;
@@ -2707,7 +2721,21 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     h.total = h.o_tcount + 256;
     return h;
 }
-int64_t stream_bytes(int64_t n, int64_t n_periods) { return stream_takes(n) ? stream_shape(n, n_periods).total : 0; }
+// (never shrinks when n_periods grows: a plan sized for its largest grid serves every smaller one, whichever kernels
+// that one takes)
+int64_t stream_bytes(int64_t n, int64_t n_periods) {
+    if (n < 4096 || n > kStreamMaxN || n_periods < 1) return 0;
+    const int64_t forced = stream_min_n();
+    int64_t most = n_periods;                     // the largest grid <= n_periods that takes the streamed kernels
+    if (forced >= 0) {
+        if (n < forced) return 0;
+    } else if (n < 240000) {
+        if (n < 30000) return 0;
+        const int64_t cap = n >= 65536 ? 2560 : 768;
+        most = n_periods < cap ? n_periods : cap;
+    }
+    return stream_shape(n, most).total;
+}
 
 template <int KMAX, int BLK = duo::kB, int NBL = fast::kNB>
 int launch_duo(const duo::DuoArgs &a, int64_t grid, hipStream_t st) {
@@ -2890,7 +2918,7 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
     a.ghist = a.gorder + (may_need_partition(n) ? grid * a.n_pad : 0);
     hipStream_t st = (hipStream_t)stream;
     static const bool general_only = [] { const char *e = getenv("PDC_SL_GENERAL"); return e && e[0] == '1'; }();
-    if (!general_only && stream_takes(n)) {
+    if (!general_only && stream_takes(n, n_periods)) {
         // ---- streamed path: histogram -> bin table -> partition -> sort every bin in LDS -> link, batch by batch ----
         const StreamShape h = stream_shape(n, n_periods);
         const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;

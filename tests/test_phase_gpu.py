@@ -165,6 +165,19 @@ def test_stringlength_two_workgroups_per_cu_equal_the_one_workgroup_kernel(tmp_p
 
 
 def test_stringlength_large_n_runs_in_phase_slices():
+    """The sizes below with a handful of periods: by default the streamed kernels take them (few periods leave the
+    one-workgroup-per-period kernels' grid empty); a child process with PDC_SL_STREAM_MIN=350000 keeps everything below
+    that on the several-slice kernels they were written for."""
+    import subprocess
+    import sys
+    _large_n_body()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", "import tests.test_phase_gpu as T; T._large_n_body(); print('ok')"],
+                         env=dict(os.environ, PDC_SL_STREAM_MIN="350000"), cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def _large_n_body():
     # more samples than one LDS slice holds (52112 with 16-bit indices): up to 16 slices of ~24k the fast
     # kernel reads every sample's bucket id back per slice and keeps that slice's; beyond, the general kernel groups
     # the samples by coarse bucket once per period in global scratch and sorts slice after slice
