@@ -460,46 +460,81 @@ __global__ __launch_bounds__(BLOCK) void pdm_scan_kernel(PdmArgs a) {
 
 // Split mode, last step: one thread per trial period adds the slices' histograms in slice order
 // (LDS laid out like the scan kernel's, [bin][thread]) and evaluates theta.
-__global__ __launch_bounds__(64) void pdm_finish_kernel(PdmArgs a) {
+// (64 periods per workgroup - lane = period - times kFinZ waves that share the slices: few periods and many samples
+// mean up to 1024 slices, and one thread adding 1024 x bins partial sums one after the other took 1.4 ms for 64
+// periods at N = 1e6.  Wave zy adds the slices z = zy (mod kFinZ) in z order, the waves' sums are added in wave order:
+// a fixed order again, whatever the slice count.)
+constexpr int kFinZ = 16;
+__global__ __launch_bounds__(64 * kFinZ) void pdm_finish_kernel(PdmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ double red[1];
+    __shared__ double part_s[kFinZ][64];
+    __shared__ long long part_a[kFinZ][64], part_b[kFinZ][64];
+    __shared__ double s_q_total;
     const bool counts_only = a.kind == 2 || a.kind == 4;
     const int m0 = counts_only ? a.nb : a.nb * a.nc;
-    const int nbins = a.kind == 2 ? (a.nb + 1) * a.nc : m0 + 1, tid = threadIdx.x;
+    const int nbins = a.kind == 2 ? (a.nb + 1) * a.nc : m0 + 1, tid = threadIdx.x & 63, zy = threadIdx.x >> 6;
     // sums [nbins][64] then counts [nbins][64]; the counts-only kinds keep no sums
     double *hsum = reinterpret_cast<double *>(lds_raw);
     long long *hcnt = reinterpret_cast<long long *>(hsum + (counts_only ? 0 : (size_t)nbins * 64));
-    const double q_total = fold_parts<64>(a.stat + 2 * kStatParts, a.n_stat, red, false);
+    if (zy == 0) {   // (the fold of the statistics' partial sums as a 64-thread workgroup does it)
+        double v = 0.0;
+        for (int i = tid; i < a.n_stat; i += 64) v += a.stat[2 * kStatParts + i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (tid == 0) s_q_total = v;
+    }
     const int64_t pidx = (int64_t)blockIdx.x * 64 + tid;
-    if (pidx >= a.n_periods) return;
+    const bool live = pidx < a.n_periods;
+    const int64_t pc = live ? pidx : 0;
+    // one cell (or pair of 16-bit cells) at a time: every wave its share of the slices, then wave 0 the waves
+    auto over_waves = [&](auto per_slice, auto store) {
+        double ps = 0.0;
+        long long pa = 0, pb = 0;
+        for (int64_t z = zy; z < a.n_z; z += kFinZ) per_slice(z, ps, pa, pb);
+        part_s[zy][tid] = ps;
+        part_a[zy][tid] = pa;
+        part_b[zy][tid] = pb;
+        __syncthreads();
+        if (zy == 0) {
+            double ts = part_s[0][tid];
+            long long ta = part_a[0][tid], tb = part_b[0][tid];
+            for (int w = 1; w < kFinZ; ++w) {
+                ts += part_s[w][tid];
+                ta += part_a[w][tid];
+                tb += part_b[w][tid];
+            }
+            store(ts, ta, tb);
+        }
+        __syncthreads();
+    };
     double q_over = 0.0, q_nan = 0.0;
     if (counts_only) {   // two 16-bit cells per word in a slice's partial histogram; their sum over the slices is not
         const int ncw = (nbins + 1) / 2;
-        for (int k = 0; k < ncw; ++k) {
-            long long lo = 0, hi = 0;
-            for (int64_t z = 0; z < a.n_z; ++z) {
-                const unsigned w = a.pcnt[(z * ncw + k) * a.p_pad + pidx];
-                lo += w & 0xFFFFu;
-                hi += w >> 16;
-            }
-            hcnt[(2 * k) * 64 + tid] = lo;
-            if (2 * k + 1 < nbins) hcnt[(2 * k + 1) * 64 + tid] = hi;
-        }
+        for (int k = 0; k < ncw; ++k)
+            over_waves([&](int64_t z, double &, long long &lo, long long &hi) {
+                           const unsigned w = a.pcnt[(z * ncw + k) * a.p_pad + pc];
+                           lo += w & 0xFFFFu;
+                           hi += w >> 16;
+                       },
+                       [&](double, long long lo, long long hi) {
+                           hcnt[(2 * k) * 64 + tid] = lo;
+                           if (2 * k + 1 < nbins) hcnt[(2 * k + 1) * 64 + tid] = hi;
+                       });
+    } else {
+        for (int k = 0; k < nbins; ++k)
+            over_waves([&](int64_t z, double &sum, long long &cnt, long long &) {
+                           sum += a.psum[(z * nbins + k) * a.p_pad + pc];
+                           cnt += a.pcnt[(z * nbins + k) * a.p_pad + pc];
+                       },
+                       [&](double sum, long long cnt, long long) {
+                           hsum[k * 64 + tid] = sum;
+                           hcnt[k * 64 + tid] = cnt;
+                       });
+        for (int which = 0; which < 2; ++which)
+            over_waves([&](int64_t z, double &sum, long long &, long long &) { sum += a.pq[(z * 2 + which) * a.p_pad + pc]; },
+                       [&](double sum, long long, long long) { (which == 0 ? q_over : q_nan) = sum; });
     }
-    for (int k = 0; k < nbins && !counts_only; ++k) {
-        double sum = 0.0;
-        long long cnt = 0;
-        for (int64_t z = 0; z < a.n_z; ++z) {
-            sum += a.psum[(z * nbins + k) * a.p_pad + pidx];
-            cnt += a.pcnt[(z * nbins + k) * a.p_pad + pidx];
-        }
-        hsum[k * 64 + tid] = sum;
-        hcnt[k * 64 + tid] = cnt;
-    }
-    for (int64_t z = 0; z < a.n_z && !counts_only; ++z) {
-        q_over += a.pq[(z * 2 + 0) * a.p_pad + pidx];
-        q_nan += a.pq[(z * 2 + 1) * a.p_pad + pidx];
-    }
+    if (zy != 0 || !live) return;
+    const double q_total = s_q_total;
     auto sum_at = [&](int b) { return hsum[b * 64 + tid]; };
     auto cnt_at = [&](int b) { return hcnt[b * 64 + tid]; };
     if (a.kind == 4) a.theta[pidx] = gl_from_bins(cnt_at, m0, a.nc);
@@ -547,7 +582,7 @@ SplitShape split_shape(int kind, int64_t n, int64_t n_periods, int nb, int nc) {
     const int64_t must_z = counts_only ? (n + kCellSamples - 1) / kCellSamples : 1;
     if (n_periods == 0 || n == 0) return sh;
     const bool may = env_split != 0 && n >= 32 * kChunk && lds_bytes(last, 256, counts_only ? 4 : 12) <= 150 * 1024 &&
-                     (size_t)nbins * 64 * (counts_only ? 8 : 16) <= 150 * 1024;
+                     (size_t)nbins * 64 * (counts_only ? 8 : 16) <= 128 * 1024;   // (+ 24 KB of the finishing kernel's own)
     if (!may && must_z <= 1) return sh;
     const int64_t max_z = n / (8 * kChunk) > must_z ? n / (8 * kChunk) : must_z;
     int64_t n_z = 1;
@@ -650,7 +685,7 @@ int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t,
         a.n_z = (int)sh.n_z;
         a.z_len = sh.z_len;
         a.n_stat = sh.n_stat;
-        PDC_TRY(allow_lds(pdm_finish_kernel));
+        PDC_TRY(allow_dynamic_lds((const void *)pdm_finish_kernel, 128 * 1024));   // (+ 24 KB of its own)
         void *spv = work;
         ScratchPin pin;
         if (work) {
@@ -686,7 +721,7 @@ int pdc::phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t,
         else if (kind == 2) PDC_TRY(zlaunch(pdm_scan_kernel<256, 4, true, 2>));
         else if (kind == 1) PDC_TRY(zlaunch(pdm_scan_kernel<256, 4, true, 1>));
         else PDC_TRY(zlaunch(pdm_scan_kernel<256, 4, true, 0>));
-        hipLaunchKernelGGL(pdm_finish_kernel, dim3((unsigned)groups0), dim3(64), (size_t)nbins * 64 * (kind >= 2 ? 8 : 16), st, a);
+        hipLaunchKernelGGL(pdm_finish_kernel, dim3((unsigned)groups0), dim3(64 * kFinZ), (size_t)nbins * 64 * (kind >= 2 ? 8 : 16), st, a);
         PDC_HIP(hipGetLastError());
         return PDC_OK;
     }
