@@ -87,6 +87,7 @@ struct SlArgs {
     unsigned *ghist;            // [grid][kBucketsLarge]  first sorted position of every coarse bucket
     const unsigned char *todo = nullptr;   // NULL, or [n_periods]: only periods with a non-zero entry are worked off
     const unsigned *todo_count = nullptr;  // (with todo) how many entries are non-zero: 0 ends every workgroup at once
+    const unsigned char *skip = nullptr;   // NULL, or [n_periods]: periods with a non-zero entry are done already (one cycle)
 };
 
 __device__ __forceinline__ double fold_phase(double t, double period) {
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(kBlock) void sl_scan_kernel(SlArgs a) {
 
     for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
         if (a.todo && !a.todo[p]) continue;   // (workgroup-uniform)
+        if (a.skip && a.skip[p]) continue;    // (workgroup-uniform)
         const double period = a.periods[p];
         const double rp = 1.0 / period;
         const double thr = 0.5 - (double)NB * (8.9e-16 * tmax * __builtin_fabs(rp) + 8.9e-16);
@@ -783,6 +785,7 @@ struct FastArgs {
     int slice_cap;              // samples per LDS slice (several slices)
     const unsigned char *todo;  // NULL, or [n_periods]: only periods with a non-zero entry are worked off
     const unsigned *todo_count; // (with todo) how many entries are non-zero: 0 ends every workgroup at once
+    const unsigned char *skip;  // NULL, or [n_periods]: periods with a non-zero entry are done already (one cycle)
 };
 
 // RN(t / period) without the division: y = RN(1 / period); q0 = RN(t y) is within 1.5 ulp of the
@@ -975,6 +978,7 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
     if (a.todo && *a.todo_count == 0u) return;
     for (int64_t p = blockIdx.x; p < a.n_periods; p += gridDim.x) {
         if (a.todo && !a.todo[p]) continue;   // (workgroup-uniform)
+        if (a.skip && a.skip[p]) continue;    // (workgroup-uniform)
         const double period = a.periods[p];
         const double y = 1.0 / period;
         const bool safe = period_is_safe(period, t_safe);
@@ -1406,6 +1410,7 @@ struct DuoArgs {
     unsigned *ticket;           // [0] next period, [1] periods marked in todo[] (both zeroed before the launch)
     double *ell;
     unsigned char *todo;        // [n_periods]: 1 = left to the one-workgroup kernel
+    const unsigned char *skip;  // NULL, or [n_periods]: periods with a non-zero entry are done already (one cycle)
     double *rsum;               // [grid][nr_pad][4]
     int *rcnt;                  // [grid][nr_pad]
     double *rlen;               // [grid][nr_pad]
@@ -1456,6 +1461,7 @@ __global__ __launch_bounds__(BLK, 4) void sl_duo_kernel(DuoArgs a) {
         const unsigned item = s_item;
         if (item >= n_items) break;
         const int64_t p = (int64_t)item;
+        if (a.skip && a.skip[p]) continue;   // (workgroup-uniform)
         const double period = a.periods[p];
         const double y = 1.0 / period;
         const bool safe = period_is_safe(period, t_safe);
@@ -1878,14 +1884,15 @@ __global__ __launch_bounds__(256) void sl_lut_kernel(StreamArgs a) {
         const double c0 = __builtin_floor(exact_quotient(a.t[0], period, y, safe));
         const double c1 = __builtin_floor(exact_quotient(a.t[a.n - 1], period, y, safe));
         const double cycles = c1 - c0 + 1.0;
-        const bool slices = a.slices != 0 && a.bad_t[1] == 0u && nb > 0u && cycles >= 1.0 && cycles < (double)kCycS &&
+        // (a negative period runs the phases DOWN along t: neither mode applies)
+        const bool slices = a.slices != 0 && a.bad_t[1] == 0u && period > 0.0 && nb > 0u && cycles >= 1.0 && cycles < (double)kCycS &&
                             cycles * (double)nb * (double)kMinSlice <= (double)a.n;
         a.ncyc[q] = slices ? (int)cycles : 0;
         a.cyc0[q] = c0;
         // One cycle (the period outlasts the samples) and t non-decreasing: the phases are in order as the samples
         // stand - no sort, one pass (sl_direct_kernel).  These are also the periods whose phases pile up in a few
         // coarse buckets (p >> baseline), which no bin table can take.
-        if (a.direct != 0 && a.bad_t[1] == 0u && cycles == 1.0) {
+        if (a.direct != 0 && a.bad_t[1] == 0u && period > 0.0 && cycles == 1.0) {
             a.flag[q] = kFlagDirect;
             a.nbins[q] = 0u;
             a.ncyc[q] = 0;
@@ -2633,40 +2640,97 @@ int64_t scratch_bytes(int64_t n, int64_t n_periods, int64_t partition) {
 // AoS (t, m) records + flags of the fast path, placed behind the general scratch
 int64_t fast_table_bytes(int64_t n) { return ((n * 16 + 255) & ~(int64_t)255) + 256; }
 
+// ---- periods of ONE cycle, whatever kernels take the rest ---------------------------------------------------
+// A period that outlasts the samples (p > baseline: the last ten of the reference's grid, phase.py:67-68 with dphi =
+// 0.1) folds them into [0, baseline / p): with t non-decreasing that IS the sorted order, and the kernels that give
+// a period to one workgroup are at their worst there - the phases pile up in a tenth of the coarse buckets, the
+// ranges overflow and go through the deferred bitonic sort: 0.88 ms for such a period at N = 29 000 against 0.06 ms
+// for any other, i.e. most of a call with the reference's default 1000 periods.  A pre-pass marks these periods
+// (skip[]) and sums their segments as the samples stand; the kernels behind it pass them over.
+namespace onecycle {
+using namespace fast;
+struct OneArgs {
+    const double *t, *m, *periods;
+    int64_t n, n_periods;
+    const unsigned *bad;        // [0] some |t| outside {0} u [1e-150, 1e150]; [1] t not non-decreasing (sl_tame_kernel)
+    unsigned char *skip;        // [n_periods] 1 = summed here
+    unsigned *list, *count;     // the marked periods, in no particular order
+    double *ell;
+};
+
+__global__ __launch_bounds__(256) void sl_onecycle_mark_kernel(OneArgs a) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.n_periods) return;
+    bool one = false;
+    if (a.bad[1] == 0u && a.n >= 2) {
+        const double period = a.periods[p];
+        const double y = 1.0 / period;
+        const bool safe = period_is_safe(period, a.bad[0] == 0u);
+        const double c0 = __builtin_floor(exact_quotient(a.t[0], period, y, safe));
+        const double c1 = __builtin_floor(exact_quotient(a.t[a.n - 1], period, y, safe));
+        one = period > 0.0 && c1 - c0 == 0.0;   // (NaN: no)
+    }
+    a.skip[p] = one ? 1 : 0;
+    if (one) a.list[atomicAdd(a.count, 1u)] = (unsigned)p;
+}
+
+__global__ __launch_bounds__(kBlock) void sl_onecycle_kernel(OneArgs a) {
+    __shared__ double red[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned count = *a.count;
+    for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {   // (workgroup-uniform)
+        const int64_t p = a.list[k];
+        const double period = a.periods[p];
+        const double y = 1.0 / period;
+        const bool safe = period_is_safe(period, a.bad[0] == 0u);
+        double acc = 0.0;
+        for (int64_t i = tid + 1; i < a.n; i += kBlock) {        // segment (i - 1, i)
+            const double p1 = fast_phase(a.t[i], period, y, safe), p0 = fast_phase(a.t[i - 1], period, y, safe);
+            acc += short_hypot(a.m[i] - a.m[i - 1], p1 - p0);
+        }
+        acc = wave_sum_fixed(acc);
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double total = 0.0;
+            for (int x = 0; x < kBlock / 64; ++x) total += red[x];
+            // closing segment of np.roll(-1): first minus last, no phase wrap (phase.py:50)
+            total += hypot(a.m[0] - a.m[a.n - 1],
+                           fast_phase(a.t[0], period, y, safe) - fast_phase(a.t[a.n - 1], period, y, safe));
+            a.ell[p] = total;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace onecycle
+
+// skip[n_periods], list[n_periods], the flags of sl_tame_kernel + the count
+int64_t onecycle_bytes(int64_t n_periods) { return ((n_periods + 255) & ~(int64_t)255) + ((n_periods * 4 + 255) & ~(int64_t)255) + 512; }
+
 // workspace of the two-workgroups-per-CU kernel, behind the (t, m) table: the marks for the one-workgroup
 // kernel and the ticket counter
 int64_t duo_bytes(int64_t n_periods) { return ((n_periods + 255) & ~(int64_t)255) + 256; }
 
 
 // ---- streamed path: batch geometry and workspace ---------------------------------------------------------
-// The streamed kernels work on ALL of a period's samples with the whole chip; the kernels above give a period to one
-// workgroup and want thousands of periods to fill 256 - 1024 of them.  Which is faster therefore depends on the
-// number of periods as much as on N (same box, reference grid, ms streamed / ms otherwise):
-//   N = 2e5 x 8192: 25.7 / 16.7, x 4096: 11.1 / 10.0, x 2048: 5.2 / 6.5, x 1000: 2.5 / 4.7
-//   N = 131 000 x 8192: 16.0 / 11.1, x 2048: 3.5 / 5.1, x 1000: 1.7 / 4.0      N = 74 326 x 4096: 4.5 / 3.7, x 3000: 3.3 / 3.2,
-//   x 2048: 2.2 / 2.6, x 1000: 1.1 / 2.0, x 500: 0.56 / 1.70                   N = 60 000 x 2048: 1.9 / 1.3, x 1000: 0.92 / 0.86,
-//   x 500: 0.50 / 0.61       N = 52 000 x 256: 0.24 / 1.25       N = 40 000 x 1000: 0.67 / 0.78, x 300: 0.22 / 0.65
-// (slices mode; the lists mode - samples in any order - is a quarter slower and still ahead from 65 536 samples on).
-// Rule: every N >= 240 000; 65 536 <= N < 240 000 up to 2560 periods; 30 000 <= N < 65 536 up to 768 periods.
-// The reference's own defaults (n_periods = 1000, phase.py:38) on its 74 326-sample SunSpots curve land in the
-// second row.  PDC_SL_STREAM_MIN=<n>: every N >= n instead; PDC_SL_STREAM=0 switches the streamed kernels off (A/B,
-// tests).
+// PDC_SL_STREAM_MIN: smallest N that takes the streamed kernels.  Default 262 144 = where the several-slice kernel's
+// bit-plane indices end (same box, reference grid, ms streamed / ms several slices: N = 250 000 x 1000 3.0 / 3.1, x 4096
+// 12.9 / 9.7; N = 262 000 x 2048 6.6 / 5.8, x 8192 29.0 / 20.9; N = 270 000 x 2048 6.8 / 7.4; N = 300 000 x 1000 3.6 / 5.0,
+// x 4096 15.3 / 17.2; N = 383 000 x 2048 9.2 / 15.6).  (Before the one-cycle pre-pass - namespace onecycle - the
+// kernels that give a period to one workgroup lost 0.9 ms and more per call to the ten longest periods of the
+// reference's grid, and the streamed kernels looked better for few periods at any N: a rule by period count was
+// measured, built and withdrawn the same day.)  PDC_SL_STREAM=0 switches the streamed kernels off (A/B, tests).
 int64_t stream_min_n() {
     static const int64_t v = [] {
         const char *on = getenv("PDC_SL_STREAM");
         if (on && on[0] == '0') return (int64_t)1 << 62;
         const char *e = getenv("PDC_SL_STREAM_MIN");
-        return e ? (int64_t)atoll(e) : (int64_t)-1;
+        return e ? (int64_t)atoll(e) : (int64_t)262144;
     }();
     return v;
 }
 constexpr int64_t kStreamMaxN = (int64_t)(stream::kS1Max - 2) * stream::kMinFill;
-bool stream_takes(int64_t n, int64_t n_periods) {
-    if (n < 4096 || n > kStreamMaxN) return false;
-    const int64_t forced = stream_min_n();
-    if (forced >= 0) return n >= forced;
-    return n >= 240000 || (n >= 65536 && n_periods <= 2560) || (n >= 30000 && n_periods <= 768);
-}
+bool stream_takes(int64_t n, int64_t) { return n >= stream_min_n() && n >= 4096 && n <= kStreamMaxN; }
 
 struct StreamShape {
     int s1, batch, groups, tiles_w;
@@ -2721,21 +2785,7 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     h.total = h.o_tcount + 256;
     return h;
 }
-// (never shrinks when n_periods grows: a plan sized for its largest grid serves every smaller one, whichever kernels
-// that one takes)
-int64_t stream_bytes(int64_t n, int64_t n_periods) {
-    if (n < 4096 || n > kStreamMaxN || n_periods < 1) return 0;
-    const int64_t forced = stream_min_n();
-    int64_t most = n_periods;                     // the largest grid <= n_periods that takes the streamed kernels
-    if (forced >= 0) {
-        if (n < forced) return 0;
-    } else if (n < 240000) {
-        if (n < 30000) return 0;
-        const int64_t cap = n >= 65536 ? 2560 : 768;
-        most = n_periods < cap ? n_periods : cap;
-    }
-    return stream_shape(n, most).total;
-}
+int64_t stream_bytes(int64_t n, int64_t n_periods) { return stream_takes(n, n_periods) && n_periods > 0 ? stream_shape(n, n_periods).total : 0; }
 
 template <int KMAX, int BLK = duo::kB, int NBL = fast::kNB>
 int launch_duo(const duo::DuoArgs &a, int64_t grid, hipStream_t st) {
@@ -2884,7 +2934,8 @@ extern "C" {
 int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) {
     if (n < 0 || n_periods < 0) return -1;
     const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
-    return scratch_bytes(n, n_periods, partition) + fast_table_bytes(n) + duo_bytes(n_periods) + stream_bytes(n, n_periods);
+    return scratch_bytes(n, n_periods, partition) + fast_table_bytes(n) + duo_bytes(n_periods) + onecycle_bytes(n_periods) +
+           stream_bytes(n, n_periods);
 }
 
 int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
@@ -2923,7 +2974,7 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
         const StreamShape h = stream_shape(n, n_periods);
         const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
         char *area = static_cast<char *>(work) + scratch_bytes(n, n_periods, partition) + fast_table_bytes(n) +
-                     duo_bytes(n_periods);
+                     duo_bytes(n_periods) + onecycle_bytes(n_periods);
         stream::StreamArgs sa = stream_args(h, area, d_t, d_m, d_periods, n, d_ell);
         PDC_HIP(hipMemsetAsync(area + h.o_bad, 0, 256, st));
         PDC_HIP(hipMemsetAsync(sa.todo_count, 0, 256, st));
@@ -2974,6 +3025,30 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
         PDC_HIP(hipGetLastError());
         return PDC_OK;
     }
+    // ---- periods of one cycle: summed as the samples stand, passed over by the kernels below (namespace onecycle) ----
+    static const bool onecycle_on = [] { const char *e = getenv("PDC_SL_SLICES"); return !(e && e[0] == '0'); }();
+    if (onecycle_on && n >= 2) {
+        const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
+        char *oc = static_cast<char *>(work) + scratch_bytes(n, n_periods, partition) + fast_table_bytes(n) + duo_bytes(n_periods);
+        onecycle::OneArgs o;
+        o.t = d_t;
+        o.m = d_m;
+        o.periods = d_periods;
+        o.n = n;
+        o.n_periods = n_periods;
+        o.skip = reinterpret_cast<unsigned char *>(oc);
+        o.list = reinterpret_cast<unsigned *>(oc + ((n_periods + 255) & ~(int64_t)255));
+        unsigned *flags = reinterpret_cast<unsigned *>(oc + ((n_periods + 255) & ~(int64_t)255) + ((n_periods * 4 + 255) & ~(int64_t)255));
+        o.bad = flags;
+        o.count = flags + 64;
+        o.ell = d_ell;
+        PDC_HIP(hipMemsetAsync(flags, 0, 512, st));
+        hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(n < 65536 ? 64 : 512), dim3(256), 0, st, d_t, d_m,
+                           static_cast<fast::rec_t *>(nullptr), n, flags);
+        hipLaunchKernelGGL(onecycle::sl_onecycle_mark_kernel, dim3((unsigned)((n_periods + 255) / 256)), dim3(256), 0, st, o);
+        hipLaunchKernelGGL(onecycle::sl_onecycle_kernel, dim3(64), dim3(kBlock), 0, st, o);
+        a.skip = o.skip;
+    }
     // beyond ~16 slices the general kernel (one-off grouping of the indices in global scratch) is ahead: the
     // fast kernel's per-slice passes over the bucket ids and its 16-byte gathers (table > L2) grow with N
     // (x 2048 periods: N = 3.3e5 20.5 against 23.2 ms, N = 4.5e5 39.3 against 35.3 ms); PDC_SL_FAST_SLICES moves it
@@ -3005,6 +3080,7 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
         f.slice_cap = fast::FL<unsigned>::capacity;
         f.todo = nullptr;
         f.todo_count = nullptr;
+        f.skip = a.skip;
         // Two workgroups per CU (sl_duo_kernel) whenever a period's permutation fits half of LDS;
         // PDC_SL_DUO=0 keeps the one-workgroup kernel (A/B, tests)
         static const bool duo_on = [] { const char *e = getenv("PDC_SL_DUO"); return !(e && e[0] == '0'); }();
@@ -3021,6 +3097,7 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
             char *area = table + fast_table_bytes(n);
             unsigned char *todo = reinterpret_cast<unsigned char *>(area);
             d.todo = todo;
+            d.skip = a.skip;
             d.ticket = reinterpret_cast<unsigned *>(area + ((n_periods + 255) & ~(int64_t)255));
             d.rsum = a.rsum;
             d.rcnt = a.rcnt;

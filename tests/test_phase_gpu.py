@@ -165,15 +165,15 @@ def test_stringlength_two_workgroups_per_cu_equal_the_one_workgroup_kernel(tmp_p
 
 
 def test_stringlength_large_n_runs_in_phase_slices():
-    """The sizes below with a handful of periods: by default the streamed kernels take them (few periods leave the
-    one-workgroup-per-period kernels' grid empty); a child process with PDC_SL_STREAM_MIN=350000 keeps everything below
-    that on the several-slice kernels they were written for."""
+    """Default dispatch (the several-slice kernels up to 262 143 samples, the streamed kernels beyond), and once more in
+    a child process with PDC_SL_STREAM_MIN=100000, which sends the 200 000-sample curve through the streamed kernels
+    too."""
     import subprocess
     import sys
     _large_n_body()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", "import tests.test_phase_gpu as T; T._large_n_body(); print('ok')"],
-                         env=dict(os.environ, PDC_SL_STREAM_MIN="350000"), cwd=root, capture_output=True, text=True, timeout=900)
+                         env=dict(os.environ, PDC_SL_STREAM_MIN="100000"), cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-1500:] + out.stderr[-1500:]
 
 
@@ -273,7 +273,7 @@ def test_streamed_stringlength_slices_mode_at_its_own_sizes(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    specs = ["250000x4096", "1000000x384"]
+    specs = ["300000x4096", "1000000x384"]
     runs = []
     for mode in ("1", "0", "1"):
         path = str(tmp_path / f"ab{len(runs)}.npz")

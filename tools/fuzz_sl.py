@@ -1,8 +1,7 @@
 """Randomised parity run of the StringLength kernels against the C oracle: sizes around the fast
 path's capacity, clustered / tied / offset / non-finite time stamps, extreme and special periods.
-``python tools/fuzz_sl.py --cases 200 [--seed 1]``; exit code 1 on any mismatch.  The cases have <= 43 periods, which
-from 30 000 samples on go to the streamed kernels by default: ``PDC_SL_STREAM=0`` keeps them on the kernels that give a
-period to one workgroup, ``PDC_SL_STREAM_MIN=4096`` sends everything from 4096 samples on through the streamed ones."""
+``python tools/fuzz_sl.py --cases 200 [--seed 1]``; exit code 1 on any mismatch.  ``PDC_SL_STREAM_MIN=4096``
+sends everything from 4096 samples on through the streamed kernels (default: from 262 144), ``PDC_SL_STREAM=0`` nothing."""
 import argparse
 import os
 import sys
