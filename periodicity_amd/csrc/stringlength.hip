@@ -1881,8 +1881,8 @@ __global__ __launch_bounds__(256) void sl_lut_kernel(StreamArgs a) {
         const double period = a.periods[a.p0 + q];
         const bool safe = period_is_safe(period, a.bad_t[0] == 0u);
         const double y = 1.0 / period;
-        const double c0 = __builtin_floor(exact_quotient(a.t[0], period, y, safe));
-        const double c1 = __builtin_floor(exact_quotient(a.t[a.n - 1], period, y, safe));
+        const double q0 = exact_quotient(a.t[0], period, y, safe), q1 = exact_quotient(a.t[a.n - 1], period, y, safe);
+        const double c0 = __builtin_floor(q0), c1 = __builtin_floor(q1);
         const double cycles = c1 - c0 + 1.0;
         // (a negative period runs the phases DOWN along t: neither mode applies)
         const bool slices = a.slices != 0 && a.bad_t[1] == 0u && period > 0.0 && nb > 0u && cycles >= 1.0 && cycles < (double)kCycS &&
@@ -1892,7 +1892,8 @@ __global__ __launch_bounds__(256) void sl_lut_kernel(StreamArgs a) {
         // One cycle (the period outlasts the samples) and t non-decreasing: the phases are in order as the samples
         // stand - no sort, one pass (sl_direct_kernel).  These are also the periods whose phases pile up in a few
         // coarse buckets (p >> baseline), which no bin table can take.
-        if (a.direct != 0 && a.bad_t[1] == 0u && period > 0.0 && cycles == 1.0) {
+        // (... or less than one cycle across a cycle boundary: the later samples' phases lie below the first sample's)
+        if (a.direct != 0 && a.bad_t[1] == 0u && period > 0.0 && (cycles == 1.0 || (cycles == 2.0 && q1 - c1 < q0 - c0))) {
             a.flag[q] = kFlagDirect;
             a.nbins[q] = 0u;
             a.ncyc[q] = 0;
@@ -2666,9 +2667,12 @@ __global__ __launch_bounds__(256) void sl_onecycle_mark_kernel(OneArgs a) {
         const double period = a.periods[p];
         const double y = 1.0 / period;
         const bool safe = period_is_safe(period, a.bad[0] == 0u);
-        const double c0 = __builtin_floor(exact_quotient(a.t[0], period, y, safe));
-        const double c1 = __builtin_floor(exact_quotient(a.t[a.n - 1], period, y, safe));
-        one = period > 0.0 && c1 - c0 == 0.0;   // (NaN: no)
+        const double q0 = exact_quotient(a.t[0], period, y, safe), q1 = exact_quotient(a.t[a.n - 1], period, y, safe);
+        const double c0 = __builtin_floor(q0), c1 = __builtin_floor(q1);
+        // (the samples span less than one cycle: all in one, or the later ones in the next with phases BELOW the first
+        // sample's - sorted order = those, then the earlier ones, each as they stand: the same segments, the pair across
+        // the cycle boundary being the closing one.  NaN: no)
+        one = period > 0.0 && (c1 - c0 == 0.0 || (c1 - c0 == 1.0 && q1 - c1 < q0 - c0));
     }
     a.skip[p] = one ? 1 : 0;
     if (one) a.list[atomicAdd(a.count, 1u)] = (unsigned)p;

@@ -288,6 +288,29 @@ def test_streamed_stringlength_slices_mode_at_its_own_sizes(tmp_path):
         assert np.array_equal(runs[0][spec], runs[2][spec]), spec
 
 
+def test_stringlength_periods_that_outlast_the_samples():
+    """p > baseline: the samples span less than one cycle, their phase order is their time order (or, across a cycle
+    boundary, the later samples first) and no kernel sorts anything (onecycle::* / sl_direct_kernel).  Julian-date
+    offsets put the cycle boundary inside the samples for many of these periods; duplicates keep their index order;
+    p just below the baseline takes the ordinary kernels.  All families: one slice, several slices, streamed."""
+    rng = np.random.default_rng(31)
+    for n in (3000, 30_000, 90_000, 300_000):
+        t = np.sort(rng.uniform(0.0, 400.0, n)) + 2454953.5
+        t[7:n:11] = t[6:n - 1:11]                            # duplicate time stamps
+        y = np.sin(2 * np.pi * t / 13.7) + 0.2 * rng.standard_normal(n)
+        m = so.stringlength_scale(y)
+        base = t[-1] - t[0]
+        periods = np.concatenate([base * np.array([0.97, 0.999, 1.0, 1.001, 1.5, 2.0, 3.3, 9.99, 10.0, 57.0]),
+                                  base * rng.uniform(1.0, 12.0, 14), [2454953.5, 2454953.5 / 2, 1e7, 1e9]])
+        got = _cabi.stringlength_scan(t, m, periods)
+        np.testing.assert_allclose(got, co.stringlength_scan(t, m, periods), rtol=RTOL)
+        assert np.array_equal(got, _cabi.stringlength_scan(t, m, periods))
+        # the same curve in another order: nothing may be assumed about it
+        order = rng.permutation(n)
+        np.testing.assert_allclose(_cabi.stringlength_scan(t[order], m[order], periods[:6]),
+                                   co.stringlength_scan(t[order], m[order], periods[:6]), rtol=RTOL)
+
+
 def test_streamed_stringlength_at_its_own_sizes():
     """N = 4e5 (just above the several-slice kernel's range) and N = 1e6 take the streamed kernels by default."""
     rng = np.random.default_rng(12)

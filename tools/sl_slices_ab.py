@@ -20,6 +20,8 @@ for spec in sys.argv[2:]:
     df = 0.1 / (t[-1] - t[0])
     periods = 1 / np.linspace(n_per * df, df, n_per)
     out[spec] = _cabi.stringlength_scan(t, m, periods)
-    out[spec + ":one_cycle"] = np.floor(t[0] / periods) == np.floor(t[-1] / periods)   # (summed as the samples stand)
+    q0, q1 = t[0] / periods, t[-1] / periods                   # (summed as the samples stand: less than one cycle)
+
+    out[spec + ":one_cycle"] = (periods > 0) & ((np.floor(q1) == np.floor(q0)) | ((np.floor(q1) - np.floor(q0) == 1) & (q1 % 1 < q0 % 1)))
 np.savez(sys.argv[1], **out)
 print("ok")
