@@ -1071,7 +1071,8 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         } else {
         // ---- P1 (several slices): histogram of ALL samples, then the grouping by coarse bucket in global
         // scratch, once per period -------------------------------------------------------------------------
-        const int tid = tid0;
+        int tid = tid0;   // (opaque copy, as above: addresses built from the thread id are not hoisted out of the period loop and spilled)
+        asm volatile("" : "+v"(tid));
         for (int b = tid; b < NB; b += kBlock) hist[b] = 0u;
         __syncthreads();
         // (eight coalesced loads per trip, the next trip's requested before this one is folded)
@@ -1116,8 +1117,10 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         for (int b = tid; b < NB; b += kBlock) ghist[b] = hist[b];
         __syncthreads();
         }
-        const int tid = tid0;
+        int tid = tid0;   // (opaque copy, as above: addresses built from the thread id are not hoisted out of the period loop and spilled)
+        asm volatile("" : "+v"(tid));
         do {   // one trip per slice
+        asm volatile("" : "+v"(tid));   // (... nor out of the slice loop)
         if constexpr (MULTI) {
             __syncthreads();
             for (int b = tid; b < NB; b += kBlock) hist[b] = ghist[b];
