@@ -1694,11 +1694,11 @@ using namespace fast;
 constexpr int kTA = 2048;          // samples per partition tile
 constexpr int kBA = 512;           // threads of the histogram / partition kernels (4 samples each per tile)
 constexpr int kNC = 4096;          // coarse phase buckets of the histogram and the bin table
-constexpr int kS1Max = 1024;       // bins per period at most
+constexpr int kS1Max = 2048;       // bins per period at most (5.5 M samples: ~1350 to a coarse bucket - twice that and the
+                                   // buckets themselves crowd the bins' capacity)
 constexpr int kCap = PDC_SL_CAP;   // records a bin's list (and the sort kernel's LDS) holds
 constexpr int kSlack = 16;         // a period's bins are filled to kCap - kSlack - (its heaviest coarse bucket) ...
 constexpr int kMinFill = PDC_SL_MINFILL;   // ... and not below this: heavier coarse buckets (clustered phases) go to the general kernel
-constexpr int kGroupsMax = 16;     // workgroups per period in the histogram / partition kernels
 constexpr int kBB = PDC_SL_BB;     // threads of the sort kernel
 constexpr int kPerB = kCap / kBB;  // records per thread
 constexpr int kFineB = PDC_SL_FINE; // fine buckets per bin, 16-bit counters packed two to a word
@@ -2758,6 +2758,7 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     while (groups < 4 && tiles / (2 * groups) >= 16) groups *= 2;
     static const int env_groups = [] { const char *e = getenv("PDC_SL_STREAM_GROUPS"); return e ? atoi(e) : 0; }();
     if (env_groups == 1 || env_groups == 2 || env_groups == 4 || env_groups == 8 || env_groups == 16) groups = env_groups;
+    while ((int64_t)h.s1 * groups * 4 > 128 * 1024 && groups > 1) groups /= 2;   // (the bin table kernel's LDS)
     h.groups = groups;
     h.tiles_w = (int)((tiles + groups - 1) / groups);
     static const int64_t env_batch = [] { const char *e = getenv("PDC_SL_STREAM_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
@@ -2858,15 +2859,16 @@ int stream_sort_batch(int device, hipStream_t st, const StreamShape &h, stream::
     sa.p0 = p0;
     sa.batch = (int)bc;
     PDC_REQUIRE(bc * h.s1 < ((int64_t)1 << 31), "stringlength: grid too large");
-    const bool wide = h.s1 > 512;
-    const size_t lds_a = stream::lds_part(wide ? 1024 : 512);
+    const int s1p = h.s1 > 1024 ? 2048 : (h.s1 > 512 ? 1024 : 512);
+    const size_t lds_a = stream::lds_part(s1p);
     // (period_and_group(): eight workgroups - one per XCD - per 8 / groups periods)
     const dim3 wg((unsigned)(h.groups > 8 ? bc * h.groups : 8 * ((bc + 8 / h.groups - 1) / (8 / h.groups))));
     hipLaunchKernelGGL(stream::sl_hist_kernel, wg, dim3(stream::kBA), 0, st, sa);
     hipLaunchKernelGGL(stream::sl_lut_kernel, dim3((unsigned)bc), dim3(256), (size_t)h.s1 * h.groups * 4, st, sa);
     if (sa.direct) hipLaunchKernelGGL(stream::sl_direct_kernel, dim3((unsigned)(bc * stream::kDirectW)), dim3(stream::kBB), 0, st, sa);
     // (every other period takes one of the two: a workgroup of the other kernel returns at once)
-    if (wide) hipLaunchKernelGGL(stream::sl_part_kernel<1024>, wg, dim3(stream::kBA), lds_a, st, sa);
+    if (s1p == 2048) hipLaunchKernelGGL(stream::sl_part_kernel<2048>, wg, dim3(stream::kBA), lds_a, st, sa);
+    else if (s1p == 1024) hipLaunchKernelGGL(stream::sl_part_kernel<1024>, wg, dim3(stream::kBA), lds_a, st, sa);
     else hipLaunchKernelGGL(stream::sl_part_kernel<512>, wg, dim3(stream::kBA), lds_a, st, sa);
     if (sa.slices) hipLaunchKernelGGL(stream::sl_bound_kernel, wg, dim3(stream::kBA), 0, st, sa);
     const int64_t sort_slots = (int64_t)cu_count(device) * (stream::kLdsB + 1024 <= 80 * 1024 ? 2 : 1);
@@ -2878,8 +2880,10 @@ int stream_sort_batch(int device, hipStream_t st, const StreamShape &h, stream::
 
 int stream_allow_lds(const StreamShape &h) {
     PDC_TRY(allow_dynamic_lds((const void *)stream::sl_sort_kernel, (int)stream::kLdsB));
-    PDC_TRY(allow_dynamic_lds((const void *)stream::sl_lut_kernel, stream::kS1Max * stream::kGroupsMax * 4));
-    if (h.s1 > 512) PDC_TRY(allow_dynamic_lds((const void *)stream::sl_part_kernel<1024>, (int)stream::lds_part(1024)));
+    PDC_REQUIRE((size_t)h.s1 * h.groups * 4 <= 128 * 1024, "stringlength: %d bins x %d groups do not fit the bin table kernel's LDS", h.s1, h.groups);
+    PDC_TRY(allow_dynamic_lds((const void *)stream::sl_lut_kernel, 128 * 1024));
+    if (h.s1 > 1024) PDC_TRY(allow_dynamic_lds((const void *)stream::sl_part_kernel<2048>, (int)stream::lds_part(2048)));
+    else if (h.s1 > 512) PDC_TRY(allow_dynamic_lds((const void *)stream::sl_part_kernel<1024>, (int)stream::lds_part(1024)));
     else PDC_TRY(allow_dynamic_lds((const void *)stream::sl_part_kernel<512>, (int)stream::lds_part(512)));
     return PDC_OK;
 }
