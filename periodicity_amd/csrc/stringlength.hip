@@ -1720,6 +1720,8 @@ struct StreamArgs {
     int batch;                  // periods in this batch
     int s1;                     // bins reserved per period (the table may use fewer)
     int slices;                 // != 0: periods whose cells are long enough take the slices mode (PDC_SL_SLICES=0: none)
+    int no_lists;               // != 0: the workspace holds no lists (the host saw that every period takes the slices or the
+                                //       one-cycle mode): a period that does not after all goes to the general kernel
     int direct;                 // != 0: periods that outlast the samples are summed as the samples stand (not when the
                                 //       sorted curve itself is wanted: Supersmoother)
     int groups;                 // W: workgroups per period in the histogram / partition kernels
@@ -1900,6 +1902,9 @@ __global__ __launch_bounds__(256) void sl_lut_kernel(StreamArgs a) {
             a.flag[q] = kFlagDirect;
             a.nbins[q] = 0u;
             a.ncyc[q] = 0;
+        } else if (a.no_lists != 0 && !slices && nb > 0u) {
+            a.flag[q] = 32u;             // (cannot happen: the host's test is the stricter one)
+            a.nbins[q] = 0u;
         }
     }
     // how many records every group contributes to every bin - from the groups' own histograms, so the partition
@@ -2743,7 +2748,7 @@ struct StreamShape {
     int s1, batch, groups, tiles_w;
     int64_t o_bad, o_flag, o_nbins, o_ncyc, o_cyc0, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_dpart, o_bnd, o_ix, o_pm, o_tm, o_todo, o_tcount, total;
 };
-StreamShape stream_shape(int64_t n, int64_t n_periods) {
+StreamShape stream_shape(int64_t n, int64_t n_periods, bool lists = true) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
     StreamShape h;
     h.s1 = (int)(n / stream::kMinFill + 2);
@@ -2765,6 +2770,7 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     const int64_t list_bytes = (int64_t)h.s1 * stream::kCap * 20;                 // one period's lists
     int64_t batch = ((int64_t)12 << 30) / list_bytes / 32 * 32;
     batch = batch > 384 ? 384 : (batch < 32 ? 32 : batch);
+    if (!lists) batch = 384;
     if (env_batch > 0) batch = env_batch;
     batch = batch > n_periods ? n_periods : batch;
     batch = batch < 1 ? 1 : (batch > stream::kBatchMax ? stream::kBatchMax : batch);   // (the sort kernel keeps a prefix over the batch's periods in LDS)
@@ -2786,14 +2792,16 @@ StreamShape stream_shape(int64_t n, int64_t n_periods) {
     h.o_dpart = h.o_slen + up(items * 8);
     h.o_bnd = h.o_dpart + up(batch * stream::kDirectW * 8);
     h.o_ix = h.o_bnd + up(items * stream::kCycS * 4);
-    h.o_pm = h.o_ix + up(items * stream::kCap * 4);
-    h.o_tm = h.o_pm + up(items * stream::kCap * 16);
+    h.o_pm = h.o_ix + (lists ? up(items * stream::kCap * 4) : 256);
+    h.o_tm = h.o_pm + (lists ? up(items * stream::kCap * 16) : 256);
     h.o_todo = h.o_tm + up(n * 16);
     h.o_tcount = h.o_todo + up(n_periods);
     h.total = h.o_tcount + 256;
     return h;
 }
-int64_t stream_bytes(int64_t n, int64_t n_periods) { return stream_takes(n, n_periods) && n_periods > 0 ? stream_shape(n, n_periods).total : 0; }
+int64_t stream_bytes(int64_t n, int64_t n_periods, bool lists = true) {
+    return stream_takes(n, n_periods) && n_periods > 0 ? stream_shape(n, n_periods, lists).total : 0;
+}
 
 template <int KMAX, int BLK = duo::kB, int NBL = fast::kNB>
 int launch_duo(const duo::DuoArgs &a, int64_t grid, hipStream_t st) {
@@ -2841,6 +2849,7 @@ stream::StreamArgs stream_args(const StreamShape &h, char *area, const double *d
     static const bool slices = [] { const char *e = getenv("PDC_SL_SLICES"); return !(e && e[0] == '0'); }();
     sa.slices = slices ? 1 : 0;
     sa.direct = sa.slices;
+    sa.no_lists = 0;
     sa.sorted = nullptr;
     sa.ssum = reinterpret_cast<double *>(area + h.o_ssum);
     sa.slen = reinterpret_cast<double *>(area + h.o_slen);
@@ -2942,22 +2951,62 @@ int launch_fast(const fast::FastArgs &a, int64_t grid, hipStream_t st) {
 
 extern "C" {
 
-int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) {
+}  // extern "C"
+
+namespace {
+int64_t stringlength_work_bytes(int64_t n, int64_t n_periods, bool lists) {
     if (n < 0 || n_periods < 0) return -1;
     const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
     return scratch_bytes(n, n_periods, partition) + fast_table_bytes(n) + duo_bytes(n_periods) + onecycle_bytes(n_periods) +
-           stream_bytes(n, n_periods);
+           stream_bytes(n, n_periods, lists);
 }
+
+// Host-side test for pdc_stringlength_scan (host arrays in hand): will EVERY period take the slices or the one-cycle
+// mode of the streamed kernels?  Then the workspace needs no lists - at N = 1e6 12 GB of them, whose allocation alone
+// made a process's first call take 1.2 s.  The same conditions as sl_lut_kernel's with the bins reserved (s1) in place
+// of the bins used: stricter, never laxer.
+bool host_all_slices(const double *t, int64_t n, const double *periods, int64_t n_periods) {
+    static const bool on = [] { const char *e = getenv("PDC_SL_SLICES"); return !(e && e[0] == '0'); }();
+    if (!on || !stream_takes(n, n_periods) || n_periods < 1) return false;
+    for (int64_t i = 1; i < n; ++i)
+        if (!(t[i - 1] <= t[i])) return false;
+    const double s1 = (double)stream_shape(n, n_periods, false).s1;
+    for (int64_t p = 0; p < n_periods; ++p) {
+        const double period = periods[p];
+        if (!(period > 0.0)) return false;
+        const double cycles = std::floor(t[n - 1] / period) - std::floor(t[0] / period) + 1.0;
+        if (!(cycles >= 1.0 && cycles < (double)stream::kCycS && cycles * s1 * (double)stream::kMinSlice <= (double)n)) return false;
+    }
+    return true;
+}
+
+int stringlength_scan_impl(int device, void *stream, const double *d_t, const double *d_m,
+                           int64_t n, const double *d_periods, int64_t n_periods, double *d_ell,
+                           void *work, int64_t work_bytes, bool lists);
+}  // namespace
+
+extern "C" {
+
+int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) { return stringlength_work_bytes(n, n_periods, true); }
 
 int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
                               int64_t n, const double *d_periods, int64_t n_periods, double *d_ell,
                               void *work, int64_t work_bytes) {
+    return stringlength_scan_impl(device, stream, d_t, d_m, n, d_periods, n_periods, d_ell, work, work_bytes, true);
+}
+
+}  // extern "C"
+
+namespace {
+int stringlength_scan_impl(int device, void *stream, const double *d_t, const double *d_m,
+                           int64_t n, const double *d_periods, int64_t n_periods, double *d_ell,
+                           void *work, int64_t work_bytes, bool lists) {
     PDC_REQUIRE(d_t && d_m && (d_periods || n_periods == 0) && (d_ell || n_periods == 0),
                 "stringlength: NULL argument");
     PDC_REQUIRE(n >= 0 && n_periods >= 0, "stringlength: negative size");
     PDC_REQUIRE(n < ((int64_t)1 << 31), "stringlength: at most 2^31-1 samples");
     PDC_REQUIRE(n_periods < ((int64_t)1 << 32), "stringlength: at most 2^32-1 trial periods per call");
-    PDC_REQUIRE(work && work_bytes >= pdc_stringlength_work_bytes(n, n_periods),
+    PDC_REQUIRE(work && work_bytes >= stringlength_work_bytes(n, n_periods, lists),
                 "stringlength: workspace too small");
     if (n_periods == 0) return PDC_OK;
     PDC_TRY(use_device(device));
@@ -2982,11 +3031,12 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
     static const bool general_only = [] { const char *e = getenv("PDC_SL_GENERAL"); return e && e[0] == '1'; }();
     if (!general_only && stream_takes(n, n_periods)) {
         // ---- streamed path: histogram -> bin table -> partition -> sort every bin in LDS -> link, batch by batch ----
-        const StreamShape h = stream_shape(n, n_periods);
+        const StreamShape h = stream_shape(n, n_periods, lists);
         const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
         char *area = static_cast<char *>(work) + scratch_bytes(n, n_periods, partition) + fast_table_bytes(n) +
                      duo_bytes(n_periods) + onecycle_bytes(n_periods);
         stream::StreamArgs sa = stream_args(h, area, d_t, d_m, d_periods, n, d_ell);
+        sa.no_lists = lists ? 0 : 1;
         PDC_HIP(hipMemsetAsync(area + h.o_bad, 0, 256, st));
         PDC_HIP(hipMemsetAsync(sa.todo_count, 0, 256, st));
         hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, d_m, const_cast<fast::rec_t *>(sa.tm), n,
@@ -3163,6 +3213,9 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
     PDC_HIP(hipGetLastError());
     return PDC_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int pdc_stringlength_scan(const double *t, const double *m, int64_t n, const double *periods,
                           int64_t n_periods, double *ell_out, int device) {
@@ -3171,7 +3224,9 @@ int pdc_stringlength_scan(const double *t, const double *m, int64_t n, const dou
     PDC_REQUIRE(n >= 0 && n_periods >= 0, "stringlength: negative size");
     PDC_TRY(use_device(device));
     DeviceLock lock(device);
-    const int64_t wb = pdc_stringlength_work_bytes(n, n_periods);
+    // (time-ordered samples and periods that all take the slices / one-cycle modes: no lists in the workspace)
+    const bool lists = !host_all_slices(t, n, periods, n_periods);
+    const int64_t wb = stringlength_work_bytes(n, n_periods, lists);
     void *d_t, *d_m, *d_p, *d_e, *d_w;
     PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
     PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_m));
@@ -3182,8 +3237,8 @@ int pdc_stringlength_scan(const double *t, const double *m, int64_t n, const dou
     PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_m, m, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_p, periods, n_periods * 8, hipMemcpyHostToDevice, st));
-    PDC_TRY(pdc_stringlength_scan_dev(device, st, (double *)d_t, (double *)d_m, n, (double *)d_p,
-                                      n_periods, (double *)d_e, d_w, wb));
+    PDC_TRY(stringlength_scan_impl(device, st, (double *)d_t, (double *)d_m, n, (double *)d_p,
+                                   n_periods, (double *)d_e, d_w, wb, lists));
     PDC_HIP(hipMemcpyAsync(ell_out, d_e, n_periods * 8, hipMemcpyDeviceToHost, st));
     PDC_HIP(hipStreamSynchronize(st));
     return PDC_OK;
