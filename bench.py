@@ -471,6 +471,9 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
     # slices per period), and N = 1e6 takes the streamed kernels (counting sort by phase bin through HBM, no gathers)
     for key, n_l, np_l, kern, what in (
             ("sl_sunspots_size", 74_326, 20_000, "sl_fast_kernel", "the several-slice kernel (N > 52 112: one period no longer fits one LDS slice)"),
+            ("sl_sunspots_reference_defaults", 74_326, 1000, "sl_fast_kernel",
+             "the reference's own defaults (n_periods = 1000, dphi = 0.1, phase.py:38) at the size of its bundled SunSpots curve: ten of "
+             "the 1000 periods outlast the samples and are summed without a sort (one-cycle pre-pass)"),
             ("sl_streamed_1e6", 1_000_000, 2048, "sl_sort_kernel", "the streamed kernels, slices mode: histogram -> bin table -> table of the (cycle, bin) cells' first samples -> LDS sort per bin, records fetched as slices of t / m -> links")):
         tl, yl, _ = synth_curve(n_l, 5, period=13.7)
         ml = (yl - yl.max()) / (2 * (yl.max() - yl.min())) + 0.25
