@@ -2919,8 +2919,10 @@ SsShape ss_shape(int64_t n, int64_t n_periods) {
         z.batch = (int)(b < 1 ? 1 : b);
     }
     z.stride = (n + n / 2 + 24 + 7) & ~(int64_t)7;   // (prefix arrays run over the curve extended by a quarter on either side)
-    // two smoother workgroups per CU, within 12 GB of scratch
-    int64_t g = ((int64_t)12 << 30) / (ss::kArrays * z.stride * 8);
+    // two smoother workgroups per CU, within 48 GB of scratch (a sixth of the 288 GB: a workgroup's fifteen arrays take
+    // 180 MB at N = 1e6, and with 12 GB only 66 of the 256 CUs had one - N = 1e6 x 256 periods: 12 GB 206 ms, 32 GB 117,
+    // 44 GB 77)
+    int64_t g = ((int64_t)48 << 30) / (ss::kArrays * z.stride * 8);
     g = g < 1 ? 1 : (g > 512 ? 512 : g);
     z.grid_ss = (int)(g < z.batch ? g : z.batch);
     z.grid_fb = z.batch < 256 ? z.batch : 256;
