@@ -41,6 +41,25 @@ def test_matches_scipy_on_random_plateau_nan_and_edge_cases():
         assert idx[b] == j and val[b] == v
 
 
+def test_highest_peak_of_few_long_rows_is_found_by_several_workgroups_per_row():
+    """Rows of more than 32 768 bins are cut into shares of >= 16 384 bins, a workgroup each, and merged: flat tops that
+    run across a share's end, equal maxima in different shares (the lower bin wins), NaN, rows without any maximum, a
+    row count that does not divide the workgroup budget."""
+    rng = np.random.default_rng(3)
+    for rows, nf in ((1, 1_000_003), (3, 250_001), (7, 70_000), (1, 32_768), (1, 32_769)):
+        x = rng.standard_normal((rows, nf)).round(2)
+        share = -(-nf // max(1, min(2048 // rows, nf // 16384)))
+        x[0, share - 3:share + 4] = 9.0                      # a flat top across the first share's end ...
+        x[0, min(5 * share // 2, nf - 3)] = 9.0              # ... and the same height again further on: the first wins
+        if rows > 1:
+            x[1, ::2] = np.nan                               # NaN everywhere: no maximum at all
+            x[-1] = np.arange(nf)                            # monotone: none either
+        idx, val = _cabi.highest_peak(x)
+        for b in range(rows):
+            j, v = scipy_highest(x[b])
+            assert idx[b] == j and (val[b] == v or (np.isnan(val[b]) and np.isnan(v))), (rows, nf, b, idx[b], j)
+
+
 def test_batched_periodograms_reduced_on_device():
     rng = np.random.default_rng(5)
     lens = [300, 511, 1000, 64]
