@@ -2907,13 +2907,13 @@ struct SsShape {
     int batch, grid_ss, grid_fb;
     int64_t stride, n_pad, o_sorted, o_scratch, o_gk, o_gi, o_bad, total;
 };
-SsShape ss_shape(int64_t n, int64_t n_periods) {
+SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
     SsShape z;
     z.streamed = n >= 4096 && n <= kStreamMaxN;
     int64_t at = 0;
     if (z.streamed) {
-        z.h = stream_shape(n, n_periods);
+        z.h = stream_shape(n, n_periods, lists);
         z.batch = z.h.batch;
         at = up(z.h.total);
     } else {
@@ -2922,10 +2922,11 @@ SsShape ss_shape(int64_t n, int64_t n_periods) {
         z.batch = (int)(b < 1 ? 1 : b);
     }
     z.stride = (n + n / 2 + 24 + 7) & ~(int64_t)7;   // (prefix arrays run over the curve extended by a quarter on either side)
-    // two smoother workgroups per CU, within 48 GB of scratch (a sixth of the 288 GB: a workgroup's fifteen arrays take
-    // 180 MB at N = 1e6, and with 12 GB only 66 of the 256 CUs had one - N = 1e6 x 256 periods: 12 GB 206 ms, 32 GB 117,
-    // 44 GB 77)
-    int64_t g = ((int64_t)48 << 30) / (ss::kArrays * z.stride * 8);
+    // two smoother workgroups per CU, within 16 GB of scratch.  (A workgroup's fifteen arrays take 180 MB at N = 1e6:
+    // 12 GB put a smoother on 66 of the 256 CUs - N = 1e6 x 256 periods 206 ms -, 32 GB 117 ms, 44 GB 77 ms; but the
+    // workspace is allocated on a process's first call at ~0.1 s per GB, and a search of a few thousand periods never
+    // earns 4 s of allocation back.)
+    int64_t g = ((int64_t)16 << 30) / (ss::kArrays * z.stride * 8);
     g = g < 1 ? 1 : (g > 512 ? 512 : g);
     z.grid_ss = (int)(g < z.batch ? g : z.batch);
     z.grid_fb = z.batch < 256 ? z.batch : 256;
@@ -2970,9 +2971,9 @@ int64_t stringlength_work_bytes(int64_t n, int64_t n_periods, bool lists) {
 // mode of the streamed kernels?  Then the workspace needs no lists - at N = 1e6 12 GB of them, whose allocation alone
 // made a process's first call take 1.2 s.  The same conditions as sl_lut_kernel's with the bins reserved (s1) in place
 // of the bins used: stricter, never laxer.
-bool host_all_slices(const double *t, int64_t n, const double *periods, int64_t n_periods) {
+bool host_all_slices(const double *t, int64_t n, const double *periods, int64_t n_periods, int64_t min_n) {
     static const bool on = [] { const char *e = getenv("PDC_SL_SLICES"); return !(e && e[0] == '0'); }();
-    if (!on || !stream_takes(n, n_periods) || n_periods < 1) return false;
+    if (!on || n < min_n || n < 4096 || n > kStreamMaxN || n_periods < 1) return false;
     for (int64_t i = 1; i < n; ++i)
         if (!(t[i - 1] <= t[i])) return false;
     const double s1 = (double)stream_shape(n, n_periods, false).s1;
@@ -3230,7 +3231,7 @@ int pdc_stringlength_scan(const double *t, const double *m, int64_t n, const dou
     PDC_TRY(use_device(device));
     DeviceLock lock(device);
     // (time-ordered samples and periods that all take the slices / one-cycle modes: no lists in the workspace)
-    const bool lists = !host_all_slices(t, n, periods, n_periods);
+    const bool lists = !host_all_slices(t, n, periods, n_periods, stream_min_n());
     const int64_t wb = stringlength_work_bytes(n, n_periods, lists);
     void *d_t, *d_m, *d_p, *d_e, *d_w;
     PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
@@ -3255,15 +3256,34 @@ int64_t pdc_supersmoother_work_bytes(int64_t n, int64_t n_periods) {
     return ss_shape(n, n_periods).total;
 }
 
+}  // extern "C"
+
+namespace {
+int supersmoother_scan_impl(int device, void *stream, const double *d_t, const double *d_y, int64_t n,
+                            const double *d_periods, int64_t n_periods, double alpha, double *d_stat, void *work,
+                            int64_t work_bytes, bool lists);
+}
+
+extern "C" {
+
 int pdc_supersmoother_scan_dev(int device, void *stream, const double *d_t, const double *d_y, int64_t n,
                                const double *d_periods, int64_t n_periods, double alpha, double *d_stat, void *work,
                                int64_t work_bytes) {
+    return supersmoother_scan_impl(device, stream, d_t, d_y, n, d_periods, n_periods, alpha, d_stat, work, work_bytes, true);
+}
+
+}  // extern "C"
+
+namespace {
+int supersmoother_scan_impl(int device, void *stream, const double *d_t, const double *d_y, int64_t n,
+                            const double *d_periods, int64_t n_periods, double alpha, double *d_stat, void *work,
+                            int64_t work_bytes, bool lists) {
     PDC_REQUIRE(d_t && d_y && (d_periods || n_periods == 0) && (d_stat || n_periods == 0), "supersmoother: NULL argument");
     PDC_REQUIRE(n >= 5 && n < ((int64_t)1 << 30), "supersmoother: between 5 and 2^30 samples (the woofer window spans "
                                                   "half the curve)");
     PDC_REQUIRE(n_periods >= 0, "supersmoother: negative size");
     PDC_REQUIRE(alpha >= 0.0 && alpha <= 10.0, "supersmoother: the bass control alpha lies in [0, 10] (0 = off)");
-    const SsShape z = ss_shape(n, n_periods);
+    const SsShape z = ss_shape(n, n_periods, lists);
     PDC_REQUIRE(work && work_bytes >= z.total, "supersmoother: workspace too small (%lld < %lld bytes)",
                 (long long)work_bytes, (long long)z.total);
     if (n_periods == 0) return PDC_OK;
@@ -3279,6 +3299,7 @@ int pdc_supersmoother_scan_dev(int device, void *stream, const double *d_t, cons
         sa = stream_args(z.h, base, d_t, d_y, d_periods, n, nullptr);
         sa.sorted = sorted;
         sa.direct = 0;
+        sa.no_lists = lists ? 0 : 1;
         PDC_TRY(stream_allow_lds(z.h));
     }
     ss::SsSortArgs fa;
@@ -3313,6 +3334,9 @@ int pdc_supersmoother_scan_dev(int device, void *stream, const double *d_t, cons
     }
     return PDC_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const double *periods, int64_t n_periods,
                            double alpha, double *stat_out, int device) {
@@ -3320,7 +3344,9 @@ int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const do
     PDC_REQUIRE(n >= 0 && n_periods >= 0, "supersmoother: negative size");
     PDC_TRY(use_device(device));
     DeviceLock lock(device);
-    const int64_t wb = pdc_supersmoother_work_bytes(n, n_periods);
+    // (time-ordered samples and periods that all take the slices mode: no lists in the workspace, as pdc_stringlength_scan)
+    const bool lists = !host_all_slices(t, n, periods, n_periods, 4096);
+    const int64_t wb = ss_shape(n, n_periods, lists).total;
     void *d_t, *d_y, *d_p, *d_s, *d_w;
     PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
     PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_y));
@@ -3331,8 +3357,8 @@ int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const do
     PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_p, periods, n_periods * 8, hipMemcpyHostToDevice, st));
-    PDC_TRY(pdc_supersmoother_scan_dev(device, st, (double *)d_t, (double *)d_y, n, (double *)d_p, n_periods, alpha,
-                                       (double *)d_s, d_w, wb));
+    PDC_TRY(supersmoother_scan_impl(device, st, (double *)d_t, (double *)d_y, n, (double *)d_p, n_periods, alpha,
+                                    (double *)d_s, d_w, wb, lists));
     PDC_HIP(hipMemcpyAsync(stat_out, d_s, n_periods * 8, hipMemcpyDeviceToHost, st));
     PDC_HIP(hipStreamSynchronize(st));
     return PDC_OK;
