@@ -152,6 +152,11 @@ int pdc_gls_plan_create_loopback(int device, int n_slots, int64_t n_max, int64_t
 /* n_slots; the size RCCL reports for the plan's communicator (ncclCommCount; 0 = no communicator);
  * exchange: 0 none (one slot), 1 RCCL all-gather, 2 device-to-device copies.  Any pointer may be NULL. */
 int pdc_gls_plan_info(void *plan, int *n_slots, int *rccl_ranks, int *exchange);
+/* If ncclCommInitAll failed when the plan was built, the plan does NOT fail: it warns on stderr and exchanges the
+ * slabs by device-to-device copies (peer access enabled where the devices allow it) - exchange == 2 above - and the
+ * reason is kept here (empty string: the communicators were built, or never needed).  PDC_FORCE_RCCL_FAIL=1 injects
+ * the failure (tests, `bench.py --loopback`). */
+int pdc_gls_plan_init_error(void *plan, char *buf, int buf_len);
 int pdc_gls_plan_upload(void *plan, const double *t, const double *y, const double *dy, int64_t n);
 int pdc_gls_plan_scan(void *plan, double f0, double delta, int64_t nf, int fit_mean, int psd);
 int pdc_gls_plan_wait(void *plan);

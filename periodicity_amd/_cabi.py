@@ -52,6 +52,7 @@ PROTOTYPES = {
     "pdc_gls_plan_create": (_I, [_VP, _I, _L, _L, C.POINTER(_VP)]),
     "pdc_gls_plan_create_loopback": (_I, [_I, _I, _L, _L, C.POINTER(_VP)]),
     "pdc_gls_plan_info": (_I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "pdc_gls_plan_init_error": (_I, [_VP, C.c_char_p, _I]),
     "pdc_gls_plan_upload": (_I, [_VP, _VP, _VP, _VP, _L]),
     "pdc_gls_plan_scan": (_I, [_VP, _D, _D, _L, _I, _I]),
     "pdc_gls_plan_wait": (_I, [_VP]),
@@ -311,7 +312,10 @@ class GlsPlan:
         exchange the plan performs ("none", "rccl", "copy")."""
         n, r, x = C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib().pdc_gls_plan_info(self._plan, C.byref(n), C.byref(r), C.byref(x)))
-        return {"n_slots": n.value, "rccl_ranks": r.value, "exchange": ("none", "rccl", "copy")[x.value]}
+        buf = C.create_string_buffer(512)
+        check(lib().pdc_gls_plan_init_error(self._plan, buf, 512))
+        return {"n_slots": n.value, "rccl_ranks": r.value, "exchange": ("none", "rccl", "copy")[x.value],
+                "init_error": buf.value.decode() or None}
 
     def upload(self, t, y, dy=None):
         t, y = _f64(t, "t"), _f64(y, "y")

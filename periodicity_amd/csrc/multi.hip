@@ -116,6 +116,7 @@ struct GlsPlan {
     std::vector<ncclComm_t> comms;
     Exchange exchange = EX_NONE;
     bool loopback = false;
+    std::string init_error;   // why the RCCL communicators could not be built (the plan then exchanges by copies)
     PinBuf stage;        // (t, y, dy) staged once, then copied to every device asynchronously
     int64_t n_cap = 0, slab_cap = 0, work_cap = 0;
     int64_t n = 0, nf = 0, slab = 0;
@@ -128,6 +129,12 @@ struct GlsPlan {
 
 bool force_rccl() {
     static const bool f = [] { const char *e = getenv("PDC_FORCE_RCCL"); return e && e[0] == '1'; }();
+    return f;
+}
+
+// PDC_FORCE_RCCL_FAIL=1: behave as if ncclCommInitAll had failed (exercises the fallback on any box)
+bool force_rccl_fail() {
+    static const bool f = [] { const char *e = getenv("PDC_FORCE_RCCL_FAIL"); return e && e[0] == '1'; }();
     return f;
 }
 
@@ -185,10 +192,38 @@ int plan_build(GlsPlan *p, const int *devices, int n_devices, int64_t n_max, int
     PDC_TRY(ensure(p->stage, 3 * n_max * 8));
     if (loopback || (n_devices > 1 && exchange_by_copy())) {
         p->exchange = n_devices > 1 ? EX_COPY : EX_NONE;
+        if (loopback && force_rccl_fail()) {   // (a 1-GPU box: the injected failure lands where a real one would)
+            p->init_error = "ncclCommInitAll failed: PDC_FORCE_RCCL_FAIL=1 (injected; loopback plan)";
+            fprintf(stderr, "periodicity_hip: WARNING: %s - the plan exchanges slabs by device-to-device copies instead of an RCCL all-gather\n",
+                    p->init_error.c_str());
+        }
     } else if (n_devices > 1 || force_rccl()) {
         p->comms.assign(n_devices, nullptr);
-        PDC_NCCL(ncclCommInitAll(p->comms.data(), n_devices, devices));
-        p->exchange = EX_RCCL;
+        const ncclResult_t rc = force_rccl_fail() ? ncclSystemError : ncclCommInitAll(p->comms.data(), n_devices, devices);
+        if (rc == ncclSuccess) {
+            p->exchange = EX_RCCL;
+        } else {
+            // No communicator: the job must not die for it.  The all-gather is the same data movement as the copy
+            // exchange (slot i pulls slab j from slot j: hipMemcpyPeerAsync over xGMI once peer access is on), so
+            // the plan falls back to that - LOUDLY: stderr here, pdc_gls_plan_init_error / plan_info for the caller.
+            p->init_error = std::string("ncclCommInitAll failed: ") + (force_rccl_fail() ? "PDC_FORCE_RCCL_FAIL=1 (injected)" : ncclGetErrorString(rc));
+            fprintf(stderr, "periodicity_hip: WARNING: %s - the plan exchanges slabs by device-to-device copies instead of an RCCL all-gather\n",
+                    p->init_error.c_str());
+            for (ncclComm_t &c : p->comms) c = nullptr;
+            p->comms.clear();
+            for (int i = 0; i < n_devices; ++i)
+                for (int j = 0; j < n_devices; ++j) {
+                    if (devices[i] == devices[j]) continue;
+                    int can = 0;
+                    PDC_HIP(hipDeviceCanAccessPeer(&can, devices[i], devices[j]));
+                    if (!can) continue;                       // (hipMemcpyPeerAsync then stages through the host)
+                    PDC_TRY(use_device(devices[i]));
+                    const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) PDC_HIP(e);
+                    (void)hipGetLastError();
+                }
+            p->exchange = n_devices > 1 ? EX_COPY : EX_NONE;
+        }
     }
     return PDC_OK;
 }
@@ -362,6 +397,14 @@ int pdc_gls_plan_info(void *plan, int *n_slots, int *rccl_ranks, int *exchange) 
         *rccl_ranks = 0;
         if (!p->comms.empty()) PDC_NCCL(ncclCommCount(p->comms[0], rccl_ranks));
     }
+    return PDC_OK;
+}
+
+int pdc_gls_plan_init_error(void *plan, char *buf, int buf_len) {
+    PDC_REQUIRE(plan && buf && buf_len > 0, "gls_plan_init_error: NULL argument");
+    GlsPlan *p = static_cast<GlsPlan *>(plan);
+    std::lock_guard<std::mutex> lk(p->mu);
+    snprintf(buf, (size_t)buf_len, "%s", p->init_error.c_str());
     return PDC_OK;
 }
 

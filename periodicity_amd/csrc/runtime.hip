@@ -100,6 +100,7 @@ struct StreamScratch {
     void *buf;
     int64_t cap;
     int pins;   // callers between stream_scratch() and stream_scratch_done(): their launches are not enqueued yet
+    std::vector<void *> retired;   // blocks outgrown while pinned: freed when the last of those callers is done
 };
 static std::mutex g_scratch_mutex;
 static std::vector<StreamScratch> g_scratch;   // least recently used entry first
@@ -109,11 +110,12 @@ constexpr size_t kScratchPerDevice = 64;
 static int free_scratch_entry(size_t i) {
     StreamScratch s = g_scratch[i];
     g_scratch.erase(g_scratch.begin() + (long)i);
-    if (s.buf) {
+    if (s.buf || !s.retired.empty()) {
         int now = -1;
         PDC_HIP(hipGetDevice(&now));
         PDC_HIP(hipSetDevice(s.device));
-        PDC_HIP(hipFree(s.buf));
+        if (s.buf) PDC_HIP(hipFree(s.buf));
+        for (void *r : s.retired) PDC_HIP(hipFree(r));
         PDC_HIP(hipSetDevice(now));
     }
     return PDC_OK;
@@ -149,7 +151,7 @@ int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
                 ++i;
             }
         }
-        g_scratch.push_back({device, stream, nullptr, 0, 0});
+        g_scratch.push_back({device, stream, nullptr, 0, 0, {}});
     } else if (at + 1 != g_scratch.size()) {   // a hit moves to the back: true LRU order
         const StreamScratch hit = g_scratch[at];
         g_scratch.erase(g_scratch.begin() + (long)at);
@@ -157,7 +159,15 @@ int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
     }
     StreamScratch *e = &g_scratch.back();
     if (e->cap < bytes) {
-        if (e->buf) PDC_HIP(hipFree(e->buf));   // (synchronises the device: no kernel still uses it)
+        // Another thread on the same (device, stream) may hold the block pinned with its launches not enqueued yet:
+        // hipFree's device synchronisation cannot protect launches that do not exist yet, so a pinned block is only
+        // RETIRED here and freed by the stream_scratch_done() that brings the pins back to zero.
+        if (e->buf) {
+            if (e->pins > 0)
+                e->retired.push_back(e->buf);
+            else
+                PDC_HIP(hipFree(e->buf));       // (synchronises the device: no kernel still uses it)
+        }
         e->buf = nullptr;
         e->cap = 0;
         const int64_t want = bytes + bytes / 4;
@@ -172,7 +182,26 @@ int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
 void stream_scratch_done(int device, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_scratch_mutex);
     for (StreamScratch &e : g_scratch)
-        if (e.device == device && e.stream == stream && e.pins > 0) --e.pins;
+        if (e.device == device && e.stream == stream && e.pins > 0) {
+            --e.pins;
+            if (e.pins == 0 && !e.retired.empty()) {
+                // every caller that could hold an outgrown block has enqueued its launches: hipFree waits for them
+                int now = -1;
+                if (hipGetDevice(&now) == hipSuccess && hipSetDevice(e.device) == hipSuccess) {
+                    for (void *r : e.retired) (void)hipFree(r);
+                    (void)hipSetDevice(now);
+                }
+                e.retired.clear();
+            }
+        }
+}
+
+// (tests) blocks retired but not yet freed, over all entries
+int64_t stream_scratch_retired() {
+    std::lock_guard<std::mutex> lk(g_scratch_mutex);
+    int64_t c = 0;
+    for (const StreamScratch &e : g_scratch) c += (int64_t)e.retired.size();
+    return c;
 }
 
 int drop_stream_scratch(int device, hipStream_t stream) {
@@ -185,9 +214,11 @@ int drop_stream_scratch(int device, hipStream_t stream) {
 static int release_stream_scratch() {
     std::lock_guard<std::mutex> lk(g_scratch_mutex);
     for (StreamScratch &s : g_scratch) {
-        if (!s.buf) continue;
+        if (!s.buf && s.retired.empty()) continue;
         PDC_HIP(hipSetDevice(s.device));
-        PDC_HIP(hipFree(s.buf));
+        if (s.buf) PDC_HIP(hipFree(s.buf));
+        for (void *r : s.retired) PDC_HIP(hipFree(r));
+        s.retired.clear();
         s.buf = nullptr;
         s.cap = 0;
     }

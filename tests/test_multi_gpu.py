@@ -274,6 +274,76 @@ def test_scratch_table_never_frees_a_block_in_use():
         b.free()
 
 
+def test_scratch_regrow_never_frees_a_pinned_block():
+    """when a (device, stream) entry must grow while another host thread still holds the old block pinned
+    (its launches not enqueued yet), the old block is RETIRED and freed only when the pins are back to zero.
+    Deterministic leg: the library's internal table driven directly (C++ symbols of the .so, no public entry) - pin a
+    small block, ask for a larger one on the same stream, the first block must still be writable device memory and
+    counted as retired until both callers are done.  Threaded leg: two host threads on ONE stream, one with a short
+    period grid, one whose grids keep growing, every result equal to the single-thread one."""
+    import threading
+    lib = _cabi.lib()
+    scratch = getattr(lib, "_ZN3pdc14stream_scratchEiP12ihipStream_tlPPv")
+    done = getattr(lib, "_ZN3pdc19stream_scratch_doneEiP12ihipStream_t")
+    retired = getattr(lib, "_ZN3pdc22stream_scratch_retiredEv")
+    scratch.argtypes, scratch.restype = [C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)], C.c_int
+    done.argtypes, done.restype = [C.c_int, C.c_void_p], None
+    retired.argtypes, retired.restype = [], C.c_int64
+    s = C.c_void_p()
+    _cabi.check(lib.pdc_stream_create(0, C.byref(s)))
+    a, b = C.c_void_p(), C.c_void_p()
+    _cabi.check(scratch(0, s, 1 << 20, C.byref(a)))            # caller 1: pinned, nothing enqueued yet
+    _cabi.check(scratch(0, s, 64 << 20, C.byref(b)))           # caller 2 outgrows the block
+    assert a.value != b.value and retired() == 1
+    host = np.arange(1 << 17, dtype=np.float64)                # caller 1 now uses ITS block: still valid memory
+    _cabi.check(lib.pdc_memcpy_h2d(0, a, host.ctypes.data_as(C.c_void_p), host.nbytes))
+    back = np.empty_like(host)
+    _cabi.check(lib.pdc_memcpy_d2h(0, back.ctypes.data_as(C.c_void_p), a, host.nbytes))
+    assert np.array_equal(back, host)
+    done(0, s)
+    assert retired() == 1                                      # one caller is still out
+    done(0, s)
+    assert retired() == 0
+    _cabi.check(lib.pdc_stream_destroy(0, s))
+
+    t, x, _ = phase_inputs(60_000, 9)
+    sigma = float(np.var(x, ddof=1))
+    bt, bx = _cabi.DeviceBuffer.from_array(t), _cabi.DeviceBuffer.from_array(x)
+    grids = [np.linspace(0.7, 30.0, k) for k in (24, 32, 48, 64, 96, 128, 160, 192)]   # split mode: scratch grows with the grid
+    want = [_cabi.pdm_scan(t, x, g, 5, 2, sigma) for g in grids]
+    s = C.c_void_p()
+    _cabi.check(lib.pdc_stream_create(0, C.byref(s)))
+    bad = []
+
+    def run(order, rounds):
+        try:
+            bufs = [(_cabi.DeviceBuffer.from_array(grids[k]), _cabi.DeviceBuffer(grids[k].size * 8)) for k in order]
+            for _ in range(rounds):
+                for k, (bp, bo) in zip(order, bufs):
+                    _cabi.check(lib.pdc_pdm_scan_dev(0, s, bt.ptr, bx.ptr, t.size, bp.ptr, grids[k].size, 5, 2, sigma, bo.ptr))
+                    _cabi.check(lib.pdc_stream_sync(0, s))
+                    if not np.array_equal(bo.to_array(np.float64, grids[k].size), want[k]):
+                        bad.append(k)
+            for bp, bo in bufs:
+                bp.free()
+                bo.free()
+        except Exception as exc:                              # pragma: no cover
+            bad.append(exc)
+    for trial in range(6):
+        _cabi.check(lib.pdc_stream_destroy(0, s))             # (drops the entry: the next trial regrows from nothing)
+        _cabi.check(lib.pdc_stream_create(0, C.byref(s)))
+        threads = [threading.Thread(target=run, args=([0], 40)), threading.Thread(target=run, args=(list(range(8)), 2))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    assert not bad, bad
+    assert retired() == 0
+    _cabi.check(lib.pdc_stream_destroy(0, s))
+    bt.free()
+    bx.free()
+
+
 def test_cond_entropy_dev_entry_ignores_out_of_range_bins():
     """the kernel used the caller's double as an LDS index unchecked.  Through the `_dev` entry
     a NaN / negative / too large magnitude bin now counts nowhere (as if the sample were absent); the host

@@ -288,6 +288,40 @@ def test_streamed_stringlength_slices_mode_at_its_own_sizes(tmp_path):
         assert np.array_equal(runs[0][spec], runs[2][spec]), spec
 
 
+def _sl_oracle_full(specs, **env):
+    """tools/sl_oracle_full.py in a child process (the library reads its PDC_SL_* switches once per process): EVERY
+    period of the reference's grid against the C oracle (OpenMP over periods: seconds on the GPU box's host)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "sl_oracle_full.py"), *specs],
+                         env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=1700)
+    print(out.stdout)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1].startswith("ok"), out.stdout[-2500:] + out.stderr[-2500:]
+
+
+@pytest.mark.parametrize("slices", ["1", "0"])
+def test_streamed_stringlength_every_period_against_the_oracle_at_its_own_sizes(slices):
+    """The round-4 streamed family where it actually runs - 300 000 x 4096 and 1 000 000 x 384 (a full batch of 384
+    periods), ALL periods against the oracle, not a sample of three: slices mode (default) and lists mode
+    (PDC_SL_SLICES=0).  phase.py:45-51 + core.py:473-477,543-544."""
+    _sl_oracle_full(["300000x4096", "1000000x384"], PDC_SL_SLICES=slices)
+
+
+@pytest.mark.parametrize("groups", ["1", "2", "4"])
+def test_streamed_stringlength_full_batches_per_group_count(groups):
+    """The shape of the race fixed in 597cf50 (one period in thousands wrong at batches of 320+ periods): a batch of
+    384 periods for every group count of the histogram / boundary / partition kernels, every period against the
+    oracle; duplicates + gaps + a negative start, a Julian-date offset, and a grid of short periods (lists mode for
+    time-ordered samples), all at N >= 262 144."""
+    _sl_oracle_full(["262144x384", "300000x384d", "280000x352o", "270000x384s", "262144x320ds"], PDC_SL_STREAM_GROUPS=groups)
+
+
+def test_several_slice_stringlength_every_period_against_the_oracle():
+    """The several-slice instances of sl_fast_kernel (52 112 < N < 262 144; 16-bit indices + bit planes): all periods."""
+    _sl_oracle_full(["74326x2048", "131000x1024d", "200000x1024o", "261000x512"])
+
+
 def test_stringlength_periods_that_outlast_the_samples():
     """p > baseline: the samples span less than one cycle, their phase order is their time order (or, across a cycle
     boundary, the later samples first) and no kernel sorts anything (onecycle::* / sl_direct_kernel).  Julian-date

@@ -58,6 +58,28 @@ def test_supersmoother_scan_matches_the_oracle(n, even, alpha):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [50_000, 74_326, 200_000])
+def test_supersmoother_scan_matches_the_oracle_at_the_sizes_it_runs(n):
+    """N = 5e4 is bench.py's shape, 74 326 the reference's SunSpots curve, 2e5 the class the workspace is sized for:
+    ten periods each - a commensurate (tied phases) one on an evenly sampled copy, periods beyond the baseline, the
+    bass control on - against the oracle's long-double window sums.  The observed error is printed per N so that the
+    trend with N (the device forms windows from fp64 running sums) is on record."""
+    worst = {}
+    for even, alpha in ((False, 0.0), (False, 6.0), (True, 0.0)):
+        t, y = curve(n, n + 7, even)
+        periods = np.array([0.61, 2.1, 7.3, 10.0, 25.0, 33.3, 0.013 * t[-1], 0.31 * t[-1], 1.7 * t[-1], 12.0 * t[-1]])
+        if even and n > 60_000:
+            periods = periods[[1, 3, 6, 8]]        # (long tied runs are one oracle loop each: keep the CPU leg short)
+        got = _cabi.supersmoother_scan(t, y, periods, alpha)
+        want = so.supersmoother_scan(t, y, periods, alpha)
+        rel = np.abs(got - want) / np.abs(want)
+        worst[(even, alpha)] = float(rel.max())
+        np.testing.assert_allclose(got, want, rtol=RTOL)
+        assert np.array_equal(got, _cabi.supersmoother_scan(t, y, periods, alpha))
+    print(f"supersmoother N={n}: max rel err vs oracle " + ", ".join(f"even={e} alpha={a}: {v:.2e}" for (e, a), v in worst.items()))
+
+
+@pytest.mark.gpu
 def test_supersmoother_class_finds_the_period_and_edges():
     t, y = curve(6000, 11)
     res = SuperSmoother(p_min=5.0, p_max=10.0, n_periods=201)(TSeries(t, y))
