@@ -701,7 +701,7 @@ def sharded_extras_one_process(cabi, lib, devices):
     return out
 
 
-def sharded_extras_dist(cabi, lib, torch, dist, dev, rank, world):
+def sharded_extras_dist(cabi, lib, torch, dist, dev, rank, world, coll):
     """One rank per GPU (torch.distributed): this rank takes slab `rank` of C5's period grid / group `rank`
     of C3's curves; kernel time = HIP events on this rank, MAX over ranks; end to end = barrier-to-barrier
     wall of host-buffer calls + the all-gather of the results, MAX over ranks."""
@@ -712,10 +712,7 @@ def sharded_extras_dist(cabi, lib, torch, dist, dev, rank, world):
     stream = s.value
     tm = EventTimer(lib, cabi, dev, stream)
 
-    def max_over_ranks(x):
-        v = torch.tensor([x], dtype=torch.float64, device="cuda")
-        dist.all_reduce(v, op=dist.ReduceOp.MAX)
-        return float(v.item())
+    max_over_ranks = coll.max
 
     def end_to_end(fn):
         fn()
@@ -780,7 +777,7 @@ def sharded_extras_dist(cabi, lib, torch, dist, dev, rank, world):
         send = torch.zeros(per, dtype=torch.float64, device="cuda")
         send[:nb] = torch.from_numpy(a).cuda()
         full = torch.empty(per * world, dtype=torch.float64, device="cuda")
-        dist.all_gather_into_tensor(full, send)
+        coll.gather_into(full, send)
         return full[:B].cpu().numpy()
     e2e, got = end_to_end(c3_host)
     pairs3 = float(B) * ns * nf
@@ -893,7 +890,8 @@ def strong_scaling_one_process(cabi, devices, loopback):
             loopN["speedup_vs_1gpu"] = round(loop1["ms_per_step"] / loopN["ms_per_step"], 3)
         out[key] = strong_entry(
             key, n, nf, slots, kN, sgN, eN, one, loopN, pN, p1,
-            {"ranks_in_communicator": info["rccl_ranks"], "exchange": info["exchange"], "slots": info["n_slots"]},
+            {"ranks_in_communicator": info["rccl_ranks"], "exchange": info["exchange"], "slots": info["n_slots"],
+             "init_error": info.get("init_error")},
             loopback,
             "one process, N devices (pdc_gls_plan_*); kernel = HIP events around every slot's slab scan, the slowest; "
             "scan_plus_gather = enqueue to all streams drained, wall; end to end = upload of (t, y, dy) to every "
@@ -903,7 +901,7 @@ def strong_scaling_one_process(cabi, devices, loopback):
     return out
 
 
-def strong_scaling_dist(cabi, lib, torch, dist, dev, rank, world):
+def strong_scaling_dist(cabi, lib, torch, dist, dev, rank, world, coll):
     """One rank per GPU: rank r scans slab r of the fixed grid, all_gather_into_tensor (RCCL), rank 0 brings the
     whole array to the host.  Times are barrier to barrier, MAX over ranks; one_gpu = the whole grid on rank 0
     alone while the others wait."""
@@ -912,10 +910,7 @@ def strong_scaling_dist(cabi, lib, torch, dist, dev, rank, world):
     stream = torch.cuda.current_stream().cuda_stream
     tm = EventTimer(lib, cabi, dev, stream)
 
-    def max_over_ranks(x):
-        v = torch.tensor([x], dtype=torch.float64, device="cuda")
-        dist.all_reduce(v, op=dist.ReduceOp.MAX)
-        return float(v.item())
+    max_over_ranks = coll.max
 
     def timed(fn):
         torch.cuda.synchronize()
@@ -952,7 +947,7 @@ def strong_scaling_dist(cabi, lib, torch, dist, dev, rank, world):
 
         def scan_gather():
             slab_scan()
-            dist.all_gather_into_tensor(full, send)
+            coll.gather_into(full, send)
 
         def end_to_end():
             dev_in[0] = torch.from_numpy(host).cuda()
@@ -961,9 +956,7 @@ def strong_scaling_dist(cabi, lib, torch, dist, dev, rank, world):
 
         scan(b0, min(cnt, 200_000), send.data_ptr(), work.ptr, wb)          # clocks up
         k_ms = max_over_ranks(tm.ms(slab_scan, reps=1, warm=0))
-        mine = torch.tensor([tm.ms(slab_scan, reps=1, warm=0)], dtype=torch.float64, device="cuda")
-        all_ms = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(all_ms, mine)
+        all_ms = coll.all_scalars(tm.ms(slab_scan, reps=1, warm=0))
         sg, _ = timed(scan_gather)
         e2e, power = timed(end_to_end)
         loop = None
@@ -1013,9 +1006,8 @@ def strong_scaling_dist(cabi, lib, torch, dist, dev, rank, world):
         dist.barrier()
         if rank == 0:
             out[key] = strong_entry(
-                key, n, nf, world, [float(v.item()) for v in all_ms], sg, e2e, one, loop, power, power_one,
-                {"ranks_in_communicator": dist.get_world_size(),
-                 "exchange": f"rccl (torch.distributed, backend {dist.get_backend()})", "slots": world},
+                key, n, nf, world, all_ms, sg, e2e, one, loop, power, power_one,
+                {"ranks_in_communicator": dist.get_world_size(), "exchange": coll.describe(), "slots": world},
                 False,
                 "one rank per GPU (torch.distributed); kernel = HIP events around this rank's slab scan, every rank's "
                 "listed; scan_plus_gather / end to end = barrier to barrier, MAX over ranks; end to end = H2D of "
@@ -1025,6 +1017,93 @@ def strong_scaling_dist(cabi, lib, torch, dist, dev, rank, world):
         work.free()
         del send, full, dev_in
     return out
+
+
+def clock_probe(lib, cabi, dev, stream, iters=10_000, reps=3):
+    """The clock this box sustains under fp64 load, measured in THIS run right after the timed steps: a fixed count
+    of v_fma_f64 (pdc_clock_probe: 16 independent chains per lane, 4 waves on every SIMD) / HIP-event time, at 4 issue
+    cycles per wave64 instruction.  A 26.3-vs-28.3 ms swing of the same kernel between two boxes of the pool is then
+    attributable from the line itself (the chip is power-limited under fp64 load: 2.04-2.13 GHz seen, nominal 2.4)."""
+    ghz, ratios, all_ms = [], [], []
+    for _ in range(reps):
+        ms, wi, ratio = C.c_float(), C.c_double(), C.c_double()
+        cabi.check(lib.pdc_clock_probe(dev, stream, iters, C.byref(ms), C.byref(wi), C.byref(ratio)))
+        ghz.append(wi.value * FP64_ISSUE_CYCLES / (ms.value * 1e-3) / 1e9)
+        ratios.append(ratio.value)
+        all_ms.append(round(ms.value, 4))
+    return {"effective_clock_GHz": round(float(np.median(ghz)), 4), "probe_ms": all_ms,
+            "fma_wave_instr_per_simd": 4.0 * iters * 128.0,
+            "s_memtime_ticks_per_100MHz_tick": round(float(np.median(ratios)), 4),
+            "note": "fixed-instruction-count fp64 fma spin (pdc_clock_probe) run right after the timed steps: "
+                    "wave-instructions per SIMD x 4 cycles / HIP-event time, median of 3; a LOWER bound of the clock "
+                    "(it assumes the fmas issue back to back)"}
+
+
+class Coll:
+    """The few collectives bench.py needs, on whichever backend init_dist() got: device tensors over RCCL ("nccl"),
+    or - the loud fallback - host tensors over gloo."""
+
+    def __init__(self, torch, dist, backend):
+        self.torch, self.dist, self.backend = torch, dist, backend
+        self.where = "cuda" if backend == "nccl" else "cpu"
+
+    def max(self, x):
+        v = self.torch.tensor([x], dtype=self.torch.float64, device=self.where)
+        self.dist.all_reduce(v, op=self.dist.ReduceOp.MAX)
+        return float(v.item())
+
+    def all_scalars(self, x):
+        mine = self.torch.tensor([x], dtype=self.torch.float64, device=self.where)
+        got = [self.torch.zeros_like(mine) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(got, mine)
+        return [float(v.item()) for v in got]
+
+    def gather_into(self, full, send, async_op=False):
+        """all_gather_into_tensor of device tensors; through the host under gloo (synchronous there)."""
+        if self.backend == "nccl":
+            return self.dist.all_gather_into_tensor(full, send, async_op=async_op)
+        host = self.torch.empty(full.numel(), dtype=full.dtype)
+        self.dist.all_gather_into_tensor(host, send.cpu())
+        full.copy_(host)
+        return None
+
+    def describe(self):
+        if self.backend == "nccl":
+            return f"rccl (torch.distributed, backend {self.dist.get_backend()})"
+        return "FALLBACK: gloo through host memory (the RCCL process group could not be built)"
+
+
+def init_dist(torch, dist, local_rank):
+    """torch.distributed over RCCL (backend "nccl"); if the communicator cannot be built - or its first collective
+    fails - every rank falls back, LOUDLY, to gloo: the barrier / max-over-ranks timing and the all-gather of the
+    power array then go through host memory, the line says so (`rccl.exchange`, `rccl.init_error`), and the run
+    still prints its headline instead of dying with rc != 0.  Returns (backend, error or None)."""
+    err = None
+    if os.environ.get("PDC_FORCE_RCCL_FAIL") == "1":
+        err = "PDC_FORCE_RCCL_FAIL=1 (injected)"
+    elif not torch.cuda.is_available():
+        err = "torch.cuda.is_available() is False"
+    else:
+        try:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != dist.get_world_size():
+                raise RuntimeError(f"all_reduce probe returned {probe.item()} on {dist.get_world_size()} ranks")
+            return "nccl", None
+        except Exception as exc:
+            err = f"{type(exc).__name__}: {exc}"[:400]
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:
+                pass
+    sys.stderr.write(f"bench.py: WARNING: RCCL process group unavailable ({err}); falling back to gloo - the power "
+                     "array is gathered through host memory\n")
+    dist.init_process_group(backend="gloo")
+    return "gloo", err
 
 
 def main():
@@ -1064,6 +1143,7 @@ def main():
     n_slots = loopback if loopback else n_gpus          # slabs of the grid
 
     torch = dist = None
+    dist_backend, dist_error = None, None
     if dist_mode:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -1072,8 +1152,10 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist_backend, dist_error = init_dist(torch, dist, local_rank)
+        coll = Coll(torch, dist, dist_backend)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
 
     from periodicity_amd import _cabi
     lib = _cabi.lib()
@@ -1151,7 +1233,7 @@ def main():
         if ev:
             _cabi.check(lib.pdc_event_record(dev, ev[1], stream))
         if dist_mode:
-            pending[g] = dist.all_gather_into_tensor(powers[g], slabs[g], async_op=True)
+            pending[g] = coll.gather_into(powers[g], slabs[g], async_op=True)
             counter[0] += 1
 
     def drain():
@@ -1186,9 +1268,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist_mode:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = coll.max(elapsed)
+
+    # same-run clock evidence: what this box sustains under fp64 load, right after the timed steps
+    try:
+        clock = clock_probe(lib, _cabi, dev, None if plan_mode else stream)
+    except Exception as exc:
+        clock = {"effective_clock_GHz": None, "error": f"{type(exc).__name__}: {exc}"}
 
     if plan_mode:
         # kernel time of one slab scan on device 0, measured outside the timed region (the plan keeps
@@ -1219,7 +1305,7 @@ def main():
         # exception raised before a collective is raised on all of them)
         try:
             if dist_mode:
-                sharded = sharded_extras_dist(_cabi, lib, torch, dist, dev, rank, world)
+                sharded = sharded_extras_dist(_cabi, lib, torch, dist, dev, rank, world, coll)
             else:
                 sharded = sharded_extras_one_process(_cabi, lib, [0] * loopback if loopback else list(range(args.gpus)))
         except Exception as exc:
@@ -1228,7 +1314,7 @@ def main():
         # grid cut N ways, against one slot of the same run
         try:
             if dist_mode:
-                strong = strong_scaling_dist(_cabi, lib, torch, dist, dev, rank, world)
+                strong = strong_scaling_dist(_cabi, lib, torch, dist, dev, rank, world, coll)
             else:
                 strong = strong_scaling_one_process(_cabi, [0] * loopback if loopback else list(range(args.gpus)),
                                                     bool(loopback))
@@ -1289,6 +1375,10 @@ def main():
                          "kernel_ms": round(kernel_ms_now, 4),
                          "kernel_ms_is": "median of the HIP-event times of the timed steps",
                          "kernel_ms_all": kernel_all_ms,
+                         "effective_clock_GHz": clock.get("effective_clock_GHz"),
+                         "frac_at_effective_clock": None if (frac is None or not clock.get("effective_clock_GHz"))
+                         else round(frac * (CLOCK_HZ / 1e9) / clock["effective_clock_GHz"], 4),
+                         "clock_probe": clock,
                          **fr,
                          "valu_issue": blk,
                          "algorithmic": {"flop_per_pair": FLOP_PER_PAIR,
@@ -1310,17 +1400,28 @@ def main():
         }
         if plan_mode:
             out["rccl"] = {"ranks_in_communicator": plan_info["rccl_ranks"], "exchange": plan_info["exchange"],
-                           "slots": plan_info["n_slots"]}
+                           "slots": plan_info["n_slots"], "init_error": plan_info.get("init_error")}
             out["end_to_end_sharded"] = {
                 "ms": round(end_to_end_s * 1e3, 3),
                 "Gpair_per_s": round(pairs_per_step / end_to_end_s / 1e9, 1),
                 "note": "H2D of (t, y, dy) to every device + slab scans + all-gather + D2H of power[nf] "
                         "from device 0, wall clock (the shape of pdc_gls_scan_multi / GLS(devices=...))"}
         if dist_mode:
-            out["rccl"] = {"ranks_in_communicator": dist.get_world_size(),
-                           "exchange": f"rccl (torch.distributed, backend {dist.get_backend()})", "slots": world}
+            out["rccl"] = {"ranks_in_communicator": dist.get_world_size(), "exchange": coll.describe(), "slots": world,
+                           "init_error": dist_error}
         if sharded is not None:
             out["extras"] = sharded
+            c4 = sharded.get("c4_sharded") if isinstance(sharded, dict) else None
+            if isinstance(c4, dict) and "speedup_vs_1gpu" in c4:
+                # `value` above is WEAK-scaled (C2 per GPU); the north star's ">= 6x at 8 GPUs" is THIS figure
+                out["strong_scaling"] = dict(c4["speedup_vs_1gpu"], config="BASELINE configs[3]: N=1e6 x nf=1e7, fixed total work",
+                                             slots=c4["slots"], end_to_end_ms=c4["end_to_end_ms"],
+                                             one_gpu_end_to_end_ms=c4["one_gpu"]["end_to_end_ms"],
+                                             note="copy of extras.c4_sharded.speedup_vs_1gpu: strong scaling of the fixed C4 "
+                                                  "workload against one slot of the same run" + ("; LOOPBACK: ~1 by construction"
+                                                                                                    if loopback else ""))
+            else:
+                out["strong_scaling"] = None
         if n_slots == 1 and not dist_mode and not plan_mode:
             # informational: the reference's own algorithm on the device (Tier F), same workload
             wb = lib.pdc_gls_fft_work_bytes(n, nf_total)

@@ -64,6 +64,12 @@ int pdc_event_create(int device, void **event);
 int pdc_event_destroy(int device, void *event);
 int pdc_event_record(int device, void *event, void *stream);
 int pdc_event_elapsed_ms(int device, void *start, void *stop, float *ms);  /* syncs on stop */
+/* Measurement aid (no counterpart upstream): a fixed count of fp64 fmas, 16 independent chains per lane, 4 waves on
+ * every SIMD of the device, timed with HIP events on `stream`.  *wave_instr_per_simd x 4 cycles / *ms = the clock the
+ * chip sustains under fp64 load right now (it is power-limited there), the figure bench.py prints beside the
+ * headline so that a box-to-box difference of the same kernel can be attributed; *memtime_ratio = s_memtime ticks
+ * per s_memrealtime tick (100 MHz) over one wave's loop.  iters ~ 10 000 runs about 10 ms. */
+int pdc_clock_probe(int device, void *stream, int iters, float *ms, double *wave_instr_per_simd, double *memtime_ratio);
 
 /* ---- generalized Lomb-Scargle --------------------------------------------------------------
  * Replaces GLS.__call__ from the weights onward (spectral.py:99-132): w = dy^-2 / sum(dy^-2)

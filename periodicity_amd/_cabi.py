@@ -41,6 +41,7 @@ PROTOTYPES = {
     "pdc_event_destroy": (_I, [_I, _VP]),
     "pdc_event_record": (_I, [_I, _VP, _VP]),
     "pdc_event_elapsed_ms": (_I, [_I, _VP, _VP, C.POINTER(C.c_float)]),
+    "pdc_clock_probe": (_I, [_I, _VP, _I, C.POINTER(C.c_float), C.POINTER(_D), C.POINTER(_D)]),
     "pdc_gls_scan": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _L, _I, _I, _VP, _I]),
     "pdc_gls_scan_batch": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _L, _I, _I,
                                 _VP, _VP, _VP, _I]),

@@ -256,6 +256,42 @@ DeviceLock::~DeviceLock() {
     if (device >= 0 && device < (int)g_devices.size()) g_devices[device]->call_mutex.unlock();
 }
 
+
+// ---- clock probe ------------------------------------------------------------------------------------------------
+// A fixed count of fp64 fmas with nothing else in the way: 16 independent chains per lane, 4 waves per SIMD (1024
+// workgroups of 256 threads, 40 KB of LDS each so that a CU takes exactly four).  fp64 fma = 4 issue cycles per
+// wave64 instruction, so  wave-instructions per SIMD x 4 / HIP-event time  = the clock the chip SUSTAINS under fp64
+// load on this box, in this minute (the chip is power-limited there: 2.04-2.13 GHz seen across the pool against the
+// nominal 2.4).  One wave also reads s_memtime / s_memrealtime around its loop (shader clock against the 100 MHz
+// reference clock).
+__global__ __launch_bounds__(256) void clock_probe_kernel(double *out, unsigned long long *stamps, double a, double b, int iters) {
+    extern __shared__ double probe_lds[];
+    double x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) x[c] = threadIdx.x * 1e-3 + c;
+    unsigned long long c0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        c0 = __builtin_readcyclecounter();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = __builtin_fma(x[c], a, b);
+        }
+    }
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += x[c];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        stamps[0] = __builtin_readcyclecounter() - c0;
+        stamps[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
+    if (s == 12345.678) probe_lds[threadIdx.x] = s;   // (never: keeps the LDS allocation alive)
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 }  // namespace pdc
 
 using namespace pdc;
@@ -408,6 +444,40 @@ int pdc_event_elapsed_ms(int device, void *start, void *stop, float *ms) {
     PDC_HIP(hipEventSynchronize((hipEvent_t)stop));
     PDC_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return PDC_OK;
+}
+
+int pdc_clock_probe(int device, void *stream, int iters, float *ms, double *wave_instr_per_simd, double *memtime_ratio) {
+    PDC_REQUIRE(ms && iters > 0 && iters <= 1000000, "pdc_clock_probe: bad argument");
+    PDC_TRY(use_device(device));
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int kBlocks = 1024, kLds = 40 * 1024;
+    void *buf = nullptr;
+    PDC_HIP(hipMalloc(&buf, (size_t)kBlocks * 256 * 8 + 64));
+    unsigned long long *stamps = (unsigned long long *)((char *)buf + (size_t)kBlocks * 256 * 8);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = PDC_OK;
+    auto body = [&]() -> int {
+        PDC_TRY(allow_dynamic_lds((const void *)clock_probe_kernel, kLds));
+        PDC_HIP(hipEventCreate(&e0));
+        PDC_HIP(hipEventCreate(&e1));
+        clock_probe_kernel<<<kBlocks, 256, kLds, st>>>((double *)buf, stamps, 0.999999, 1e-9, 64);   // (code object loaded)
+        PDC_HIP(hipEventRecord(e0, st));
+        clock_probe_kernel<<<kBlocks, 256, kLds, st>>>((double *)buf, stamps, 0.999999, 1e-9, iters);
+        PDC_HIP(hipEventRecord(e1, st));
+        PDC_HIP(hipEventSynchronize(e1));
+        PDC_HIP(hipEventElapsedTime(ms, e0, e1));
+        unsigned long long h[2] = {0, 0};
+        PDC_HIP(hipMemcpy(h, stamps, 16, hipMemcpyDeviceToHost));
+        // 4 waves per SIMD, each iters x 8 x 16 fmas
+        if (wave_instr_per_simd) *wave_instr_per_simd = 4.0 * (double)iters * 128.0;
+        if (memtime_ratio) *memtime_ratio = h[1] ? (double)h[0] / (double)h[1] : 0.0;
+        return PDC_OK;
+    };
+    rc = body();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    return rc;
 }
 
 }  // extern "C"

@@ -87,3 +87,39 @@ def test_two_rank_gloo_allgather_reassembles_the_spectrum(tmp_path, n_grid):
         b, e, _ = slab_bounds(n_grid, world, rank)
         assert np.load(tmp_path / f"calls{rank}.npy").tolist() == [[b, e - b]]
         assert np.array_equal(np.load(tmp_path / f"theta{rank}.npy"), np.load(tmp_path / "theta_want.npy"))
+
+
+def _fallback_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    backend, err = bench.init_dist(torch, dist, rank)           # no GPU here: the RCCL group cannot be built
+    coll = bench.Coll(torch, dist, backend)
+    send = torch.full((5,), float(rank + 1), dtype=torch.float64)
+    full = torch.empty(5 * world, dtype=torch.float64)
+    assert coll.gather_into(full, send, async_op=True) is None
+    worst = coll.max(float(rank))
+    every = coll.all_scalars(10.0 + rank)
+    dist.barrier()
+    np.save(os.path.join(out_dir, f"fb{rank}.npy"), full.numpy())
+    with open(os.path.join(out_dir, f"fb{rank}.txt"), "w") as f:
+        f.write(f"{backend}|{err}|{worst}|{every}|{coll.describe()}")
+    dist.destroy_process_group()
+
+
+def test_bench_falls_back_to_gloo_loudly_when_the_rccl_group_cannot_be_built(tmp_path):
+    """the first real multi-GPU run must not come back empty.  bench.init_dist() tries RCCL and,
+    when that fails (here: no GPU at all), re-initialises the process group on gloo; the collectives bench.py uses
+    (max over ranks, all-gather of the slabs, per-rank scalars) then go through host memory and the line records why."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_fallback_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        got = np.load(tmp_path / f"fb{rank}.npy")
+        assert got.tolist() == [1.0] * 5 + [2.0] * 5
+        backend, err, worst, every, what = open(tmp_path / f"fb{rank}.txt").read().split("|")
+        assert backend == "gloo" and err != "None" and float(worst) == 1.0 and every == "[10.0, 11.0]"
+        assert what.startswith("FALLBACK")

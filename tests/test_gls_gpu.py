@@ -314,6 +314,20 @@ def test_rccl_all_gather_path_on_one_device():
     assert "all-gather equal: True" in out.stdout, out.stdout[-400:] + out.stderr[-400:]
 
 
+def test_plan_falls_back_to_copies_when_the_communicators_cannot_be_built():
+    """plan_build had no fallback - a failing ncclCommInitAll killed the whole `--gpus 8` run.
+    PDC_FORCE_RCCL_FAIL=1 injects the failure: the plan is built all the same, warns on stderr, keeps the reason
+    (pdc_gls_plan_init_error) and exchanges by device-to-device copies; results unchanged."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PDC_FORCE_RCCL="1", PDC_FORCE_RCCL_FAIL="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_single_device_check.py"), "fail"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert "fallback after a failed ncclCommInitAll equal: True" in out.stdout, out.stdout[-600:] + out.stderr[-600:]
+    assert "WARNING: ncclCommInitAll failed" in out.stderr
+
+
 def test_persistent_plan_repeated_scans_and_validation():
     """pdc_gls_plan_*: buffers, streams and communicators created once; scans only enqueue, outputs are
     double-buffered; every scan of a sequence comes back bit-identical to the one-shot call."""
