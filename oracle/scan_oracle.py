@@ -534,8 +534,10 @@ def supersmoother(x, y, alpha=0.0, smooth=ss_smooth):
     resmin = res[best, np.arange(n)]
     span_j = np.asarray(SS_SPANS)[best]
     if 0.0 < alpha <= 10.0:
-        pull = (resmin < res[2]) & (res[2] > 0)
-        ratio = np.maximum(SS_SML, resmin / np.where(res[2] > 0, res[2], 1.0))
+        # (R's stats::supsmu guards with `resmin .lt. sc(j,6) .and. resmin .gt. 0`; Friedman's original has no
+        # positivity test: a smoothed residual <= 0 - an exactly fitted run - leaves the span alone here, as in R)
+        pull = (resmin < res[2]) & (resmin > 0)
+        ratio = np.maximum(SS_SML, resmin / np.where(pull, res[2], 1.0))
         span_j = np.where(pull, span_j + (SS_SPANS[2] - span_j) * ratio ** (10.0 - alpha), span_j)
     span_s, _ = smooth(x, span_j, SS_SPANS[1], vsmlsq, False)
     span_s = np.clip(span_s, SS_SPANS[0], SS_SPANS[2])

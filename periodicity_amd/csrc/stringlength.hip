@@ -2903,40 +2903,65 @@ int stream_allow_lds(const StreamShape &h) {
 // ---- Supersmoother: workspace -----------------------------------------------------------------------------
 struct SsShape {
     StreamShape h;
-    bool streamed;
-    int batch, grid_ss, grid_fb;
-    int64_t stride, n_pad, o_sorted, o_scratch, o_gk, o_gi, o_bad, total;
+    bool streamed, tiled;
+    int batch, grid_ss, grid_fb, sb, seg, seg_len;
+    int64_t stride, n_pad, o_sorted, o_scratch, o_gk, o_gi, o_bad, o_sm, o_arec, o_srec, o_flag, o_part, total;
 };
 SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
     SsShape z;
     z.streamed = n >= 4096 && n <= kStreamMaxN;
+    z.tiled = n >= ss2::kMinN && n <= ss2::kMaxN;
+    // the sorted batch - 16 bytes a point and period - stays within 2 GB (batches of >= 8 periods)
+    int64_t cap = ((int64_t)2 << 30) / (16 * (n > 0 ? n : 1));
+    cap = cap < 8 ? 8 : cap;
+    static const int64_t env_cap = [] { const char *e = getenv("PDC_SS_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)128; }();
+    cap = cap < env_cap ? cap : env_cap;   // (the bin lists of the streamed sort take ~49 bytes per point and period: 128 periods)
     int64_t at = 0;
     if (z.streamed) {
-        z.h = stream_shape(n, n_periods, lists);
+        z.h = stream_shape(n, n_periods < cap ? n_periods : cap, lists);
         z.batch = z.h.batch;
         at = up(z.h.total);
     } else {
         z.h = StreamShape{};
         int64_t b = n_periods < 512 ? n_periods : 512;
+        b = b < cap ? b : cap;
         z.batch = (int)(b < 1 ? 1 : b);
     }
     z.stride = (n + n / 2 + 24 + 7) & ~(int64_t)7;   // (prefix arrays run over the curve extended by a quarter on either side)
-    // two smoother workgroups per CU, within 16 GB of scratch.  (A workgroup's fifteen arrays take 180 MB at N = 1e6:
-    // 12 GB put a smoother on 66 of the 256 CUs - N = 1e6 x 256 periods 206 ms -, 32 GB 117 ms, 44 GB 77 ms; but the
-    // workspace is allocated on a process's first call at ~0.1 s per GB, and a search of a few thousand periods never
-    // earns 4 s of allocation back.)
-    int64_t g = ((int64_t)16 << 30) / (ss::kArrays * z.stride * 8);
-    g = g < 1 ? 1 : (g > 512 ? 512 : g);
+    // The generic smoother (ss_smooth_kernel: fifteen arrays of 1.5 n doubles per workgroup) is the whole path below
+    // ss2::kMinN samples and, above, takes only the periods the tiled kernels hand back: 1 GB of arrays for it.
+    int64_t g = ((int64_t)1 << 30) / (ss::kArrays * z.stride * 8);
+    g = g < 1 ? 1 : (g > (z.tiled ? 16 : 512) ? (z.tiled ? 16 : 512) : g);
     z.grid_ss = (int)(g < z.batch ? g : z.batch);
-    z.grid_fb = z.batch < 256 ? z.batch : 256;
+    z.grid_fb = z.batch < (z.streamed ? 64 : 256) ? z.batch : (z.streamed ? 64 : 256);
+    // Periods whose phases cluster are sorted by one workgroup each in global scratch (12 bytes a padded point): the
+    // pool of such workgroups stays within 1 GB
+    const int64_t fb_cap = ((int64_t)1 << 30) / (pad_pow2(n) * 12);
+    z.grid_fb = (int)(z.grid_fb < fb_cap ? z.grid_fb : (fb_cap < 1 ? 1 : fb_cap));
     z.n_pad = pad_pow2(n);
+    // tiled smoother: sub-batches of <= 64 periods, 72 bytes of intermediates per point and period within 1.5 GB
+    int64_t sb = ((int64_t)3 << 29) / (72 * (n > 0 ? n : 1)) / 8 * 8;
+    sb = sb < 8 ? 8 : (sb > ss2::kSubBatch ? ss2::kSubBatch : sb);
+    static const int env_sb = [] { const char *e = getenv("PDC_SS_SB"); return e ? atoi(e) : 0; }();
+    static const int env_seg = [] { const char *e = getenv("PDC_SS_SEG"); return e ? atoi(e) : 0; }();
+    if (env_sb >= 8 && env_sb <= ss2::kSubBatch && env_sb % 8 == 0 && env_sb < sb) sb = env_sb;
+    z.sb = (int)sb;
+    const int64_t tiles = (n + ss2::kSegUnit - 1) / ss2::kSegUnit;
+    const int seg_max = env_seg >= 1 && env_seg <= ss2::kSegMax ? env_seg : 8;
+    z.seg = (int)(tiles < seg_max ? (tiles < 1 ? 1 : tiles) : seg_max);
+    z.seg_len = (int)((tiles + z.seg - 1) / z.seg * ss2::kSegUnit);
     z.o_sorted = at;
     z.o_scratch = z.o_sorted + up((int64_t)z.batch * n * 16);
     z.o_gk = z.o_scratch + up((int64_t)z.grid_ss * ss::kArrays * z.stride * 8);
     z.o_gi = z.o_gk + up((int64_t)z.grid_fb * z.n_pad * 8);
     z.o_bad = z.o_gi + up((int64_t)z.grid_fb * z.n_pad * 4);
-    z.total = z.o_bad + 256;
+    z.o_sm = z.o_bad + 256;
+    z.o_arec = z.o_sm + (z.tiled ? up(3 * sb * n * 8) : 0);
+    z.o_srec = z.o_arec + (z.tiled ? up(sb * n * 32) : 0);
+    z.o_flag = z.o_srec + (z.tiled ? up(sb * n * 16) : 0);
+    z.o_part = z.o_flag + up((int64_t)z.batch * 4);
+    z.total = z.o_part + up((int64_t)z.batch * ss2::kSegMax * 8);
     return z;
 }
 
@@ -3320,6 +3345,21 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
     ka.alpha = alpha;
     ka.scratch = reinterpret_cast<double *>(base + z.o_scratch);
     ka.stat = d_stat;
+    ka.only = z.tiled ? reinterpret_cast<const unsigned *>(base + z.o_flag) : nullptr;
+    ss2::Args ta;
+    ta.sorted = sorted;
+    ta.n = n;
+    ta.seg = z.seg;
+    ta.seg_len = z.seg_len;
+    ta.alpha = alpha;
+    ta.sm = reinterpret_cast<double *>(base + z.o_sm);
+    ta.arec = reinterpret_cast<ss2::rec4_t *>(base + z.o_arec);
+    ta.srec = reinterpret_cast<fast::rec_t *>(base + z.o_srec);
+    ta.mrec = reinterpret_cast<fast::rec_t *>(base + z.o_arec);    // (over arec: dead after the second sweep)
+    ta.flag = reinterpret_cast<unsigned *>(base + z.o_flag);
+    ta.part = reinterpret_cast<double *>(base + z.o_part);
+    ta.plane = (int64_t)z.sb * n;
+    ta.stat = d_stat;
     for (int64_t p0 = 0; p0 < n_periods; p0 += z.batch) {
         const int64_t bc = n_periods - p0 < z.batch ? n_periods - p0 : z.batch;
         if (z.streamed) PDC_TRY(stream_sort_batch(device, st, z.h, sa, p0, bc));
@@ -3327,6 +3367,20 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
         fa.batch = (int)bc;
         hipLaunchKernelGGL(ss::ss_sort_fallback_kernel, dim3((unsigned)(bc < z.grid_fb ? bc : z.grid_fb)), dim3(kBlock), 0,
                            st, fa);
+        if (z.tiled) {
+            PDC_HIP(hipMemsetAsync(ta.flag, 0, (size_t)bc * 4, st));
+            ta.p0 = p0;
+            for (int q0 = 0; q0 < (int)bc; q0 += z.sb) {
+                ta.q0 = q0;
+                ta.nq = (int)bc - q0 < z.sb ? (int)bc - q0 : z.sb;
+                const unsigned grid = (unsigned)((ta.nq + 7) / 8 * z.seg * 8);
+                hipLaunchKernelGGL(ss2::ss2_stage_kernel<1>, dim3(grid), dim3(ss2::kTh), 0, st, ta);
+                hipLaunchKernelGGL(ss2::ss2_stage_kernel<2>, dim3(grid), dim3(ss2::kTh), 0, st, ta);
+                hipLaunchKernelGGL(ss2::ss2_stage_kernel<3>, dim3(grid), dim3(ss2::kTh), 0, st, ta);
+                hipLaunchKernelGGL(ss2::ss2_stage_kernel<4>, dim3(grid), dim3(ss2::kTh), 0, st, ta);
+                hipLaunchKernelGGL(ss2::ss2_finish_kernel, dim3((unsigned)((ta.nq + 63) / 64)), dim3(64), 0, st, ta);
+            }
+        }
         ka.p0 = p0;
         ka.batch = (int)bc;
         hipLaunchKernelGGL(ss::ss_smooth_kernel, dim3((unsigned)(bc < z.grid_ss ? bc : z.grid_ss)), dim3(ss::kB), 0, st, ka);
