@@ -520,17 +520,28 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
                                                                 10, 5, bth.ptr)), reps=5, warm=2)
     fr, _ = two_fracs(("pdm_scan_kernel<", ", 2> grid"), ms, pdm_algorithmic_frac(pairs, ms), "40 flop/pair vs 78.6 TFLOP/s")
     out["c5_cond_entropy"] = {"ms": round(ms, 4), "Gpair_per_s": round(pairs / ms / 1e6, 1), "cells": "10 x 5", **fr}
-    # Supersmoother (a one-line TODO upstream, spectral.py:8): streamed sort + prefix-sum smoother, 4096 of C5's periods
+    # Supersmoother (a one-line TODO upstream, spectral.py:8): streamed sort + the tiled smoother, 4096 of C5's periods
     n_ss = 4096
     wss = lib.pdc_supersmoother_work_bytes(n, n_ss)
     bss = DB(wss, dev)
     ms = tm.ms(lambda: cabi.check(lib.pdc_supersmoother_scan_dev(dev, stream, bt5.ptr, bx.ptr, n, bp.ptr, n_ss, 0.0, bth.ptr,
                                                                  bss.ptr, wss)), reps=3)
+    ss_hbm = None
+    if os.path.isfile(PMC_SUMMARY):
+        kern = json.load(open(PMC_SUMMARY)).get("kernels", {})
+        per = [k for name, k in kern.items() if "ss2_stage_kernel" in name and "hbm_bytes" in k]
+        if len(per) >= 4:      # (each sweep's entry is the mean over its launches of 64 periods)
+            ss_hbm = round(sum(k["hbm_bytes"] for k in per) / 64.0 / 1e6, 2)
     out["c5_supersmoother"] = {"ms": round(ms, 3), "Gpair_per_s": round(float(n) * n_ss / ms / 1e6, 2), "n_periods": n_ss,
+                               "workspace_MB": round(wss / 1e6, 1),
+                               "hbm_MB_per_period_smoother_sweeps": ss_hbm,
+                               "algorithmic_MB_per_period": round(208.0 * n / 1e6, 2),
                                "executed_issue_frac": None, "algorithmic_frac": None,
                                "note": "Friedman's variable span smoother on the phase-sorted curve, mean absolute residual "
-                                       "(Reimann 1994); parity unpinned by the reference; ~70 MB of prefix-scan and window "
-                                       "passes per period through HBM (DESIGN 4.7)"}
+                                       "(Reimann 1994); parity unpinned by the reference; round 5: four fused sweeps of sliding "
+                                       "window sums over tiles (no prefix arrays), 208 algorithmic bytes per point and period; "
+                                       "hbm_MB_per_period = (2 FETCH_SIZE + WRITE_SIZE) of the four sweeps' launches (PMC) / 64 "
+                                       "periods (DESIGN 4.7)"}
     bss.free()
     for b in (bt5, bx, bp, bth, bm, bsp, be, swork, bmag):
         b.free()

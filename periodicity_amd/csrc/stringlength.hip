@@ -3381,6 +3381,19 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
                 hipLaunchKernelGGL(ss2::ss2_finish_kernel, dim3((unsigned)((ta.nq + 63) / 64)), dim3(64), 0, st, ta);
             }
         }
+#ifdef PDC_SS_DBG   // (developer builds: s_memrealtime stamps of one tile of sweep PDC_SS_DBG, 10 ns ticks)
+        if (z.tiled && p0 == 0) {
+            std::vector<double> h((size_t)bc * ss2::kSegMax);
+            PDC_HIP(hipStreamSynchronize(st));
+            PDC_HIP(hipMemcpy(h.data(), ta.part, h.size() * 8, hipMemcpyDeviceToHost));
+            for (int q : {0, 9, 63, 64, 100}) {
+                if (q >= bc) continue;
+                const double *r = &h[(size_t)q * ss2::kSegMax];
+                fprintf(stderr, "dbg sweep %d period %d seg 1 tile 2: loads landed %.0f scans %.0f barrier %.0f fits %.0f stores %.0f barrier %.0f\n", PDC_SS_DBG, q,
+                        r[21] - r[20], r[22] - r[21], r[23] - r[22], r[24] - r[23], r[25] - r[24], r[26] - r[25]);
+            }
+        }
+#endif
         ka.p0 = p0;
         ka.batch = (int)bc;
         hipLaunchKernelGGL(ss::ss_smooth_kernel, dim3((unsigned)(bc < z.grid_ss ? bc : z.grid_ss)), dim3(ss::kB), 0, st, ka);
