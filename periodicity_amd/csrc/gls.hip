@@ -835,6 +835,159 @@ __global__ __launch_bounds__(kShBlock) void gls_shared_kernel(SharedArgs a) {
     }
 }
 
+// ---- the same, TWO frequencies per lane (round 5; individual weights) --------------------------------------------
+// In gls_shared_kernel every scalar load of a sample's weights and every LDS tile row feeds 6 fmas per curve.  Here a
+// lane owns frequencies j and j + 64 of a 128-frequency tile: 512 threads, 8 waves x 8 curves, 96 accumulators per lane
+// (256 registers), so the two 64-byte weight loads of a sample feed 96 fmas instead of 48 and twice as many fmas stand
+// between a request and its wait.  The second frequency's sin / cos come from the first's by ONE plane rotation with
+// (cos, sin)(2 pi 64 delta t) - the same for every lane, so 32 lanes compute a chunk's worth one chunk ahead - instead
+// of a second software sincos: the tile fill costs 4 sincos + 4 rotations per thread and 3072 fmas.
+constexpr int kSh2Block = 512;
+constexpr int kSh2Waves = kSh2Block / 64;
+constexpr int kSh2Chunk = 32;
+constexpr int kSh2Curves = 8;
+constexpr size_t kSh2Lds = (size_t)(kSh2Chunk + 2) * 4 * 64 * sizeof(double2);
+
+template <bool FIT_MEAN>
+__global__ __launch_bounds__(kSh2Block) void gls_shared2_kernel(SharedArgs a) {
+    constexpr int RT = kSh2Curves;
+    constexpr int MODE = FIT_MEAN ? MODE_FIT_MEAN : MODE_NO_MEAN;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sh2_raw[];
+    double2 (*trig)[4][64] = reinterpret_cast<double2 (*)[4][64]>(sh2_raw);   // [sample]{sc_a, qq_a, sc_b, qq_b}[lane]
+    __shared__ double2 rot_s[2][kSh2Chunk];                                     // (cos, sin)(2 pi 64 delta t) of a chunk's samples
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    const int64_t tiles128 = (a.nf + 127) / 128;
+    const int64_t G = a.groups * tiles128;
+    const int64_t per_xcd = (G + 7) / 8;
+    const int64_t L = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (L >= G) return;
+    const int64_t group = L / tiles128, tile = L - group * tiles128;
+    const int64_t ja = tile * 128 + lane, jb = ja + 64;
+    const double fa = __dadd_rn(a.f0, __dmul_rn((double)(a.j_begin + ja), a.delta));  // numpy arange
+    const double d64 = 64.0 * a.delta;
+    const int64_t r0 = (group * kSh2Waves + wave) * RT;  // first curve of this wave
+
+    double Sh[2][RT], Ch[2][RT], S[2][RT], C[2][RT], SS[2][RT], SC[2][RT];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) Sh[h][r] = Ch[h][r] = S[h][r] = C[h][r] = SS[h][r] = SC[h][r] = 0.0;
+
+    auto rotation = [&](int64_t i) -> double2 {
+        const double t = i < a.n ? a.tp[i] : 0.0;
+        double s, c;
+        sincos_cycles_half(frac_product(d64, t), s, c);
+        return make_double2(c, s);
+    };
+    if (threadIdx.x < kSh2Chunk) rot_s[0][threadIdx.x] = rotation(threadIdx.x);
+    int cur = 0;
+    for (int64_t base = 0; base < a.n; base += kSh2Chunk, cur ^= 1) {
+        __syncthreads();
+        if (threadIdx.x < kSh2Chunk) rot_s[cur ^ 1][threadIdx.x] = rotation(base + kSh2Chunk + threadIdx.x);
+#pragma unroll
+        for (int q = 0; q < kSh2Chunk / kSh2Waves; ++q) {
+            const int il = wave * (kSh2Chunk / kSh2Waves) + q;
+            const int64_t i = base + il;
+            const double t = i < a.n ? a.tp[i] : 0.0;
+            double s, c;
+            sincos_cycles_half(frac_product(fa, t), s, c);
+            const double2 rt = rot_s[cur][il];
+            double s2 = __builtin_fma(s, rt.x, c * rt.y), c2 = __builtin_fma(c, rt.x, -(s * rt.y));
+            if (i >= a.n) s = c = s2 = c2 = 0.0;  // padding rows contribute nothing
+            trig[il][0][lane] = make_double2(s, c);
+            trig[il][1][lane] = make_double2(s * s, s * c);
+            trig[il][2][lane] = make_double2(s2, c2);
+            trig[il][3][lane] = make_double2(s2 * s2, s2 * c2);
+        }
+        __syncthreads();
+        const int cnt = (int)((a.n - base) < kSh2Chunk ? (a.n - base) : kSh2Chunk);
+        const cw8 *wrow = reinterpret_cast<const cw8 *>(reinterpret_cast<uintptr_t>(a.rw + ((base * a.bpad + r0) * 2)));
+        const int64_t wstride = a.bpad * 2 / 8;  // w8 per sample row
+        auto accumulate = [&](const w8 &b0, const w8 &b1, const double2 (&tv)[4]) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const double wy = r < 4 ? b0[2 * (r & 3)] : b1[2 * (r & 3)];
+                const double w = r < 4 ? b0[2 * (r & 3) + 1] : b1[2 * (r & 3) + 1];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double2 sc = tv[2 * h], qq = tv[2 * h + 1];
+                    Sh[h][r] = __builtin_fma(wy, sc.x, Sh[h][r]);
+                    Ch[h][r] = __builtin_fma(wy, sc.y, Ch[h][r]);
+                    if (FIT_MEAN) {
+                        S[h][r] = __builtin_fma(w, sc.x, S[h][r]);
+                        C[h][r] = __builtin_fma(w, sc.y, C[h][r]);
+                    }
+                    SS[h][r] = __builtin_fma(w, qq.x, SS[h][r]);
+                    SC[h][r] = __builtin_fma(w, qq.y, SC[h][r]);
+                }
+            }
+        };
+        // (software pipeline as in gls_shared_kernel: the weights and the tile row of sample il + 1 are requested right
+        // after the wait for sample il's and before its 96 fmas; two register sets that swap roles)
+        w8 a0 = wrow[0], a1 = wrow[1];
+        double2 ta[4], tb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ta[k] = trig[0][k][lane];
+        for (int il = 0; il < cnt; il += 2) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): set A has arrived
+            const w8 b0 = wrow[wstride], b1 = wrow[wstride + 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tb[k] = trig[il + 1][k][lane];
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(a0, a1, ta);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // set B has arrived
+            a0 = wrow[2 * wstride];
+            a1 = wrow[2 * wstride + 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ta[k] = trig[il + 2][k][lane];
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(b0, b1, tb);
+            __builtin_amdgcn_sched_barrier(0);
+            wrow += 2 * wstride;
+        }
+    }
+
+    const int64_t tiles64 = (a.nf + 63) / 64;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int64_t b = r0 + r;
+        if (b >= a.n_curves) break;  // wave-uniform
+        const double *sc = a.scal + b * 4;
+        const double YY = sc[0], Wsum = sc[1], Werr = sc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t j = h ? jb : ja;
+            const bool valid = j < a.nf;
+            const double p = gls_power<MODE>(Sh[h][r], Ch[h][r], S[h][r], C[h][r], SS[h][r], SC[h][r], YY, Wsum, Werr, a.psd);
+            if (valid && a.power) a.power[b * a.nf + j] = p;
+            if (a.blk_max && 2 * tile + h < tiles64) {   // (wave-uniform)
+                double best = 0.0;
+                long long best_j = -1;
+                if (valid && p == p) {
+                    best = p;
+                    best_j = j;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double ov = __shfl_down(best, o, 64);
+                    const long long oj = __shfl_down(best_j, o, 64);
+                    if (oj >= 0 && (best_j < 0 || ov > best || (ov == best && oj < best_j))) {
+                        best = ov;
+                        best_j = oj;
+                    }
+                }
+                if (lane == 0) {
+                    a.blk_max[b * tiles64 + 2 * tile + h] = best;
+                    a.blk_arg[b * tiles64 + 2 * tile + h] = best_j;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void gls_peak_kernel(const double *blk_max, const int64_t *blk_arg,
                                                       int64_t tiles, double *amax, int64_t *argmax) {
     const int64_t curve = blockIdx.x;
@@ -1022,6 +1175,28 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
             sa.power = d_power;
             sa.blk_max = peaks ? reinterpret_cast<double *>(base + w.blk_max) : nullptr;
             sa.blk_arg = peaks ? reinterpret_cast<int64_t *>(base + w.blk_arg) : nullptr;
+            static const bool sh2 = [] { const char *e = getenv("PDC_GLS_SH2"); return !(e && e[0] == '0'); }();
+            if (!uni && sh2) {
+                // individual weights: two frequencies per lane, 64 curves per workgroup (bpad is a multiple of 128)
+                sa.groups = bpad / (kSh2Waves * kSh2Curves);
+                const int64_t G2 = sa.groups * ((nf + 127) / 128);
+                PDC_REQUIRE(G2 < (int64_t)1 << 31, "gls: grid too large");
+                const dim3 grid2((unsigned)(((G2 + 7) / 8) * 8));
+                if (mode == MODE_FIT_MEAN) {
+                    PDC_TRY(allow_dynamic_lds((const void *)gls_shared2_kernel<true>, (int)kSh2Lds));
+                    hipLaunchKernelGGL((gls_shared2_kernel<true>), grid2, dim3(kSh2Block), kSh2Lds, st, sa);
+                } else {
+                    PDC_TRY(allow_dynamic_lds((const void *)gls_shared2_kernel<false>, (int)kSh2Lds));
+                    hipLaunchKernelGGL((gls_shared2_kernel<false>), grid2, dim3(kSh2Block), kSh2Lds, st, sa);
+                }
+                PDC_HIP(hipGetLastError());
+                if (peaks) {
+                    hipLaunchKernelGGL(gls_peak_kernel, dim3((unsigned)n_curves), dim3(64), 0, st, sa.blk_max,
+                                       sa.blk_arg, sa.tiles, d_amax, d_argmax);
+                    PDC_HIP(hipGetLastError());
+                }
+                return PDC_OK;
+            }
             const int64_t G = sa.groups * sa.tiles;
             PDC_REQUIRE(G < (int64_t)1 << 31, "gls: grid too large");
             const dim3 grid((unsigned)(((G + 7) / 8) * 8));

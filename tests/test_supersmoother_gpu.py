@@ -80,6 +80,26 @@ def test_supersmoother_scan_matches_the_oracle_at_the_sizes_it_runs(n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,alpha", [(30_000, 0.0), (30_000, 7.0), (8_192, 0.0), (4_096, 3.0)])
+def test_tiled_smoother_short_runs_of_equal_phases(n, alpha):
+    """Duplicate time stamps give runs of two and three equal phases at every period: the tiled kernels (n >= 4096)
+    average the fitted values over such runs from their halos - wherever the runs fall with respect to the tiles and
+    the segments - and hand nothing back to the generic kernel; a tail of 300 equal stamps (a run longer than a halo)
+    is the generic kernel's."""
+    t, y = curve(n, 3 * n + 1)
+    t[5:n:7] = t[4:n - 1:7]
+    t[100:n:1001] = t[99:n - 1:1001]
+    t[101:n:1001] = t[99:n - 2:1001]
+    periods = np.array([0.37, 2.1, 7.3, 9.99, 31.0, 0.2 * t[-1], 2.5 * t[-1]])
+    got = _cabi.supersmoother_scan(t, y, periods, alpha)
+    np.testing.assert_allclose(got, so.supersmoother_scan(t, y, periods, alpha), rtol=RTOL)
+    assert np.array_equal(got, _cabi.supersmoother_scan(t, y, periods, alpha))
+    t[-300:] = t[-300]
+    got = _cabi.supersmoother_scan(t, y, periods[:4], alpha)
+    np.testing.assert_allclose(got, so.supersmoother_scan(t, y, periods[:4], alpha), rtol=RTOL)
+
+
+@pytest.mark.gpu
 def test_supersmoother_class_finds_the_period_and_edges():
     t, y = curve(6000, 11)
     res = SuperSmoother(p_min=5.0, p_max=10.0, n_periods=201)(TSeries(t, y))
