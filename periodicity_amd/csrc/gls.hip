@@ -1407,6 +1407,7 @@ int pdc_gls_scan_batch(const double *t, const double *y, const double *dy, const
     if (argmax_out) PDC_TRY(cached(device, SLOT_OUT2, n_curves * 8, &d_arg));
     PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     PDC_HIP(hipMemcpyAsync(d_t, t, n_t * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_y, y, n_total * 8, hipMemcpyHostToDevice, st));
     if (dy) PDC_HIP(hipMemcpyAsync(d_dy, dy, n_total * 8, hipMemcpyHostToDevice, st));
@@ -1446,6 +1447,7 @@ int pdc_trig_sums(const double *t, const double *w, int64_t n, double f0, double
     PDC_TRY(cached(device, SLOT_OUT1, nf * 8, &d_c));
     PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_w, w, n * 8, hipMemcpyHostToDevice, st));
     PDC_TRY(scan_dev(device, st, (double *)d_t, (double *)d_w, nullptr, nullptr, n, 1, 0, f0, delta,

@@ -1042,6 +1042,7 @@ int pdc_gls_scan_fft(const double *t, const double *y, const double *dy, int64_t
     PDC_TRY(cached(device, SLOT_OUT0, nf * 8, &d_pow));
     PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
     if (dy) PDC_HIP(hipMemcpyAsync(d_dy, dy, n * 8, hipMemcpyHostToDevice, st));
@@ -1105,6 +1106,7 @@ int fft_batch_host(const double *t, const double *y, const double *dy, const int
     if (argmax_out) PDC_TRY(cached(device, SLOT_OUT2, n_curves * 8, &d_arg));
     PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     PDC_HIP(hipMemcpyAsync(d_t, t, n_t * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_y, y, n_y * 8, hipMemcpyHostToDevice, st));
     if (dy) PDC_HIP(hipMemcpyAsync(d_dy, dy, n_y * 8, hipMemcpyHostToDevice, st));
@@ -1211,6 +1213,7 @@ int pdc_trig_sums_fft(const double *t, const double *h, int64_t n, double df, in
     PDC_TRY(cached(device, SLOT_OUT1, nf * 8, &d_c));
     PDC_TRY(cached(device, SLOT_WORK, nfft * 32 + 512, &d_work));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     cplx *grid = reinterpret_cast<cplx *>(d_work), *scratch = grid + nfft;
     PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_h, h, n * 8, hipMemcpyHostToDevice, st));

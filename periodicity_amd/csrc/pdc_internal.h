@@ -39,6 +39,7 @@ int pinned_alloc(void **hptr, int64_t bytes);
 // caller unpins it (stream_scratch_done, or the ScratchPin guard) once all launches that use it are enqueued:
 // from then on the stream itself is busy until they have run.  Entry points that take an
 // explicit workspace (pdc_phase_scan_dev, pdc_gls_scan_dev, pdc_stringlength_scan_dev) never come here.
+int host_stream(int device, hipStream_t *st);   // the device's stream for host entry points (caller holds DeviceLock)
 int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr);
 void stream_scratch_done(int device, hipStream_t stream);
 int drop_stream_scratch(int device, hipStream_t stream);

@@ -817,6 +817,7 @@ int phase_stat_host(int kind, const double *t, const double *x, int64_t n, const
     PDC_TRY(cached(device, SLOT_IN2, n_periods * 8, &d_p));
     PDC_TRY(cached(device, SLOT_OUT0, n_periods * 8, &d_th));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
     if (x) PDC_HIP(hipMemcpyAsync(d_x, x, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_p, periods, n_periods * 8, hipMemcpyHostToDevice, st));

@@ -652,6 +652,7 @@ int pdc_highest_peak(const double *power, int64_t n_curves, int64_t nf, int64_t 
     PDC_TRY(cached(device, SLOT_OUT1, n_curves * 8, &d_i));
     PDC_TRY(cached(device, SLOT_OUT2, n_curves * 8, &d_v));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     PDC_HIP(hipMemcpyAsync(d_p, power, n_curves * nf * 8, hipMemcpyHostToDevice, st));
     PDC_TRY(pdc_highest_peak_dev(device, st, (double *)d_p, n_curves, nf, (int64_t *)d_i, (double *)d_v));
     if (idx_out) PDC_HIP(hipMemcpyAsync(idx_out, d_i, n_curves * 8, hipMemcpyDeviceToHost, st));
@@ -744,6 +745,7 @@ int pdc_peaks_topk(const double *power, int64_t n_curves, int64_t nf, int k, int
     void *d_p;
     PDC_TRY(cached(device, SLOT_OUT0, n_curves * nf * 8, &d_p));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     PDC_HIP(hipMemcpyAsync(d_p, power, n_curves * nf * 8, hipMemcpyHostToDevice, st));
     return topk_outputs(device, st, (double *)d_p, n_curves, nf, k, by_prominence, count_out, idx_out,
                         height_out, prominence_out, half_lo_out, half_hi_out);
@@ -778,6 +780,7 @@ int pdc_gls_batch_peaks(const double *t, const double *y, const double *dy, cons
     PDC_TRY(cached(device, SLOT_OUT0, n_curves * nf * 8, &d_pow));
     PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     PDC_HIP(hipMemcpyAsync(d_t, t, n_t * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_y, y, n_total * 8, hipMemcpyHostToDevice, st));
     if (dy) PDC_HIP(hipMemcpyAsync(d_dy, dy, n_total * 8, hipMemcpyHostToDevice, st));
@@ -818,6 +821,7 @@ int pdc_gls_batch_highest_peak(const double *t, const double *y, const double *d
     PDC_TRY(cached(device, SLOT_OUT2, n_curves * 8, &d_v));
     PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     PDC_HIP(hipMemcpyAsync(d_t, t, n_t * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_y, y, n_total * 8, hipMemcpyHostToDevice, st));
     if (dy) PDC_HIP(hipMemcpyAsync(d_dy, dy, n_total * 8, hipMemcpyHostToDevice, st));

@@ -2,6 +2,7 @@
 // wrappers.  Nothing here is on the hot path.
 #include <atomic>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <vector>
 
@@ -22,6 +23,7 @@ struct DeviceState {
     void *buf[SLOT_COUNT] = {};
     int64_t cap[SLOT_COUNT] = {};
     std::mutex call_mutex;
+    hipStream_t host_stream = nullptr;   // what the host entry points enqueue on (created on first use)
 };
 
 static std::mutex g_mutex;
@@ -94,6 +96,16 @@ int cached(int device, Slot slot, int64_t bytes, void **dptr) {
     return PDC_OK;
 }
 
+// The host entry points (numpy in, numpy out) run on ONE non-blocking stream per device, not on the legacy NULL
+// stream: a thread that drives its own streams through the `_dev` entries is no longer serialised against them by
+// the default stream's implicit synchronisation.  The caller holds the device's DeviceLock.
+int host_stream(int device, hipStream_t *st) {
+    DeviceState *d = g_devices[device];
+    if (!d->host_stream) PDC_HIP(hipStreamCreateWithFlags(&d->host_stream, hipStreamNonBlocking));
+    *st = d->host_stream;
+    return PDC_OK;
+}
+
 struct StreamScratch {
     int device;
     hipStream_t stream;
@@ -103,6 +115,7 @@ struct StreamScratch {
     std::vector<void *> retired;   // blocks outgrown while pinned: freed when the last of those callers is done
 };
 static std::mutex g_scratch_mutex;
+static std::condition_variable g_scratch_cv;   // signalled by stream_scratch_done()
 static std::vector<StreamScratch> g_scratch;   // least recently used entry first
 constexpr size_t kScratchPerDevice = 64;
 
@@ -132,11 +145,20 @@ static bool scratch_entry_idle(const StreamScratch &s) {
 
 // The block comes back PINNED: call stream_scratch_done() once every launch that uses it has been enqueued.
 int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
-    std::lock_guard<std::mutex> lk(g_scratch_mutex);
+    std::unique_lock<std::mutex> lk(g_scratch_mutex);
     if (bytes < 256) bytes = 256;
-    size_t at = g_scratch.size();
-    for (size_t i = 0; i < g_scratch.size(); ++i)
-        if (g_scratch[i].device == device && g_scratch[i].stream == stream) at = i;
+    // ONE caller at a time between stream_scratch() and stream_scratch_done() on a (device, stream): two host threads
+    // that enqueue on the same stream share its block, and launches of theirs that interleaved in the stream would
+    // read each other's partial results (the legacy NULL stream is the likely shared one).  Stream order then keeps
+    // the block's users apart; a caller that needs a larger block finds the entry unpinned.
+    size_t at;
+    for (;;) {
+        at = g_scratch.size();
+        for (size_t i = 0; i < g_scratch.size(); ++i)
+            if (g_scratch[i].device == device && g_scratch[i].stream == stream) at = i;
+        if (at == g_scratch.size() || g_scratch[at].pins == 0) break;
+        g_scratch_cv.wait(lk);
+    }
     if (at == g_scratch.size()) {
         // a stream handle this table has not seen: the caller may be cycling through transient streams (and
         // HIP may never hand the same address out again), so a device's entries are bounded - the least
@@ -181,6 +203,7 @@ int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
 
 void stream_scratch_done(int device, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_scratch_mutex);
+    g_scratch_cv.notify_all();
     for (StreamScratch &e : g_scratch)
         if (e.device == device && e.stream == stream && e.pins > 0) {
             --e.pins;

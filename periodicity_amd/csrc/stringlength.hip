@@ -2877,7 +2877,7 @@ int stream_sort_batch(int device, hipStream_t st, const StreamShape &h, stream::
     const dim3 wg((unsigned)(h.groups > 8 ? bc * h.groups : 8 * ((bc + 8 / h.groups - 1) / (8 / h.groups))));
     hipLaunchKernelGGL(stream::sl_hist_kernel, wg, dim3(stream::kBA), 0, st, sa);
     hipLaunchKernelGGL(stream::sl_lut_kernel, dim3((unsigned)bc), dim3(256), (size_t)h.s1 * h.groups * 4, st, sa);
-    if (sa.direct) hipLaunchKernelGGL(stream::sl_direct_kernel, dim3((unsigned)(bc * stream::kDirectW)), dim3(stream::kBB), 0, st, sa);
+    if (sa.direct && !sa.sorted) hipLaunchKernelGGL(stream::sl_direct_kernel, dim3((unsigned)(bc * stream::kDirectW)), dim3(stream::kBB), 0, st, sa);
     // (every other period takes one of the two: a workgroup of the other kernel returns at once)
     if (s1p == 2048) hipLaunchKernelGGL(stream::sl_part_kernel<2048>, wg, dim3(stream::kBA), lds_a, st, sa);
     else if (s1p == 1024) hipLaunchKernelGGL(stream::sl_part_kernel<1024>, wg, dim3(stream::kBA), lds_a, st, sa);
@@ -3265,6 +3265,7 @@ int pdc_stringlength_scan(const double *t, const double *m, int64_t n, const dou
     PDC_TRY(cached(device, SLOT_OUT0, n_periods * 8, &d_e));
     PDC_TRY(cached(device, SLOT_WORK, wb, &d_w));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_m, m, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_p, periods, n_periods * 8, hipMemcpyHostToDevice, st));
@@ -3323,7 +3324,7 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
     if (z.streamed) {
         sa = stream_args(z.h, base, d_t, d_y, d_periods, n, nullptr);
         sa.sorted = sorted;
-        sa.direct = 0;
+        sa.direct = sa.slices;             // (one-cycle periods are marked by the bin table kernel: ss_direct_kernel writes them)
         sa.no_lists = lists ? 0 : 1;
         PDC_TRY(stream_allow_lds(z.h));
     }
@@ -3367,6 +3368,7 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
         fa.batch = (int)bc;
         hipLaunchKernelGGL(ss::ss_sort_fallback_kernel, dim3((unsigned)(bc < z.grid_fb ? bc : z.grid_fb)), dim3(kBlock), 0,
                            st, fa);
+        if (z.streamed && sa.direct) hipLaunchKernelGGL(ss::ss_direct_kernel, dim3((unsigned)(bc * 8)), dim3(kBlock), 0, st, fa);
         if (z.tiled) {
             PDC_HIP(hipMemsetAsync(ta.flag, 0, (size_t)bc * 4, st));
             ta.p0 = p0;
@@ -3421,6 +3423,7 @@ int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const do
     PDC_TRY(cached(device, SLOT_OUT0, n_periods * 8, &d_s));
     PDC_TRY(cached(device, SLOT_WORK, wb, &d_w));
     hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
     PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_p, periods, n_periods * 8, hipMemcpyHostToDevice, st));

@@ -276,12 +276,16 @@ def test_scratch_table_never_frees_a_block_in_use():
 
 def test_scratch_regrow_never_frees_a_pinned_block():
     """when a (device, stream) entry must grow while another host thread still holds the old block pinned
-    (its launches not enqueued yet), the old block is RETIRED and freed only when the pins are back to zero.
-    Deterministic leg: the library's internal table driven directly (C++ symbols of the .so, no public entry) - pin a
-    small block, ask for a larger one on the same stream, the first block must still be writable device memory and
-    counted as retired until both callers are done.  Threaded leg: two host threads on ONE stream, one with a short
-    period grid, one whose grids keep growing, every result equal to the single-thread one."""
+    (its launches not enqueued yet), hipFree's device synchronisation cannot protect launches that do not exist yet.
+    Round 5: ONE caller at a time holds a stream's block between stream_scratch() and stream_scratch_done() - the
+    second waits - so no block is ever outgrown while pinned, and launches of two threads on one stream cannot
+    interleave around the shared block.  Deterministic leg: the library's internal table driven directly (C++ symbols
+    of the .so, no public entry) - thread A pins a small block and keeps it for 0.3 s, thread B asks for a larger one
+    on the same stream: B returns only after A is done, A's block is valid device memory all along.  Threaded leg: two
+    host threads on ONE stream, one with a short period grid, one whose grids keep growing, every result equal to the
+    single-thread one."""
     import threading
+    import time
     lib = _cabi.lib()
     scratch = getattr(lib, "_ZN3pdc14stream_scratchEiP12ihipStream_tlPPv")
     done = getattr(lib, "_ZN3pdc19stream_scratch_doneEiP12ihipStream_t")
@@ -291,19 +295,26 @@ def test_scratch_regrow_never_frees_a_pinned_block():
     retired.argtypes, retired.restype = [], C.c_int64
     s = C.c_void_p()
     _cabi.check(lib.pdc_stream_create(0, C.byref(s)))
+    stamps = {}
     a, b = C.c_void_p(), C.c_void_p()
-    _cabi.check(scratch(0, s, 1 << 20, C.byref(a)))            # caller 1: pinned, nothing enqueued yet
-    _cabi.check(scratch(0, s, 64 << 20, C.byref(b)))           # caller 2 outgrows the block
-    assert a.value != b.value and retired() == 1
-    host = np.arange(1 << 17, dtype=np.float64)                # caller 1 now uses ITS block: still valid memory
+    _cabi.check(scratch(0, s, 1 << 20, C.byref(a)))            # caller A: pinned, nothing enqueued yet
+
+    def caller_b():
+        _cabi.check(scratch(0, s, 64 << 20, C.byref(b)))       # outgrows the block: must wait for A
+        stamps["b_got"] = time.monotonic()
+        done(0, s)
+    th = threading.Thread(target=caller_b)
+    th.start()
+    time.sleep(0.3)
+    host = np.arange(1 << 17, dtype=np.float64)                # A uses ITS block: still valid memory
     _cabi.check(lib.pdc_memcpy_h2d(0, a, host.ctypes.data_as(C.c_void_p), host.nbytes))
     back = np.empty_like(host)
     _cabi.check(lib.pdc_memcpy_d2h(0, back.ctypes.data_as(C.c_void_p), a, host.nbytes))
-    assert np.array_equal(back, host)
+    assert np.array_equal(back, host) and "b_got" not in stamps
+    stamps["a_done"] = time.monotonic()
     done(0, s)
-    assert retired() == 1                                      # one caller is still out
-    done(0, s)
-    assert retired() == 0
+    th.join()
+    assert stamps["b_got"] >= stamps["a_done"] and retired() == 0
     _cabi.check(lib.pdc_stream_destroy(0, s))
 
     t, x, _ = phase_inputs(60_000, 9)

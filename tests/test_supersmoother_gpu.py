@@ -100,6 +100,22 @@ def test_tiled_smoother_short_runs_of_equal_phases(n, alpha):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [5_000, 40_000])
+def test_supersmoother_periods_that_outlast_the_samples(n):
+    """p > baseline: less than one cycle, the phase order is the time order - or, with Julian-date stamps, the later
+    samples first (a cycle boundary inside the samples): written as they stand by ss_direct_kernel, no sort (the
+    bitonic fallback took ~200 passes over the padded curve for each such period).  Duplicated stamps keep their order."""
+    t, y = curve(n, n + 3)
+    t = t + 2454953.5
+    t[7:n:11] = t[6:n - 1:11]
+    base = t[-1] - t[0]
+    periods = np.concatenate([base * np.array([0.999, 1.0, 1.001, 1.5, 2.0, 3.3, 9.99, 57.0]), [2454953.5, 2454953.5 / 2, 1e7, 1e9]])
+    for alpha in (0.0, 4.0):
+        got = _cabi.supersmoother_scan(t, y, periods, alpha)
+        np.testing.assert_allclose(got, so.supersmoother_scan(t, y, periods, alpha), rtol=RTOL)
+
+
+@pytest.mark.gpu
 def test_supersmoother_class_finds_the_period_and_edges():
     t, y = curve(6000, 11)
     res = SuperSmoother(p_min=5.0, p_max=10.0, n_periods=201)(TSeries(t, y))

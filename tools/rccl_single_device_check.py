@@ -45,7 +45,8 @@ if FAIL:
     many.close()
     print("fallback info:", info1, info3)
     print("fallback after a failed ncclCommInitAll equal:",
-          np.array_equal(a, b) and np.array_equal(a, c) and info1["rccl_ranks"] == 0 and bool(info1["init_error"])
+          np.array_equal(a, b) and np.allclose(a, c, rtol=1e-11, atol=1e-13)   # (three slabs: other tile shapes, other summation order)
+          and info1["rccl_ranks"] == 0 and bool(info1["init_error"])
           and info3["exchange"] == "copy" and bool(info3["init_error"]))
 elif TORCH:
     from tools.torchrun_sharded import sharded_gls
