@@ -469,9 +469,16 @@ def ss_average_ties(x, smo):
 
 
 def ss_smooth(x, y, span, vsmlsq, cv):
-    """The same smoother from window sums (long-double prefix sums over the periodic extension x - 1, x, x + 1):
-    window of sample j = the 2 ibw + 1 points j - ibw .. j + ibw, mean line through them evaluated at x[j], and -
-    `cv` - the absolute leave-one-out residual |y - smo| / (1 - 1/fbw - (x - xm)^2 / var)."""
+    """The same smoother from window sums: window of sample j = the 2 ibw + 1 points j - ibw .. j + ibw (periodic:
+    points taken from the other end count with abscissae - 1 / + 1), mean line through them evaluated at x[j], and -
+    `cv` - the absolute leave-one-out residual |y - smo| / (1 - 1/fbw - (x - xm)^2 / var).
+
+    Long-double prefix sums over the n points AS THEY STAND, abscissae relative to the median (a running-lines fit
+    does not change under a shift of x); a wrapped window adds its far part's own sums U and point count c through
+    sum (x -+ 1) = U_x -+ c, sum (x -+ 1)^2 = U_xx -+ 2 U_x + c, sum (x -+ 1) z = U_xz -+ U_z.  (Round 4 prefixed
+    over concat(x - 1, x, x + 1): every prefix value then carried ~n terms of order 1, and for phases crowded into a
+    sliver of the cycle - a period far beyond the baseline - even 80-bit sums lost var = Sxx - fbw xm^2: the ORACLE
+    was wrong in the 8th digit at a spread of 1e-5, found when the device kernels stopped agreeing with it there.)"""
     x = np.asarray(x, dtype=float)
     y = np.asarray(y, dtype=float)
     n = x.size
@@ -479,29 +486,36 @@ def ss_smooth(x, y, span, vsmlsq, cv):
     if 2 * ibw + 1 > n:
         raise ValueError("supersmoother: too few samples for the span")
     L = np.longdouble
-    xe = np.concatenate([x - 1.0, x, x + 1.0]).astype(L)
-    ye = np.concatenate([y, y, y]).astype(L)
-    def win(v):
+    xc = (x - x[n // 2]).astype(L)
+    yl = y.astype(L)
+    j = np.arange(n)
+    lo, hi = j - ibw, j + ibw + 1
+    low, high = lo < 0, hi > n
+    wl = np.where(low, n + lo, 0)
+    wh = np.where(low, n, np.where(high, hi - n, 0))
+    sh = np.where(low, L(-1), np.where(high, L(1), L(0)))
+    cw = (wh - wl).astype(L)
+    lo_c, hi_c = np.maximum(lo, 0), np.minimum(hi, n)
+    def sums(v):
         c = np.concatenate([[L(0)], np.cumsum(v)])
-        j = np.arange(n) + n
-        return c[j + ibw + 1] - c[j - ibw]
+        return c[hi_c] - c[lo_c], c[wh] - c[wl]
+    (mx, ux), (mxx, uxx), (my, uy), (mxy, uxy) = sums(xc), sums(xc * xc), sums(yl), sums(xc * yl)
     fbw = L(2 * ibw + 1)
-    sx, sy, sxx, sxy = win(xe), win(ye), win(xe * xe), win(xe * ye)
+    sx, sxx, sy, sxy = mx + (ux + sh * cw), mxx + (uxx + 2 * sh * ux + cw), my + uy, mxy + (uxy + sh * uy)
     xm, ym = sx / fbw, sy / fbw
     var = sxx - fbw * xm * xm
     cvar = sxy - fbw * xm * ym
     a = np.where(var > vsmlsq, cvar / np.where(var > vsmlsq, var, 1), 0)
-    xl = x.astype(L)
-    smo = a * (xl - xm) + ym
+    smo = a * (xc - xm) + ym
     acvr = np.zeros(n)
     if cv:
-        h = 1 / fbw + np.where(var > vsmlsq, (xl - xm) ** 2 / np.where(var > vsmlsq, var, 1), 0)
+        h = 1 / fbw + np.where(var > vsmlsq, (xc - xm) ** 2 / np.where(var > vsmlsq, var, 1), 0)
         a1 = 1 - h
         ok = a1 > 0
-        acvr = np.where(ok, np.abs(y.astype(L) - smo) / np.where(ok, a1, 1), 0).astype(float)
-        for j in np.nonzero(~ok)[0]:                    # (`smooth`, label 70: carried over from the point before)
-            if j > 0:
-                acvr[j] = acvr[j - 1]
+        acvr = np.where(ok, np.abs(yl - smo) / np.where(ok, a1, 1), 0).astype(float)
+        for jj in np.nonzero(~ok)[0]:                    # (`smooth`, label 70: carried over from the point before)
+            if jj > 0:
+                acvr[jj] = acvr[jj - 1]
     return ss_average_ties(x, smo.astype(float)), acvr
 
 

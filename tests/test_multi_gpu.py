@@ -46,7 +46,7 @@ def test_loopback_plan_matches_slabwise_scans_on_every_slot(n_slots):
     t, y, dy = synth(3000, 11 + n_slots)
     plan = _cabi.GlsPlan([0], n_max=4000, nf_max=6000, loopback_slots=n_slots)
     info = plan.info()
-    assert info == {"n_slots": n_slots, "rccl_ranks": 0, "exchange": "copy"}
+    assert info == {"n_slots": n_slots, "rccl_ranks": 0, "exchange": "copy", "init_error": None}
     plan.upload(t, y, dy)
     # grids: divisible, not divisible, shorter than the slot count (trailing slots own nothing), one bin
     for nf in (4096 - 4096 % n_slots, 5003, n_slots - 1, 1, 2 * n_slots + 1):

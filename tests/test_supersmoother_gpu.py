@@ -43,6 +43,33 @@ def test_oracle_window_sums_equal_the_literal_updating_formulas():
     assert abs(per[np.argmin(so.supersmoother_scan(t, y, per))] - 7.3) < 0.26
 
 
+def test_oracle_window_sums_stay_exact_for_phases_crowded_into_a_sliver_of_the_cycle():
+    """CPU: a period far beyond the baseline folds the samples into a sliver of the cycle (spread 1e-5 ... 1e-7).  The
+    oracle's window sums (long double, abscissae relative to the median, wrapped parts added through their own sums)
+    equal a brute-force fit of every window in LOCALLY centred long-double arithmetic to rounding - where the literal
+    double-precision updating formulas of the Fortran, and the round-4 oracle that prefixed over shifted abscissae, lose
+    var = Sxx - fbw xm^2 altogether (errors of 1e-4 ... 0.2).  The device kernels are held to THIS oracle."""
+    L = np.longdouble
+    rng = np.random.default_rng(2)
+    n = 300
+    for spread in (1e-5, 1e-7):
+        x = np.sort(2.45e-3 + spread * rng.uniform(0, 1, n))
+        y = np.sin(2 * np.pi * (x - x[0]) / spread * 3) + 0.3 * rng.standard_normal(n)
+        v = (1e-3 * (x[3 * (n // 4) - 1] - x[n // 4 - 1])) ** 2
+        for span in so.SS_SPANS:
+            ibw = so.ss_half_width(n, span)
+            want = np.empty(n)
+            for j in range(n):
+                idx = np.arange(j - ibw, j + ibw + 1)
+                xs = np.where(idx < 0, x[idx % n] - 1, np.where(idx >= n, x[idx % n] + 1, x[idx % n])).astype(L) - L(x[j])
+                ys = y[idx % n].astype(L)
+                xm, ym = xs.mean(), ys.mean()
+                var, cvar = ((xs - xm) ** 2).sum(), ((xs - xm) * (ys - ym)).sum()
+                want[j] = (cvar / var if var > v else 0) * (0 - xm) + ym
+            got, _ = so.ss_smooth(x, y, span, v, False)
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-13)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,even,alpha", [(300, False, 0.0), (5000, False, 0.0), (5000, False, 5.0), (9000, False, 0.0),
                                           (4000, True, 0.0), (6000, True, 2.0)])
