@@ -350,7 +350,13 @@ int pdc_phase_plan_destroy(void *plan);
  * signal of phase.py:65-66.  Samples may come in any order (equal phases keep the order given, as the
  * stable sort does); time-ordered samples - what a TSeries holds - are faster than samples in another order: the
  * periods that outlast them need no sort at all (at any size), and from 262 144 samples on a bin's samples are
- * fetched as slices of t / m (nothing is re-ordered: the kernels check and pick their way). */
+ * fetched as slices of t / m (nothing is re-ordered: the kernels check and pick their way).
+ * What samples in ANOTHER order cost (measured, profiles/r04_sl_shapes.txt): from 262 144 samples on every bin goes
+ * through the partition lists - 1.4x at N = 1e6 (34.9 against 24.4 ms for 2048 periods) - and every period that
+ * outlasts the samples takes the general kernel, ~0.1 s EACH at N = 2e6 (118 against 13 ms for the 512 periods of the
+ * reference's grid, whose last ten outlast the samples): a caller with millions of unordered samples should order
+ * them by time first, as the TSeries constructor does (core.py:473-477) - results are the same as long as no two
+ * samples share a phase. */
 int pdc_stringlength_scan(const double *t, const double *m, int64_t n,
                           const double *periods, int64_t n_periods,
                           double *ell_out, int device);
@@ -370,7 +376,9 @@ int pdc_stringlength_scan_multi(const double *t, const double *m, int64_t n,
  * smoother (Friedman 1984, SLAC PUB-3477: `supsmu` with periodic abscissae, spans 0.05 / 0.2 / 0.5, bass
  * control `alpha` in [0, 10], 0 = off) is fitted to (phase, y), and stat_out[p] = the mean absolute residual
  * about the fit (Reimann 1994): minimal at the period.  Needs n >= 5.  Parity unpinned by the reference; the
- * oracle restates the published Fortran (oracle/scan_oracle.py: supersmoother*).
+ * oracle restates the published Fortran (oracle/scan_oracle.py: supersmoother*) in exact-to-rounding window sums -
+ * for phases crowded into a sliver of the cycle (periods thousands of baselines long) the Fortran's own
+ * double-precision updating formulas lose the windows' variances; the device follows the oracle there, not them.
  * The device form takes resident inputs and a workspace of pdc_supersmoother_work_bytes(n, n_periods) bytes. */
 int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const double *periods, int64_t n_periods,
                            double alpha, double *stat_out, int device);

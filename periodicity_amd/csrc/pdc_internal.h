@@ -59,6 +59,13 @@ int phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, cons
                    const double *d_periods, int64_t n_periods, int nb, int nc, double sigma, double *d_out,
                    void *work, int64_t work_bytes);
 
+// StringLength (kind 3) / Supersmoother (kind 5) for callers that hold the host arrays too (stringlength.hip): whether
+// the streamed kernels will need their bin lists, the workspace with / without them, the scan.
+bool sorted_scan_needs_lists(int kind, const double *t, int64_t n, const double *periods, int64_t n_periods);
+int64_t sorted_scan_work_bytes(int kind, int64_t n, int64_t n_periods, bool lists);
+int sorted_scan_dev(int kind, int device, void *stream, const double *d_t, const double *d_v, int64_t n, const double *d_periods,
+                    int64_t n_periods, double alpha, double *d_out, void *work, int64_t work_bytes, bool lists);
+
 // hipSetDevice + range check; every entry point starts here.
 int use_device(int device);
 

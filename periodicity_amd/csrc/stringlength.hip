@@ -3435,3 +3435,23 @@ int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const do
 }
 
 }  // extern "C"
+
+// The two scans that sort every period by phase, for callers that hold the HOST arrays too (the phase plan of
+// multi.hip): when the host sees that every period will take the slices / one-cycle modes of the streamed kernels the
+// workspace needs no bin lists (~12 GB at a million samples) - what pdc_stringlength_scan / pdc_supersmoother_scan
+// do for themselves.  kind 3 = StringLength, 5 = Supersmoother (alpha).
+namespace pdc {
+bool sorted_scan_needs_lists(int kind, const double *t, int64_t n, const double *periods, int64_t n_periods) {
+    return !host_all_slices(t, n, periods, n_periods, kind == 5 ? (int64_t)4096 : stream_min_n());
+}
+int64_t sorted_scan_work_bytes(int kind, int64_t n, int64_t n_periods, bool lists) {
+    if (n < 0 || n_periods < 0) return -1;
+    return kind == 5 ? ss_shape(n, n_periods, lists).total : stringlength_work_bytes(n, n_periods, lists);
+}
+int sorted_scan_dev(int kind, int device, void *stream, const double *d_t, const double *d_v, int64_t n, const double *d_periods,
+                    int64_t n_periods, double alpha, double *d_out, void *work, int64_t work_bytes, bool lists) {
+    if (kind == 5) return supersmoother_scan_impl(device, stream, d_t, d_v, n, d_periods, n_periods, alpha, d_out, work, work_bytes, lists);
+    return stringlength_scan_impl(device, stream, d_t, d_v, n, d_periods, n_periods, d_out, work, work_bytes, lists);
+}
+}  // namespace pdc
+
