@@ -29,7 +29,7 @@ The product path is the C ABI (libperiodicity_hip.so).  ``oracle/`` is touched o
 
 Every roofline figure in the line means one of two things, and says which:
   * ``executed_issue_frac``: VALU issue cycles per launch / 1024 SIMDs / 2.4 GHz / the HIP-event time of this
-    run, the cycles priced BY INSTRUCTION TYPE from rocprofv3's typed counters (profiles/r04_pmc_summary.json,
+    run, the cycles priced BY INSTRUCTION TYPE from rocprofv3's typed counters (profiles/r05_pmc_summary.json,
     written by tools/pmc_summary.py for the kernel sources whose hash it records - a summary of other sources
     is refused): the fp64 / int64 classes (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, _INT64) at 4 cycles per
     wave64 instruction, every other VALU instruction at 2 (SIMD-32); ``executed_issue.frac_all_at_4_cycles`` is
@@ -66,7 +66,7 @@ SL_MODEL_BYTES_PER_PAIR = 48.0  # HBM bucket-pass model
 HBM_PEAK_TBS = 8.0
 N_SAMPLES = 100_000
 NF_PER_GPU = 1_000_000
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
 GATHER_UBENCH = os.path.join(ROOT, "profiles", "r03_ubench_gather_rate.json")
 
 
