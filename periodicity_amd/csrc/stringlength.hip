@@ -2915,8 +2915,16 @@ SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     // the sorted batch - 16 bytes a point and period - stays within 2 GB (batches of >= 8 periods)
     int64_t cap = ((int64_t)2 << 30) / (16 * (n > 0 ? n : 1));
     cap = cap < 8 ? 8 : cap;
-    static const int64_t env_cap = [] { const char *e = getenv("PDC_SS_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)128; }();
-    cap = cap < env_cap ? cap : env_cap;   // (the bin lists of the streamed sort take ~49 bytes per point and period: 128 periods)
+    // (the bin lists of the streamed sort take ~49 bytes per point and period: ~350 MB of them - 136 periods at
+    // n = 5e4 -, but at least one full sub-batch of the smoother, and the streamed kernels' own 384 from n = 18 000 down)
+    static const int64_t env_cap = [] { const char *e = getenv("PDC_SS_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+    int64_t sub = ((int64_t)3 << 29) / (72 * (n > 0 ? n : 1)) / 8 * 8;     // the smoother's sub-batch (below)
+    const int64_t sub_max = n >= 40000 ? ss2::kSubBatch : (n >= 10000 ? 128 : 384);
+    sub = sub < 8 ? 8 : (sub > sub_max ? sub_max : sub);
+    int64_t list_cap = 7000000 / (n > 0 ? n : 1);
+    list_cap = list_cap < sub ? sub : (list_cap > 384 ? 384 : list_cap / sub * sub);
+    if (env_cap > 0) list_cap = env_cap;
+    cap = cap < list_cap ? cap : list_cap;
     int64_t at = 0;
     if (z.streamed) {
         z.h = stream_shape(n, n_periods < cap ? n_periods : cap, lists);
@@ -2940,15 +2948,20 @@ SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     const int64_t fb_cap = ((int64_t)1 << 30) / (pad_pow2(n) * 12);
     z.grid_fb = (int)(z.grid_fb < fb_cap ? z.grid_fb : (fb_cap < 1 ? 1 : fb_cap));
     z.n_pad = pad_pow2(n);
-    // tiled smoother: sub-batches of <= 64 periods, 72 bytes of intermediates per point and period within 1.5 GB
-    int64_t sb = ((int64_t)3 << 29) / (72 * (n > 0 ? n : 1)) / 8 * 8;
-    sb = sb < 8 ? 8 : (sb > ss2::kSubBatch ? ss2::kSubBatch : sb);
+    // tiled smoother: sub-batches of <= 64 periods from n = 4e4 on (short curves take more per launch - a period of
+    // 4096 points is three tiles), 72 bytes of intermediates per point and period within 1.5 GB
+    int64_t sb = sub < z.batch ? sub : (z.batch + 7) / 8 * 8;
     static const int env_sb = [] { const char *e = getenv("PDC_SS_SB"); return e ? atoi(e) : 0; }();
     static const int env_seg = [] { const char *e = getenv("PDC_SS_SEG"); return e ? atoi(e) : 0; }();
-    if (env_sb >= 8 && env_sb <= ss2::kSubBatch && env_sb % 8 == 0 && env_sb < sb) sb = env_sb;
+    if (env_sb >= 8 && env_sb % 8 == 0 && env_sb < sb) sb = env_sb;
     z.sb = (int)sb;
     const int64_t tiles = (n + ss2::kSegUnit - 1) / ss2::kSegUnit;
-    const int seg_max = env_seg >= 1 && env_seg <= ss2::kSegMax ? env_seg : 8;
+    // one workgroup per CU in the first two sweeps: 256 / sub-batch segments, at least 4 (measured at n = 5e4, 64
+    // periods a sub-batch: 2 / 4 / 8 / 16 segments 37.4 / 26.0 / 28.8 / 31.7 ms - every segment sums its first window
+    // directly, ~15 us of a workgroup's ~60), 16 at n = 1e6 where a sub-batch is 16 periods
+    int seg_rule = (int)((256 + sb - 1) / sb);
+    seg_rule = seg_rule < 4 ? 4 : (seg_rule > ss2::kSegMax ? ss2::kSegMax : seg_rule);
+    const int seg_max = env_seg >= 1 && env_seg <= ss2::kSegMax ? env_seg : seg_rule;
     z.seg = (int)(tiles < seg_max ? (tiles < 1 ? 1 : tiles) : seg_max);
     z.seg_len = (int)((tiles + z.seg - 1) / z.seg * ss2::kSegUnit);
     z.o_sorted = at;
@@ -3391,8 +3404,8 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
             for (int q : {0, 9, 63, 64, 100}) {
                 if (q >= bc) continue;
                 const double *r = &h[(size_t)q * ss2::kSegMax];
-                fprintf(stderr, "dbg sweep %d period %d seg 1 tile 2: loads landed %.0f scans %.0f barrier %.0f fits %.0f stores %.0f barrier %.0f\n", PDC_SS_DBG, q,
-                        r[21] - r[20], r[22] - r[21], r[23] - r[22], r[24] - r[23], r[25] - r[24], r[26] - r[25]);
+                fprintf(stderr, "dbg sweep %d period %d seg 1 tile 2: loads landed %.0f scans %.0f barrier %.0f fits %.0f stores %.0f\n", PDC_SS_DBG, q,
+                        r[21] - r[20], r[22] - r[21], r[23] - r[22], r[24] - r[23], r[25] - r[24]);
             }
         }
 #endif
