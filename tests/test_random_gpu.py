@@ -327,3 +327,44 @@ def test_stringlength_fuzz_around_the_fast_path(seed=5):
         for case in range(60):
             ok, info = fuzz_sl.one_case(rng)
             assert ok, (case, info["n"], info["kind"], info["periods"], info["got"], info["want"])
+
+
+def test_gls_shared_time_axis_random(seed=23):
+    """Batches on ONE time axis (the bootstrap shape) with random sizes: the two-frequencies-per-lane kernel's tile
+    edges (nf mod 128 anywhere), curve counts that leave waves and groups partly empty, odd sample counts (the
+    padding row), individual and equal weights, fit_mean / psd: rows against per-curve calls and the peaks."""
+    rng = np.random.default_rng(seed)
+    for _ in range(4):
+        B, n, nf = int(rng.integers(96, 260)), int(rng.integers(40, 500)), int(rng.integers(1, 900))
+        t = np.sort(rng.uniform(0, rng.uniform(5, 500), n))
+        y = np.sin(2 * np.pi * t / rng.uniform(0.5, 30))[None, :] + rng.standard_normal((B, n))
+        dy = rng.uniform(0.1, 0.5, (B, n)) if rng.random() < 0.6 else None
+        fit_mean, psd = bool(rng.integers(2)), bool(rng.integers(2))
+        f0, delta = rng.uniform(0.001, 0.05), rng.uniform(0.0005, 0.01)
+        offsets = np.arange(B + 1) * n
+        power, amax, argmax = _cabi.gls_scan_batch(t, y.ravel(), None if dy is None else dy.ravel(), offsets, f0, delta, nf,
+                                                   fit_mean, psd, shared_t=True, want_peaks=True)
+        for b in rng.choice(B, 6, replace=False):
+            single = _cabi.gls_scan(t, y[b], None if dy is None else dy[b], f0, delta, nf, fit_mean, psd)
+            np.testing.assert_allclose(power[b], single, rtol=1e-9, atol=1e-12 * np.nanmax(np.abs(single)))
+            assert argmax[b] == np.nanargmax(power[b]) and amax[b] == np.nanmax(power[b])
+
+
+def test_supersmoother_random_cases(seed=29):
+    """The Supersmoother through both smoothers (generic below 4096 samples, tiled above) on random curves: uneven and
+    even sampling, duplicated stamps, Julian offsets, periods from a fraction of the cadence to thousands of baselines,
+    the bass control anywhere in [0, 10]."""
+    rng = np.random.default_rng(seed)
+    for n in (int(rng.integers(5, 60)), int(rng.integers(60, 4096)), int(rng.integers(4096, 9000)), int(rng.integers(9000, 30000))):
+        even = rng.random() < 0.25
+        t = np.arange(float(n)) * 0.1 if even else np.sort(rng.uniform(0, 0.1 * n, n))
+        if rng.random() < 0.5:
+            t = t + 2454953.5
+        if n > 20 and rng.random() < 0.5:
+            t[5:n:7] = t[4:n - 1:7]
+        y = np.sin(2 * np.pi * t / 7.3) + 0.3 * rng.standard_normal(n)
+        base = max(t[-1] - t[0], 1.0)
+        periods = np.concatenate([rng.uniform(0.05, 40.0, 5), base * rng.uniform(0.3, 3000.0, 3), [10.0, 7.3]])
+        alpha = float(rng.choice([0.0, rng.uniform(0.1, 10.0)]))
+        got = _cabi.supersmoother_scan(t, y, periods, alpha)
+        np.testing.assert_allclose(got, so.supersmoother_scan(t, y, periods, alpha), rtol=1e-9, err_msg=f"n={n} even={even} alpha={alpha}")

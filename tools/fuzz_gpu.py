@@ -13,7 +13,8 @@ from tests import test_random_gpu as sweeps  # noqa: E402
 CASES = [sweeps.test_gls_direct_random_cases, sweeps.test_gls_long_curves_on_short_grids_random,
          sweeps.test_gls_batch_random_ragged,
          sweeps.test_gls_fft_random_cases, sweeps.test_pdm_random_cases, sweeps.test_binned_scans_random_cases,
-         sweeps.test_stringlength_random_cases]
+         sweeps.test_stringlength_random_cases, sweeps.test_gls_shared_time_axis_random,
+         sweeps.test_supersmoother_random_cases]
 
 
 def main():
