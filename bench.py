@@ -526,15 +526,28 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
     bss = DB(wss, dev)
     ms = tm.ms(lambda: cabi.check(lib.pdc_supersmoother_scan_dev(dev, stream, bt5.ptr, bx.ptr, n, bp.ptr, n_ss, 0.0, bth.ptr,
                                                                  bss.ptr, wss)), reps=3)
-    ss_hbm = None
+    ss_hbm, ss_sweeps = None, None
     if os.path.isfile(PMC_SUMMARY):
-        kern = json.load(open(PMC_SUMMARY)).get("kernels", {})
-        per = [k for name, k in kern.items() if "ss2_stage_kernel" in name and "hbm_bytes" in k]
-        if len(per) >= 4:      # (each sweep's entry is the mean over its launches of 64 periods)
-            ss_hbm = round(sum(k["hbm_bytes"] for k in per) / 64.0 / 1e6, 2)
+        summ = json.load(open(PMC_SUMMARY))
+        now, then = source_hashes(), summ.get("src_sha", {})
+        fresh = all(now.get(f) == then.get(f) for f in KERNEL_SOURCES["ss_"])
+        per = {name: k for name, k in summ.get("kernels", {}).items() if "ss2_stage_kernel" in name and "hbm_bytes" in k}
+        if len(per) >= 4 and fresh:      # (each sweep's entry is the mean over its launches of 64 periods)
+            ss_hbm = round(sum(k["hbm_bytes"] for k in per.values()) / 64.0 / 1e6, 2)
+            ss_sweeps = {}
+            for name, k in sorted(per.items()):
+                n64 = sum(k.get(c, 0) for c in F64_COUNTERS)
+                cyc = n64 * FP64_ISSUE_CYCLES + (k["SQ_INSTS_VALU"] - n64) * B32_ISSUE_CYCLES
+                ss_sweeps[name.split("ss2::")[-1].split(" grid")[0]] = {
+                    "us_per_launch_of_64_periods": round(k["ms"] * 1e3, 1),
+                    "executed_issue_frac_by_type": round(cyc / SIMDS / CLOCK_HZ / (k["ms"] * 1e-3), 3),
+                    "fp64_share_of_valu": round(n64 / k["SQ_INSTS_VALU"], 3),
+                    "hbm_MB_per_period": round(k["hbm_bytes"] / 64.0 / 1e6, 2),
+                    "hbm_TBps": round(k["hbm_bytes"] / (k["ms"] * 1e-3) / 1e12, 2)}
     out["c5_supersmoother"] = {"ms": round(ms, 3), "Gpair_per_s": round(float(n) * n_ss / ms / 1e6, 2), "n_periods": n_ss,
                                "workspace_MB": round(wss / 1e6, 1),
                                "hbm_MB_per_period_smoother_sweeps": ss_hbm,
+                               "sweeps": ss_sweeps,
                                "algorithmic_MB_per_period": round(208.0 * n / 1e6, 2),
                                "executed_issue_frac": None, "algorithmic_frac": None,
                                "note": "Friedman's variable span smoother on the phase-sorted curve, mean absolute residual "
