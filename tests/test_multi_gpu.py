@@ -15,6 +15,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from oracle import c_oracle as co
 from oracle import scan_oracle as so
 from periodicity_amd import _cabi
 from periodicity_amd.core import TSeries
@@ -143,6 +144,32 @@ def test_phase_plan_all_kinds_and_slot_counts():
     with pytest.raises(ValueError):
         plan.scan("pdm", [1.0, 2.0], 5, 2, 1.0)       # nothing uploaded yet
     plan.close()
+
+
+def test_phase_plan_takes_the_workspace_without_lists_when_the_host_sees_it_can():
+    """the phase plan sized every StringLength / Supersmoother slot for the streamed kernels' bin
+    lists (~12 GB per slot from 262 144 samples on) even for time-ordered input.  The plan holds the host arrays at
+    scan time, so it now runs the host's test (every period takes the slices / one-cycle modes?) per slab and asks
+    for the workspace without lists; unordered samples keep the lists.  Same values either way."""
+    rng = np.random.default_rng(44)
+    n = 300_000
+    t = np.sort(rng.uniform(0, float(n), n))
+    y = np.sin(2 * np.pi * t / 13.7) + 0.2 * rng.standard_normal(n)
+    m = so.stringlength_scale(y)
+    df = 0.1 / (t[-1] - t[0])
+    periods = 1 / np.linspace(64 * df, df, 64)                 # long periods: slices mode throughout
+    one = _cabi.stringlength_scan(t, m, periods)
+    before = _cabi.alloc_counts()
+    two = _cabi.stringlength_scan(t, m, periods, devices=(0, 0))
+    assert np.array_equal(one, two)
+    np.testing.assert_allclose(two[[0, 31, 63]], co.stringlength_scan(t, m, periods[[0, 31, 63]]), rtol=1e-9)
+    assert _cabi.alloc_counts()[0] - before[0] <= 16
+    order = rng.permutation(n)
+    np.testing.assert_allclose(_cabi.stringlength_scan(t[order], m[order], periods[:4], devices=(0, 0)),
+                               co.stringlength_scan(t[order], m[order], periods[:4]), rtol=1e-9)
+    ss_one = _cabi.supersmoother_scan(t[:60_000], y[:60_000], periods[:6] / 50.0, 0.0)
+    ss_two = _cabi.supersmoother_scan(t[:60_000], y[:60_000], periods[:6] / 50.0, 0.0, devices=(0, 0))
+    np.testing.assert_allclose(ss_two, ss_one, rtol=1e-12)
 
 
 def test_cached_fan_out_allocates_nothing_on_the_second_call():
