@@ -233,7 +233,7 @@ int pdc_gls_batch_highest_peak(const double *t, const double *y, const double *d
                                double f0, double delta, int64_t nf, int fit_mean, int psd,
                                int64_t *idx_out, double *val_out, int device);
 
-/* The k <= 64 highest (by_prominence == 0: FSeries.psort_by_peak, core.py:944-946) or most prominent
+/* The k <= 1024 highest (by_prominence == 0: FSeries.psort_by_peak, core.py:944-946) or most prominent
  * (psort_by_prominence :948-950, period_at_highest_prominence :957-961) find_peaks() maxima of each
  * spectrum, found and ranked on the device: count[b] = number of maxima scipy.signal.find_peaks(x,
  * prominence=0.0) reports; idx/height/prominence are [n_curves][k], ranked descending, padded with
@@ -244,6 +244,9 @@ int pdc_gls_batch_highest_peak(const double *t, const double *y, const double *d
  * as an absolute bin (np.where(np.diff(np.signbit(..))), core.py:362); the method returns
  * (period[half_lo], period[half_hi]).  Exactly equal keys rank the lower bin first (upstream's argsort()[::-1]
  * leaves ties to numpy's unstable sort: see INTEGRATION.md).
+ * k > 64 runs as launches of 64 ranks, each ranking what comes AFTER the launch before's last winner in that total
+ * order (every launch sweeps the spectra again: ~0.5 ms per 64 ranks for 4096 spectra of 5e4 bins); it needs idx_out
+ * and the ranking key's output (height_out, or prominence_out).  The host methods of FSeries serve any k.
  * pdc_gls_batch_peaks runs the batched periodogram first; the spectra never leave HBM. */
 int pdc_peaks_topk(const double *power, int64_t n_curves, int64_t nf, int k, int by_prominence,
                    int64_t *count_out, int64_t *idx_out, double *height_out, double *prominence_out,

@@ -455,7 +455,7 @@ def _topk_outputs(nb, k):
 
 
 def peaks_topk(power, k=1, by_prominence=False, device=None):
-    """The ``k`` (<= 64) highest, or most prominent, ``find_peaks`` maxima of each row of ``power`` with
+    """The ``k`` (<= 1024; beyond 64 in launches of 64 ranks) highest, or most prominent, ``find_peaks`` maxima of each row of ``power`` with
     prominences and half-maximum crossings (``pdc_peaks_topk``); a dict of arrays shaped ``[rows, k]``
     (``count``: ``[rows]``), ranked descending, padded with -1 / NaN."""
     power = np.ascontiguousarray(power, dtype=np.float64)

@@ -136,7 +136,8 @@ constexpr int kPkBlock = 256;
 #define PDC_PK_WAVES 5
 #endif
 constexpr int kPkMaxBlocks = 4096;   // LDS: two doubles per block
-constexpr int kPkMaxK = 64;
+constexpr int kPkMaxK = 64;          // ranked peaks per launch
+constexpr int kPkMaxKTotal = 1024;   // ... per call: chunks of 64, each launch ranking what comes AFTER the chunk before
 constexpr int kPkPre = 68;           // by prominence: the first walks go to the k + 4 highest maxima
 constexpr int kPkChunk = 1024;       // bins per sweep step
 constexpr int kPkFusedShift = 8;     // 256-bin blocks = one wave's stretch of a chunk: extrema come with the sweep
@@ -147,6 +148,8 @@ struct PeakArgs {
     const double *power;
     int64_t nf;
     int k, by_prominence, blk_shift;
+    int k_total, k_off;   // the outputs are [rows][k_total]; this launch fills columns k_off .. k_off + k - 1 and ranks
+                          // only what comes after column k_off - 1 in the total order (key descending, bin ascending)
     int64_t nblk, tile;
     long long *count, *idx, *half_lo, *half_hi;
     double *height, *prom;
@@ -297,6 +300,9 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
         }
         __syncthreads();
     };
+    const bool excl = a.k_off > 0;
+    double prev_key = inf;
+    long long prev_idx = -1;
     // The m best candidates (by height or by prominence; ties: lower bin first; the same bin only once)
     // into win_*[0 .. m), by m rounds of "best entry strictly after the previous winner"; the list is then
     // cut down to those.  Returns how many there are.
@@ -304,6 +310,12 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
         const int n = s_ncand;
         double pk = inf;          // previous winner (key, bin): everything is "after" (+inf, -1)
         long long pidx = -1;
+        // a later chunk of a call with k > 64: rankings by the call's own key start after the chunk before's last winner
+        const bool ex = excl && by_prom == (a.by_prominence != 0);
+        if (ex) {
+            pk = prev_key;
+            pidx = prev_idx;
+        }
         int found = 0;
         for (int round = 0; round < m; ++round) {
             double wk = 0.0;
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
             for (int e = tid; e < n; e += kPkBlock) {
                 const double key = by_prom ? cp[e] : ch[e];
                 const long long bin = ci[e];
-                const bool after = round == 0 || key < pk || (key == pk && bin > pidx);
+                const bool after = (round == 0 && !ex) || key < pk || (key == pk && bin > pidx);
                 if (after && cand_before(key, bin, wk, wi)) {
                     wk = key;
                     wi = bin;
@@ -513,6 +525,21 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
 
     const int K = a.k < kPkMaxK ? a.k : kPkMaxK;
     const int pre = K + 4;   // by prominence: the first walks go to the `pre` highest maxima
+    const int64_t ob = (int64_t)blockIdx.x * a.k_total + a.k_off;
+    if (excl) {
+        prev_key = (a.by_prominence ? a.prom : a.height)[ob - 1];
+        prev_idx = a.idx[ob - 1];
+        if (prev_idx < 0) {   // (workgroup-uniform) the chunk before already ran out of peaks
+            if (tid < a.k) {
+                if (a.idx) a.idx[ob + tid] = -1;
+                if (a.height) a.height[ob + tid] = __builtin_nan("");
+                if (a.prom) a.prom[ob + tid] = __builtin_nan("");
+                if (a.half_lo) a.half_lo[ob + tid] = -1;
+                if (a.half_hi) a.half_hi[ob + tid] = -1;
+            }
+            return;
+        }
+    }
     static_assert(kPkMaxK + 4 <= kPkPre && kPkPre <= kPkCap / 4, "win_* and the candidate list hold the first walks");
     sweep(std::true_type{}, a.by_prominence ? pre : K);
     // lowest sample of the row (NaN aside): prominence <= height - row_min
@@ -543,7 +570,6 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
         nwin = rank_candidates(K, true);
     }
     __syncthreads();
-    const int64_t ob = (int64_t)blockIdx.x * a.k;
     if (tid == 0) {
         long long total = 0;
         for (int w = 0; w < kPkBlock / 64; ++w) total += s_count[w];
@@ -685,7 +711,10 @@ int pdc_peaks_topk_dev(int device, void *stream, const double *d_power, int64_t 
                        int k, int by_prominence, int64_t *d_count, int64_t *d_idx, double *d_height,
                        double *d_prominence, int64_t *d_half_lo, int64_t *d_half_hi) {
     PDC_REQUIRE(d_power || n_curves * nf == 0, "peaks_topk: power is NULL");
-    PDC_REQUIRE(k >= 1 && k <= kPkMaxK, "peaks_topk: k must be 1..%d", kPkMaxK);
+    PDC_REQUIRE(k >= 1 && k <= kPkMaxKTotal, "peaks_topk: k must be 1..%d", kPkMaxKTotal);
+    PDC_REQUIRE(k <= kPkMaxK || (d_idx && (by_prominence ? d_prominence != nullptr : d_height != nullptr)),
+                "peaks_topk: k > %d is ranked in chunks of %d, each after the chunk before: the indices and the ranking key's "
+                "output (heights, or prominences) must be requested", kPkMaxK, kPkMaxK);
     PDC_REQUIRE(n_curves >= 0 && nf >= 0 && n_curves < ((int64_t)1 << 31), "peaks_topk: bad size");
     PDC_REQUIRE(d_count || d_idx || d_height || d_prominence || d_half_lo || d_half_hi,
                 "peaks_topk: no output requested");
@@ -702,7 +731,16 @@ int pdc_peaks_topk_dev(int device, void *stream, const double *d_power, int64_t 
     a.half_hi = (long long *)d_half_hi;
     a.height = d_height;
     a.prom = d_prominence;
-    return launch_topk((hipStream_t)stream, a, n_curves);
+    a.k_total = k;
+    // k > 64: one launch per 64 ranks; launch c ranks what comes after column 64 c - 1 of the outputs (every launch
+    // sweeps the spectra again: 0.4-0.6 ms per 64 ranks for the 1.64 GB of a C3 batch)
+    for (int off = 0; off < k; off += kPkMaxK) {
+        a.k = k - off < kPkMaxK ? k - off : kPkMaxK;
+        a.k_off = off;
+        a.count = off == 0 ? (long long *)d_count : nullptr;
+        PDC_TRY(launch_topk((hipStream_t)stream, a, n_curves));
+    }
+    return PDC_OK;
 }
 
 namespace {
@@ -735,7 +773,7 @@ int pdc_peaks_topk(const double *power, int64_t n_curves, int64_t nf, int k, int
                    int64_t *count_out, int64_t *idx_out, double *height_out, double *prominence_out,
                    int64_t *half_lo_out, int64_t *half_hi_out, int device) {
     PDC_REQUIRE(power || n_curves * nf == 0, "peaks_topk: power is NULL");
-    PDC_REQUIRE(k >= 1 && k <= kPkMaxK, "peaks_topk: k must be 1..%d", kPkMaxK);
+    PDC_REQUIRE(k >= 1 && k <= kPkMaxKTotal, "peaks_topk: k must be 1..%d", kPkMaxKTotal);
     PDC_REQUIRE(n_curves >= 0 && nf >= 0, "peaks_topk: negative size");
     PDC_REQUIRE(count_out || idx_out || height_out || prominence_out || half_lo_out || half_hi_out,
                 "peaks_topk: no output requested");
@@ -760,7 +798,7 @@ int pdc_gls_batch_peaks(const double *t, const double *y, const double *dy, cons
                         int64_t *half_hi_out, int device) {
     PDC_REQUIRE(t && y && offsets, "gls_batch_peaks: NULL argument");
     PDC_REQUIRE(n_curves >= 1 && nf >= 0, "gls_batch_peaks: bad size");
-    PDC_REQUIRE(k >= 1 && k <= kPkMaxK, "gls_batch_peaks: k must be 1..%d", kPkMaxK);
+    PDC_REQUIRE(k >= 1 && k <= kPkMaxKTotal, "gls_batch_peaks: k must be 1..%d", kPkMaxKTotal);
     for (int64_t b = 0; b < n_curves; ++b) {
         PDC_REQUIRE(offsets[b + 1] >= offsets[b], "gls: offsets must be non-decreasing");
         PDC_REQUIRE(!shared_t || offsets[b + 1] - offsets[b] == offsets[1] - offsets[0],

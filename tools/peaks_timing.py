@@ -29,9 +29,9 @@ _cabi.check(lib.pdc_stream_create(dev, C.byref(sp)))
 tm = bench.EventTimer(lib, _cabi, dev, sp.value)
 _cabi.check(lib.pdc_gls_scan_dev(dev, sp.value, bt.ptr, by.ptr, bdy.ptr, boff.ptr, B * n, B, 0, g0, gd, 0, nf, 1, 0,
                                  power.ptr, None, None, work.ptr, wb))
-out = DB(B * 64 * 8, dev)
+out = DB(B * (1 + 5 * 256) * 8, dev)
 print("highest_peak ms", tm.ms(lambda: _cabi.check(lib.pdc_highest_peak_dev(dev, sp.value, power.ptr, B, nf, out.ptr, out.ptr + B * 8))))
-for k in (1, 4, 8):
+for k in (1, 4, 8, 64, 128, 256):
     for bp in (0, 1):
         p = out.ptr
         ms = tm.ms(lambda: _cabi.check(lib.pdc_peaks_topk_dev(dev, sp.value, power.ptr, B, nf, k, bp, p, p + B * 8, p + B * 8 * (1 + 3 * k),
