@@ -137,7 +137,11 @@ constexpr int kPkBlock = 256;
 #endif
 constexpr int kPkMaxBlocks = 4096;   // LDS: two doubles per block
 constexpr int kPkMaxK = 64;          // ranked peaks per launch
-constexpr int kPkMaxKTotal = 1024;   // ... per call: chunks of 64, each launch ranking what comes AFTER the chunk before
+constexpr int kPkMaxKTotal = 1024;
+#ifndef PDC_PK_SORT_FROM
+#define PDC_PK_SORT_FROM 16
+#endif
+constexpr int kPkSortFrom = PDC_PK_SORT_FROM;      // rankings of more than this many entries sort the candidate list instead of m reduction rounds   // ... per call: chunks of 64, each launch ranking what comes AFTER the chunk before
 constexpr int kPkPre = 68;           // by prominence: the first walks go to the k + 4 highest maxima
 constexpr int kPkChunk = 1024;       // bins per sweep step
 constexpr int kPkFusedShift = 8;     // 256-bin blocks = one wave's stretch of a chunk: extrema come with the sweep
@@ -175,6 +179,9 @@ __device__ __forceinline__ bool cand_before(double ka, long long ia, double kb, 
     return ib < 0 || (ia >= 0 && (ka > kb || (ka == kb && ia < ib)));
 }
 
+// SORT: the instance for launches of more than kPkSortFrom ranks (its rankings sort the candidate list; four more
+// registers, five workgroups per CU instead of six - which cost the few-ranks launches 10 %, so they keep their own)
+template <bool SORT>
 __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *bmin = reinterpret_cast<double *>(lds_raw);   // [nblk]
@@ -317,6 +324,71 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
             pidx = prev_idx;
         }
         int found = 0;
+        if (SORT && m > kPkSortFrom) {
+            // Many ranks (a launch of a k > 16 call): the rounds below cost a block reduction each - 68 of them ~0.3 ms per
+            // ranking.  Instead the whole list is sorted in LDS (bitonic, by key descending then bin ascending; unused
+            // slots last), duplicates of a bin and entries not after the previous chunk's last winner are dropped,
+            // and the first m that remain are the winners: ~55 compare-exchange steps for a full list.
+            int P = 2;
+            while (P < n) P <<= 1;
+            for (int e = n + tid; e < P; e += kPkBlock) {
+                ci[e] = -1;
+                ch[e] = -inf;
+                cp[e] = -inf;
+            }
+            __syncthreads();
+            for (int kk = 2; kk <= P; kk <<= 1) {
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    for (int c = tid; c < (P >> 1); c += kPkBlock) {
+                        const int i = ((c & ~(j - 1)) << 1) | (c & (j - 1)), l = i | j;
+                        const double ka = by_prom ? cp[i] : ch[i], kb = by_prom ? cp[l] : ch[l];
+                        const int ia = ci[i], ib = ci[l];
+                        // (a NaN key - none is expected here - sorts with the unused slots' -inf)
+                        const bool b_first = cand_before(kb == kb ? kb : -inf, ib, ka == ka ? ka : -inf, ia);
+                        const bool up = (i & kk) == 0;
+                        if (b_first == up && !(ia == ib && ka == kb)) {
+                            const double ha = ch[i], pa = cp[i];
+                            ch[i] = ch[l];
+                            cp[i] = cp[l];
+                            ci[i] = ib;
+                            ch[l] = ha;
+                            cp[l] = pa;
+                            ci[l] = ia;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            int taken = 0;                                       // winners so far (workgroup-uniform)
+            for (int base = 0; base < n && taken < m; base += kPkBlock) {
+                const int e = base + tid;
+                bool ok = false;
+                double key = 0.0;
+                long long bin = -1;
+                if (e < n) {
+                    key = by_prom ? cp[e] : ch[e];
+                    bin = ci[e];
+                    ok = bin >= 0 && (e == 0 || ci[e - 1] != (int)bin) && (!ex || key < pk || (key == pk && bin > pidx));
+                }
+                const unsigned long long mask = __ballot(ok);
+                if (lane == 0) red_e[wave] = __builtin_popcountll(mask);
+                __syncthreads();
+                int rank = taken + __builtin_popcountll(mask & ((1ull << lane) - 1ull)), total = 0;
+                for (int w = 0; w < kPkBlock / 64; ++w) {
+                    if (w < wave) rank += red_e[w];
+                    total += red_e[w];
+                }
+                if (ok && rank < m) {
+                    win_key[rank] = key;
+                    win_idx[rank] = bin;
+                    win_h[rank] = ch[e];
+                    win_p[rank] = cp[e];
+                }
+                taken += total;
+                __syncthreads();
+            }
+            found = taken < m ? taken : m;
+        } else
         for (int round = 0; round < m; ++round) {
             double wk = 0.0;
             long long wi = -1;
@@ -699,8 +771,13 @@ int launch_topk(hipStream_t st, PeakArgs a, int64_t n_curves) {
     a.tile = 0;
     const size_t lds = (size_t)(a.nblk > 0 ? a.nblk : 1) * 16 + (size_t)kPkCap * 20 + 16;
     PDC_REQUIRE(lds <= 150 * 1024, "peaks_topk: %lld bins per spectrum need %zu bytes of LDS", (long long)a.nf, lds);
-    PDC_TRY(allow_dynamic_lds((const void *)peaks_topk_kernel, 150 * 1024));
-    hipLaunchKernelGGL(peaks_topk_kernel, dim3((unsigned)n_curves), dim3(kPkBlock), lds, st, a);
+    if (a.k > kPkSortFrom) {
+        PDC_TRY(allow_dynamic_lds((const void *)peaks_topk_kernel<true>, 150 * 1024));
+        hipLaunchKernelGGL(peaks_topk_kernel<true>, dim3((unsigned)n_curves), dim3(kPkBlock), lds, st, a);
+    } else {
+        PDC_TRY(allow_dynamic_lds((const void *)peaks_topk_kernel<false>, 150 * 1024));
+        hipLaunchKernelGGL(peaks_topk_kernel<false>, dim3((unsigned)n_curves), dim3(kPkBlock), lds, st, a);
+    }
     PDC_HIP(hipGetLastError());
     return PDC_OK;
 }
