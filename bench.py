@@ -1168,8 +1168,10 @@ def main():
 
     torch = dist = None
     dist_backend, dist_error = None, None
+    # (the host driver of this pool only supports dmabuf IPC: RCCL between processes - and, to be safe, between the
+    # devices of one process - needs it set before anything initialises HIP)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if dist_mode:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
