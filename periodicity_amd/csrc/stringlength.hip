@@ -786,6 +786,7 @@ struct FastArgs {
     const unsigned char *todo;  // NULL, or [n_periods]: only periods with a non-zero entry are worked off
     const unsigned *todo_count; // (with todo) how many entries are non-zero: 0 ends every workgroup at once
     const unsigned char *skip;  // NULL, or [n_periods]: periods with a non-zero entry are done already (one cycle)
+    rec_t *sorted;              // (EMIT instances) [n_periods][n]: every period's (phase, m) in sorted order
 };
 
 // RN(t / period) without the division: y = RN(1 / period); q0 = RN(t y) is within 1.5 ulp of the
@@ -928,7 +929,10 @@ __device__ __forceinline__ void phases4(const double (&t)[4], double period, dou
 // entry plus PL bits in planes beside it (an LDS atomic OR per set bit): 2.125 / 2.25 bytes per entry instead of 4,
 // i.e. slices of ~45 000 / ~42 700 samples instead of 23 976 - the reference's SunSpots curve (74 326) takes two
 // slices instead of four.
-template <int KMAX, typename IdxT = unsigned short, int NB = kNB, bool MULTI = false, int PL = 0>
+// EMIT: besides the length, the sorted curve itself goes to a.sorted - the Supersmoother's sort below 262 144 samples
+// (one workgroup sorts a period of 5e4 samples in 69 us: 4096 periods 1.1 ms, where the streamed kernels - built for
+// curves that outgrow L2 - took 6.3).  Its own instances: the StringLength instances keep their registers.
+template <int KMAX, typename IdxT = unsigned short, int NB = kNB, bool MULTI = false, int PL = 0, bool EMIT = false>
 __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
     constexpr bool P17 = PL > 0;
     static_assert(PL >= 0 && PL <= 2 && (!P17 || (MULTI && sizeof(IdxT) == 4)), "the bit planes belong to the several-slice instance");
@@ -1159,6 +1163,15 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                 __syncthreads();
                 bitonic_sort<unsigned>(gk, gi, P);
                 total += segment_sum(gk, gi, cnt, a.m);
+                if (EMIT) {
+                    rec_t *const row = a.sorted + p * a.n;
+                    for (int s = tid; s < cnt; s += kBlock) {
+                        rec_t o;
+                        o.x = __longlong_as_double((long long)gk[s]);
+                        o.y = a.m[gi[s]];
+                        row[consumed + s] = o;
+                    }
+                }
                 if (tid == 0) {
                     rsum[(int64_t)r_base * 4 + 0] = __longlong_as_double((long long)gk[0]);
                     rsum[(int64_t)r_base * 4 + 1] = a.m[gi[0]];
@@ -1243,6 +1256,9 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
         continue;
 #endif
         // ---- P3a: wave-autonomous ranges -------------------------------------------------------------
+        constexpr bool kEmitSorted = EMIT;
+        rec_t *const emit_row = EMIT ? a.sorted + p * a.n : nullptr;
+        const int emit_at = consumed;
 #include "sl_ranges.inc"
         if (wave < nranges) request(wave);
         for (int r = wave; r < nranges; r = r_next) {
@@ -1275,6 +1291,13 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                     __syncthreads();
                     bitonic_sort<IdxT>(bkeys, bidx, P);
                     total += segment_sum(bkeys, bidx, cnt, a.m);
+                    if (EMIT)
+                        for (int s = tid; s < cnt; s += kBlock) {
+                            rec_t o;
+                            o.x = __longlong_as_double((long long)bkeys[s]);
+                            o.y = a.m[bidx[s]];
+                            emit_row[consumed + s_lo + s] = o;
+                        }
                     p0 = __longlong_as_double((long long)bkeys[0]);
                     m0 = a.m[bidx[0]];
                     p1 = __longlong_as_double((long long)bkeys[cnt - 1]);
@@ -1293,6 +1316,13 @@ __global__ __launch_bounds__(kBlock) void sl_fast_kernel(FastArgs a) {
                     __syncthreads();
                     bitonic_sort<unsigned>(gk, gi, P);
                     total += segment_sum(gk, gi, cnt, a.m);
+                    if (EMIT)
+                        for (int s = tid; s < cnt; s += kBlock) {
+                            rec_t o;
+                            o.x = __longlong_as_double((long long)gk[s]);
+                            o.y = a.m[gi[s]];
+                            emit_row[consumed + s_lo + s] = o;
+                        }
                     p0 = __longlong_as_double((long long)gk[0]);
                     m0 = a.m[gi[0]];
                     p1 = __longlong_as_double((long long)gk[cnt - 1]);
@@ -1561,6 +1591,9 @@ __global__ __launch_bounds__(BLK, 4) void sl_duo_kernel(DuoArgs a) {
         constexpr int NB = NBL;
         const int r_base = 0;
 #define PDC_ORDER_GET(pos) ((unsigned)order[pos])
+        constexpr bool kEmitSorted = false;
+        rec_t *const emit_row = nullptr;
+        const int emit_at = 0;
 #include "sl_ranges.inc"
 #undef PDC_ORDER_GET
         if (wave < nranges) request(wave);
@@ -2901,16 +2934,121 @@ int stream_allow_lds(const StreamShape &h) {
 }
 
 // ---- Supersmoother: workspace -----------------------------------------------------------------------------
+template <int KMAX, typename IdxT = unsigned short, int NB = fast::kNB, bool MULTI = false, int PL = 0, bool EMIT = false>
+int launch_fast(const fast::FastArgs &a, int64_t grid, hipStream_t st) {
+    constexpr bool P17 = PL > 0;
+    const int64_t slice = MULTI ? a.slice_cap : a.n;
+    const int64_t entries = (slice + 64 + 7) & ~(int64_t)7;
+    const size_t lds = (size_t)fast::FL<IdxT>::fixed +
+                       (P17 ? (size_t)entries * 2 + (size_t)PL * ((slice + 64 + 31) / 32) * 4 + 16 : (size_t)entries * sizeof(IdxT));
+    PDC_REQUIRE(lds <= (size_t)fast::kLdsTotalDyn, "stringlength: slice of %lld samples does not fit LDS", (long long)slice);
+    PDC_TRY(allow_dynamic_lds((const void *)fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI, PL, EMIT>, fast::kLdsTotalDyn));
+    hipLaunchKernelGGL((fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI, PL, EMIT>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    return PDC_OK;
+}
+
+// ---- the one-workgroup-per-period kernels as a SORT (EMIT instances of sl_fast_kernel): the Supersmoother's sorted
+// curves below the streamed kernels' range.  Workspace per batch: the kernels' scratch for grid_for(batch)
+// workgroups, the (t, y) table, the one-cycle marks, a dummy length per period.
+bool fast_sort_takes(int64_t n) {
+    static const int max_slices = [] { const char *e = getenv("PDC_SL_FAST_SLICES"); return e ? atoi(e) : 16; }();
+    static const bool on = [] { const char *e = getenv("PDC_SS_FASTSORT"); return !(e && e[0] == '0'); }();
+    return on && n >= 64 && n < stream_min_n() && n <= max_slices * (int64_t)fast::FL<unsigned>::capacity;
+}
+int64_t fast_sort_bytes(int64_t n, int64_t batch) {
+    const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
+    return scratch_bytes(n, batch, partition) + fast_table_bytes(n) + onecycle_bytes(batch) + ((batch * 8 + 255) & ~(int64_t)255) + 256;
+}
+// once per call: the AoS (t, y) table + its flags
+void fast_sort_prepare(hipStream_t st, const double *d_t, const double *d_y, int64_t n, int64_t batch, void *work) {
+    const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
+    char *table = static_cast<char *>(work) + scratch_bytes(n, batch, partition);
+    hipLaunchKernelGGL(fast::sl_prep_kernel, dim3(1), dim3(kBlock), 0, st, d_t, d_y, (int)n, reinterpret_cast<fast::rec_t *>(table),
+                       reinterpret_cast<unsigned *>(table + ((n * 16 + 255) & ~(int64_t)255)));
+}
+// one batch: periods d_periods[0 .. bc) -> sorted[q][n]; skip_out = the one-cycle marks (those rows are NOT written here)
+int fast_sort_batch(hipStream_t st, const double *d_t, const double *d_y, int64_t n, const double *d_periods, int64_t bc,
+                    int64_t batch, const unsigned *bad, fast::rec_t *sorted, void *work, const unsigned char **skip_out) {
+    const int64_t grid = grid_for(bc);
+    const int64_t n_pad = pad_pow2(n), nr_pad = range_slots(n);
+    const int64_t gridc = grid_for(batch);            // (the layout is that of a full batch)
+    const int64_t partition = may_need_partition(n) ? n_pad * 4 + kBucketsLarge * 4 : 0;
+    fast::FastArgs f;
+    f.t = d_t;
+    f.m = d_y;
+    f.periods = d_periods;
+    f.n = n;
+    f.n_periods = bc;
+    f.n_pad = n_pad;
+    f.nr_pad = nr_pad;
+    f.gkeys = reinterpret_cast<unsigned long long *>(work);
+    f.rsum = reinterpret_cast<double *>(f.gkeys + gridc * n_pad);
+    f.gidx = reinterpret_cast<unsigned *>(f.rsum + gridc * nr_pad * 4);
+    f.rcnt = reinterpret_cast<int *>(f.gidx + gridc * n_pad);
+    f.rlen = reinterpret_cast<double *>(f.rcnt + gridc * nr_pad);
+    unsigned *gorder = reinterpret_cast<unsigned *>(f.rlen + gridc * nr_pad);
+    f.ghist = gorder + (may_need_partition(n) ? gridc * n_pad : 0);
+    f.gbucket = reinterpret_cast<unsigned short *>(gorder);
+    char *table = static_cast<char *>(work) + scratch_bytes(n, batch, partition);
+    f.rec = reinterpret_cast<const fast::rec_t *>(table);
+    f.flags = reinterpret_cast<const unsigned *>(table + ((n * 16 + 255) & ~(int64_t)255));
+    char *oc = table + fast_table_bytes(n);
+    onecycle::OneArgs o;
+    o.t = d_t;
+    o.m = d_y;
+    o.periods = d_periods;
+    o.n = n;
+    o.n_periods = bc;
+    o.bad = bad;
+    o.skip = reinterpret_cast<unsigned char *>(oc);
+    o.list = reinterpret_cast<unsigned *>(oc + ((batch + 255) & ~(int64_t)255));
+    o.count = reinterpret_cast<unsigned *>(oc + ((batch + 255) & ~(int64_t)255) + ((batch * 4 + 255) & ~(int64_t)255));
+    o.ell = nullptr;
+    PDC_HIP(hipMemsetAsync(o.count, 0, 256, st));
+    hipLaunchKernelGGL(onecycle::sl_onecycle_mark_kernel, dim3((unsigned)((bc + 255) / 256)), dim3(256), 0, st, o);
+    f.ell = reinterpret_cast<double *>(oc + onecycle_bytes(batch));
+    f.todo = nullptr;
+    f.todo_count = nullptr;
+    f.skip = o.skip;
+    f.sorted = sorted;
+    f.slice_cap = fast::FL<unsigned>::capacity;
+    *skip_out = o.skip;
+    const int k = (int)((n + kBlock - 1) / kBlock);
+    if (n > fast::kCapacity && n < 65536) {
+        f.slice_cap = fast::FL<unsigned short>::capacity;
+        PDC_TRY((launch_fast<4, unsigned short, fast::kNBLarge, true, 0, true>(f, grid, st)));
+    } else if (n > fast::kCapacity && n < 131072) {
+        f.slice_cap = fast::kCapacity17;
+        PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true, 1, true>(f, grid, st)));
+    } else if (n > fast::kCapacity && n < 262144) {
+        f.slice_cap = fast::kCapacity18;
+        PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true, 2, true>(f, grid, st)));
+    } else if (n > fast::kCapacity) {
+        PDC_TRY((launch_fast<4, unsigned, fast::kNBLarge, true, 0, true>(f, grid, st)));
+    } else if (k <= 8) {
+        PDC_TRY((launch_fast<8, unsigned short, fast::kNB, false, 0, true>(f, grid, st)));
+    } else if (k <= 20) {
+        PDC_TRY((launch_fast<20, unsigned short, fast::kNB, false, 0, true>(f, grid, st)));
+    } else if (k <= 36) {
+        PDC_TRY((launch_fast<36, unsigned short, fast::kNB, false, 0, true>(f, grid, st)));
+    } else {
+        PDC_TRY((launch_fast<fast::kKMax, unsigned short, fast::kNB, false, 0, true>(f, grid, st)));
+    }
+    return PDC_OK;
+}
+
 struct SsShape {
     StreamShape h;
-    bool streamed, tiled;
+    bool streamed, tiled, fastsort;
     int batch, grid_ss, grid_fb, sb, seg, seg_len;
-    int64_t stride, n_pad, o_sorted, o_scratch, o_gk, o_gi, o_bad, o_sm, o_arec, o_srec, o_flag, o_part, total;
+    int64_t stride, n_pad, o_sorted, o_scratch, o_gk, o_gi, o_bad, o_sm, o_arec, o_srec, o_flag, o_part, o_fast, total;
 };
 SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
     SsShape z;
-    z.streamed = n >= 4096 && n <= kStreamMaxN;
+    z.fastsort = fast_sort_takes(n);
+    z.o_fast = 0;
+    z.streamed = !z.fastsort && n >= 4096 && n <= kStreamMaxN;
     z.tiled = n >= ss2::kMinN && n <= ss2::kMaxN;
     // the sorted batch - 16 bytes a point and period - stays within 2 GB (batches of >= 8 periods)
     int64_t cap = ((int64_t)2 << 30) / (16 * (n > 0 ? n : 1));
@@ -2923,6 +3061,15 @@ SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     sub = sub < 8 ? 8 : (sub > sub_max ? sub_max : sub);
     int64_t list_cap = 7000000 / (n > 0 ? n : 1);
     list_cap = list_cap < sub ? sub : (list_cap > 384 ? 384 : list_cap / sub * sub);
+    if (z.fastsort) {
+        // (no lists: one workgroup per period - 256 periods a launch fill the CUs - within ~600 MB of sorted curves
+        // + the kernels' per-workgroup scratch, and at least one sub-batch of the smoother)
+        const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
+        const int64_t per = 16 * n + pad_pow2(n) * 12 + range_slots(n) * 44 + partition;
+        int64_t b = ((int64_t)600 << 20) / per;
+        b = b > 256 ? 256 : b;
+        list_cap = b / sub * sub > 0 ? b / sub * sub : sub;
+    }
     if (env_cap > 0) list_cap = env_cap;
     cap = cap < list_cap ? cap : list_cap;
     int64_t at = 0;
@@ -2935,6 +3082,10 @@ SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
         int64_t b = n_periods < 512 ? n_periods : 512;
         b = b < cap ? b : cap;
         z.batch = (int)(b < 1 ? 1 : b);
+        if (z.fastsort) {
+            z.o_fast = 0;
+            at = (fast_sort_bytes(n, z.batch) + 255) & ~(int64_t)255;
+        }
     }
     z.stride = (n + n / 2 + 24 + 7) & ~(int64_t)7;   // (prefix arrays run over the curve extended by a quarter on either side)
     // The generic smoother (ss_smooth_kernel: fifteen arrays of 1.5 n doubles per workgroup) is the whole path below
@@ -2943,6 +3094,7 @@ SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     g = g < 1 ? 1 : (g > (z.tiled ? 16 : 512) ? (z.tiled ? 16 : 512) : g);
     z.grid_ss = (int)(g < z.batch ? g : z.batch);
     z.grid_fb = z.batch < (z.streamed ? 64 : 256) ? z.batch : (z.streamed ? 64 : 256);
+    if (z.fastsort) z.grid_fb = 1;   // (the whole-period bitonic fallback is not used)
     // Periods whose phases cluster are sorted by one workgroup each in global scratch (12 bytes a padded point): the
     // pool of such workgroups stays within 1 GB
     const int64_t fb_cap = ((int64_t)1 << 30) / (pad_pow2(n) * 12);
@@ -2978,18 +3130,6 @@ SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     return z;
 }
 
-template <int KMAX, typename IdxT = unsigned short, int NB = fast::kNB, bool MULTI = false, int PL = 0>
-int launch_fast(const fast::FastArgs &a, int64_t grid, hipStream_t st) {
-    constexpr bool P17 = PL > 0;
-    const int64_t slice = MULTI ? a.slice_cap : a.n;
-    const int64_t entries = (slice + 64 + 7) & ~(int64_t)7;
-    const size_t lds = (size_t)fast::FL<IdxT>::fixed +
-                       (P17 ? (size_t)entries * 2 + (size_t)PL * ((slice + 64 + 31) / 32) * 4 + 16 : (size_t)entries * sizeof(IdxT));
-    PDC_REQUIRE(lds <= (size_t)fast::kLdsTotalDyn, "stringlength: slice of %lld samples does not fit LDS", (long long)slice);
-    PDC_TRY(allow_dynamic_lds((const void *)fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI, PL>, fast::kLdsTotalDyn));
-    hipLaunchKernelGGL((fast::sl_fast_kernel<KMAX, IdxT, NB, MULTI, PL>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
-    return PDC_OK;
-}
 
 }  // namespace
 
@@ -3186,6 +3326,7 @@ int stringlength_scan_impl(int device, void *stream, const double *d_t, const do
         f.todo = nullptr;
         f.todo_count = nullptr;
         f.skip = a.skip;
+        f.sorted = nullptr;
         // Two workgroups per CU (sl_duo_kernel) whenever a period's permutation fits half of LDS;
         // PDC_SL_DUO=0 keeps the one-workgroup kernel (A/B, tests)
         static const bool duo_on = [] { const char *e = getenv("PDC_SL_DUO"); return !(e && e[0] == '0'); }();
@@ -3349,6 +3490,8 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
     fa.n = n;
     fa.n_pad = z.n_pad;
     fa.flag = z.streamed ? sa.flag : nullptr;
+    fa.skip8 = nullptr;
+    if (z.fastsort) fast_sort_prepare(st, d_t, d_y, n, z.batch, base + z.o_fast);
     fa.gkeys = reinterpret_cast<unsigned long long *>(base + z.o_gk);
     fa.gidx = reinterpret_cast<unsigned *>(base + z.o_gi);
     fa.sorted = sorted;
@@ -3376,12 +3519,19 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
     ta.stat = d_stat;
     for (int64_t p0 = 0; p0 < n_periods; p0 += z.batch) {
         const int64_t bc = n_periods - p0 < z.batch ? n_periods - p0 : z.batch;
-        if (z.streamed) PDC_TRY(stream_sort_batch(device, st, z.h, sa, p0, bc));
         fa.p0 = p0;
         fa.batch = (int)bc;
-        hipLaunchKernelGGL(ss::ss_sort_fallback_kernel, dim3((unsigned)(bc < z.grid_fb ? bc : z.grid_fb)), dim3(kBlock), 0,
-                           st, fa);
-        if (z.streamed && sa.direct) hipLaunchKernelGGL(ss::ss_direct_kernel, dim3((unsigned)(bc * 8)), dim3(kBlock), 0, st, fa);
+        if (z.fastsort) {
+            // one workgroup per period sorts it in LDS (the StringLength kernels' EMIT instances) and writes the sorted
+            // curve; the periods that outlast the samples are marked and written as they stand
+            PDC_TRY(fast_sort_batch(st, d_t, d_y, n, d_periods + p0, bc, z.batch, bad, sorted, base + z.o_fast, &fa.skip8));
+            hipLaunchKernelGGL(ss::ss_direct_kernel, dim3((unsigned)(bc * 8)), dim3(kBlock), 0, st, fa);
+        } else {
+            if (z.streamed) PDC_TRY(stream_sort_batch(device, st, z.h, sa, p0, bc));
+            hipLaunchKernelGGL(ss::ss_sort_fallback_kernel, dim3((unsigned)(bc < z.grid_fb ? bc : z.grid_fb)), dim3(kBlock), 0,
+                               st, fa);
+            if (z.streamed && sa.direct) hipLaunchKernelGGL(ss::ss_direct_kernel, dim3((unsigned)(bc * 8)), dim3(kBlock), 0, st, fa);
+        }
         if (z.tiled) {
             PDC_HIP(hipMemsetAsync(ta.flag, 0, (size_t)bc * 4, st));
             ta.p0 = p0;
