@@ -119,8 +119,8 @@ def c5_inputs():
 KERNEL_SOURCES = {
     "gls_": ("gls.hip", "gls_epilogue.h", "pdc_device.h"),
     "pdm_": ("pdm.hip", "pdc_device.h"),
-    "sl_": ("stringlength.hip", "sl_ranges.inc", "supersmoother.inc", "pdc_device.h"),
-    "ss_": ("stringlength.hip", "supersmoother.inc", "pdc_device.h"),
+    "sl_": ("stringlength.hip", "sl_ranges.inc", "supersmoother.inc", "timesort.inc", "pdc_device.h"),
+    "ss_": ("stringlength.hip", "supersmoother.inc", "timesort.inc", "pdc_device.h"),
     "fft_": ("glsfft.hip", "pdc_device.h"),
     "glsfft_": ("glsfft.hip", "gls_epilogue.h", "pdc_device.h"),
     "peak": ("peaks.hip", "pdc_device.h"),

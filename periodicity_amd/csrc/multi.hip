@@ -625,15 +625,15 @@ int phase_scan_enqueue(PhasePlan *p, int kind, const double *periods, int64_t n_
         // (the scans that sort every period: the samples are still in the staging block, so the host can see whether
         // this slab's periods need the streamed kernels' bin lists at all - ~12 GB per slot at a million samples)
         const bool sorted_kind = kind == 3 || kind == 5;
-        const bool lists = sorted_kind && sorted_scan_needs_lists(kind, static_cast<const double *>(p->pin_in.p), p->n, pp + sb.begin, sb.count);
-        const int64_t wb = sorted_kind ? sorted_scan_work_bytes(kind, p->n, sb.count, lists) : pdc_phase_work_bytes(kind, p->n, sb.count, nb, nc);
+        const int hints = sorted_kind ? sorted_scan_hints(kind, static_cast<const double *>(p->pin_in.p), p->n, pp + sb.begin, sb.count) : 0;
+        const int64_t wb = sorted_kind ? sorted_scan_work_bytes(kind, p->n, sb.count, hints) : pdc_phase_work_bytes(kind, p->n, sb.count, nb, nc);
         PDC_REQUIRE(wb >= 0, "phase_plan_scan: bad size");
         PDC_TRY(ensure(s.b[B_WORK], wb + 8));
         PDC_HIP(hipMemcpyAsync(s.b[B_PER].p, pp + sb.begin, sb.count * 8, hipMemcpyHostToDevice, s.stream));
         PDC_HIP(hipEventRecord(s.k0, s.stream));
         if (sorted_kind)
             PDC_TRY(sorted_scan_dev(kind, s.device, s.stream, (double *)s.b[B_T].p, (double *)s.b[B_V].p, p->n, (double *)s.b[B_PER].p,
-                                    sb.count, sigma, (double *)s.b[B_OUT].p, s.b[B_WORK].p, s.b[B_WORK].cap, lists));
+                                    sb.count, sigma, (double *)s.b[B_OUT].p, s.b[B_WORK].p, s.b[B_WORK].cap, hints));
         else
             PDC_TRY(pdc_phase_scan_dev(kind, s.device, s.stream, (double *)s.b[B_T].p, (double *)s.b[B_V].p, p->n,
                                        (double *)s.b[B_PER].p, sb.count, nb, nc, sigma, (double *)s.b[B_OUT].p,

@@ -60,11 +60,12 @@ int phase_stat_dev(int kind, int device, hipStream_t st, const double *d_t, cons
                    void *work, int64_t work_bytes);
 
 // StringLength (kind 3) / Supersmoother (kind 5) for callers that hold the host arrays too (stringlength.hip): whether
-// the streamed kernels will need their bin lists, the workspace with / without them, the scan.
-bool sorted_scan_needs_lists(int kind, const double *t, int64_t n, const double *periods, int64_t n_periods);
-int64_t sorted_scan_work_bytes(int kind, int64_t n, int64_t n_periods, bool lists);
+// the streamed kernels will need their bin lists (hints bit 0) and whether t is in order (bit 1: no time sort to
+// launch), the workspace for those hints, the scan.  hints = 1 is what a caller that has not looked passes.
+int sorted_scan_hints(int kind, const double *t, int64_t n, const double *periods, int64_t n_periods);
+int64_t sorted_scan_work_bytes(int kind, int64_t n, int64_t n_periods, int hints);
 int sorted_scan_dev(int kind, int device, void *stream, const double *d_t, const double *d_v, int64_t n, const double *d_periods,
-                    int64_t n_periods, double alpha, double *d_out, void *work, int64_t work_bytes, bool lists);
+                    int64_t n_periods, double alpha, double *d_out, void *work, int64_t work_bytes, int hints);
 
 // hipSetDevice + range check; every entry point starts here.
 int use_device(int device);

@@ -1787,7 +1787,8 @@ struct StreamArgs {
     unsigned *todo_count;
 };
 
-__global__ __launch_bounds__(256) void sl_tame_kernel(const double *t, const double *m, rec_t *tm, int64_t n, unsigned *bad) {
+__global__ __launch_bounds__(256) void sl_tame_kernel(const double *t, const double *m, rec_t *tm, double *t_copy, double *m_copy,
+                                                      int64_t n, unsigned *bad) {
     bool mine = false, unsorted = false;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         if (tm) {
@@ -1795,6 +1796,10 @@ __global__ __launch_bounds__(256) void sl_tame_kernel(const double *t, const dou
             r.x = t[i];
             r.y = m[i];
             tm[i] = r;
+        }
+        if (t_copy) {   // (samples that may be in any order: the time sort works on copies)
+            t_copy[i] = t[i];
+            m_copy[i] = m[i];
         }
         const double at = __builtin_fabs(t[i]);
         mine = mine || !(at == 0.0 || (at >= 1e-150 && at <= 1e150));
@@ -2662,6 +2667,7 @@ __global__ __launch_bounds__(256) void sl_link_kernel(StreamArgs a) {
 
 }  // namespace stream
 
+#include "timesort.inc"
 #include "supersmoother.inc"
 
 int64_t pad_pow2(int64_t n) {
@@ -2782,7 +2788,9 @@ bool stream_takes(int64_t n, int64_t) { return n >= stream_min_n() && n >= 4096 
 
 struct StreamShape {
     int s1, batch, groups, tiles_w;
-    int64_t o_bad, o_flag, o_nbins, o_ncyc, o_cyc0, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_dpart, o_bnd, o_ix, o_pm, o_tm, o_todo, o_tcount, total;
+    int64_t o_bad, o_flag, o_nbins, o_ncyc, o_cyc0, o_hist, o_lut, o_clo, o_sub, o_bcnt, o_bstart, o_ssum, o_slen, o_dpart, o_bnd, o_ix, o_pm, o_tm, o_todo, o_tcount,
+            o_ts, o_rhist, o_rtot, total;
+    int ts_tiles;
 };
 StreamShape stream_shape(int64_t n, int64_t n_periods, bool lists = true) {
     auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
@@ -2832,7 +2840,13 @@ StreamShape stream_shape(int64_t n, int64_t n_periods, bool lists = true) {
     h.o_tm = h.o_pm + (lists ? up(items * stream::kCap * 16) : 256);
     h.o_todo = h.o_tm + up(n * 16);
     h.o_tcount = h.o_todo + up(n_periods);
-    h.total = h.o_tcount + 256;
+    // the time sort of samples that come in any order (timesort.inc): (t, m) in order + the other side of the ping-pong,
+    // the tiles' digit counts
+    h.ts_tiles = (int)((n + tsort::kTile - 1) / tsort::kTile);
+    h.o_ts = h.o_tcount + 256;
+    h.o_rhist = h.o_ts + 4 * up(n * 8);
+    h.o_rtot = h.o_rhist + up((int64_t)256 * h.ts_tiles * 4);
+    h.total = h.o_rtot + 1024;
     return h;
 }
 int64_t stream_bytes(int64_t n, int64_t n_periods, bool lists = true) {
@@ -2897,6 +2911,60 @@ stream::StreamArgs stream_args(const StreamShape &h, char *area, const double *d
     sa.todo_count = reinterpret_cast<unsigned *>(area + h.o_tcount);
     sa.ell = d_ell;
     return sa;
+}
+
+// What the host knows about a call (the entry points that hold the host arrays look; the _dev entries do not know):
+constexpr int kHintLists = 1;     // the workspace holds the streamed kernels' bin lists
+constexpr int kHintOrdered = 2;   // t is non-decreasing: no time sort to launch
+
+// PDC_SL_TIMESORT=0: samples in any order take the lists mode as up to round 4 (A/B, tests)
+bool timesort_on() {
+    static const bool on = [] {
+        const char *e = getenv("PDC_SL_TIMESORT"), *s = getenv("PDC_SL_SLICES");
+        return !(e && e[0] == '0') && !(s && s[0] == '0');
+    }();
+    return on;
+}
+
+// The streamed kernels' intake: sl_tame_kernel looks at t (tame? in order?) and writes the (t, m) records; samples that
+// may be in any order are copied, ordered by time on the device if the kernel found them out of order (timesort.inc -
+// every launch of it returns at once otherwise) and the kernels downstream read the copies (sa.t / sa.m).
+int stream_intake(hipStream_t st, const StreamShape &h, char *area, const double *d_t, const double *d_m, int64_t n, int hints,
+                  stream::StreamArgs &sa) {
+    unsigned *bad = const_cast<unsigned *>(sa.bad_t);
+    fast::rec_t *tm = const_cast<fast::rec_t *>(sa.tm);
+    PDC_HIP(hipMemsetAsync(area + h.o_bad, 0, 256, st));
+    if ((hints & kHintOrdered) != 0 || !timesort_on()) {
+        hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, d_m, tm, static_cast<double *>(nullptr),
+                           static_cast<double *>(nullptr), n, bad);
+        PDC_HIP(hipGetLastError());
+        return PDC_OK;
+    }
+    const int64_t plane = (n * 8 + 255) & ~(int64_t)255;
+    double *k0 = reinterpret_cast<double *>(area + h.o_ts), *v0 = reinterpret_cast<double *>(area + h.o_ts + plane);
+    double *k1 = reinterpret_cast<double *>(area + h.o_ts + 2 * plane), *v1 = reinterpret_cast<double *>(area + h.o_ts + 3 * plane);
+    hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, d_m, static_cast<fast::rec_t *>(nullptr), k0, v0, n, bad);
+    tsort::Args ta;
+    ta.bad = bad;
+    ta.hist = reinterpret_cast<unsigned *>(area + h.o_rhist);
+    ta.tot = reinterpret_cast<unsigned *>(area + h.o_rtot);
+    ta.n = n;
+    ta.tiles = h.ts_tiles;
+    for (int pass = 0; pass < 8; ++pass) {
+        ta.kin = (pass & 1) ? k1 : k0;
+        ta.vin = (pass & 1) ? v1 : v0;
+        ta.kout = (pass & 1) ? k0 : k1;
+        ta.vout = (pass & 1) ? v0 : v1;
+        ta.shift = 8 * pass;
+        hipLaunchKernelGGL(tsort::ts_hist_kernel, dim3((unsigned)h.ts_tiles), dim3(tsort::kB), 0, st, ta);
+        hipLaunchKernelGGL(tsort::ts_scan_kernel, dim3(256), dim3(tsort::kB), 0, st, ta);
+        hipLaunchKernelGGL(tsort::ts_scatter_kernel, dim3((unsigned)h.ts_tiles), dim3(tsort::kB), 0, st, ta);
+    }
+    hipLaunchKernelGGL(tsort::ts_finish_kernel, dim3(512), dim3(256), 0, st, k0, v0, tm, n, bad);
+    PDC_HIP(hipGetLastError());
+    sa.t = k0;
+    sa.m = v0;
+    return PDC_OK;
 }
 
 // the four launches that counting-sort one batch of periods by phase bin and sort every bin (no link kernel)
@@ -3149,24 +3217,42 @@ int64_t stringlength_work_bytes(int64_t n, int64_t n_periods, bool lists) {
 // mode of the streamed kernels?  Then the workspace needs no lists - at N = 1e6 12 GB of them, whose allocation alone
 // made a process's first call take 1.2 s.  The same conditions as sl_lut_kernel's with the bins reserved (s1) in place
 // of the bins used: stricter, never laxer.
-bool host_all_slices(const double *t, int64_t n, const double *periods, int64_t n_periods, int64_t min_n) {
+// Samples out of order (the C ABI allows it; a TSeries never is): the streamed kernels order them by time on the device
+// first (timesort.inc), so the same test applies with the smallest / largest time stamp in place of the first / last -
+// unless some time stamp is not tame (NaN, infinite, beyond 1e+-150: no time sort, lists mode as it stands).
+bool host_all_slices(const double *t, int64_t n, const double *periods, int64_t n_periods, int64_t min_n, bool *ordered) {
     static const bool on = [] { const char *e = getenv("PDC_SL_SLICES"); return !(e && e[0] == '0'); }();
+    *ordered = false;
     if (!on || n < min_n || n < 4096 || n > kStreamMaxN || n_periods < 1) return false;
-    for (int64_t i = 1; i < n; ++i)
-        if (!(t[i - 1] <= t[i])) return false;
+    bool in_order = true, tame = true;
+    double lo = t[0], hi = t[0];
+    for (int64_t i = 0; i < n; ++i) {
+        const double v = t[i], av = std::fabs(v);
+        tame = tame && (av == 0.0 || (av >= 1e-150 && av <= 1e150));
+        in_order = in_order && (i == 0 || t[i - 1] <= v);
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+    *ordered = in_order;
+    if (!in_order && !(tame && timesort_on() && n >= stream_min_n())) return false;
     const double s1 = (double)stream_shape(n, n_periods, false).s1;
     for (int64_t p = 0; p < n_periods; ++p) {
         const double period = periods[p];
         if (!(period > 0.0)) return false;
-        const double cycles = std::floor(t[n - 1] / period) - std::floor(t[0] / period) + 1.0;
+        const double cycles = std::floor(hi / period) - std::floor(lo / period) + 1.0;
         if (!(cycles >= 1.0 && cycles < (double)stream::kCycS && cycles * s1 * (double)stream::kMinSlice <= (double)n)) return false;
     }
     return true;
 }
+int host_hints(const double *t, int64_t n, const double *periods, int64_t n_periods, int64_t min_n) {
+    bool ordered = false;
+    const bool all_slices = host_all_slices(t, n, periods, n_periods, min_n, &ordered);
+    return (all_slices ? 0 : kHintLists) | (ordered ? kHintOrdered : 0);
+}
 
 int stringlength_scan_impl(int device, void *stream, const double *d_t, const double *d_m,
                            int64_t n, const double *d_periods, int64_t n_periods, double *d_ell,
-                           void *work, int64_t work_bytes, bool lists);
+                           void *work, int64_t work_bytes, int hints);
 }  // namespace
 
 extern "C" {
@@ -3176,7 +3262,7 @@ int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) { return strin
 int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
                               int64_t n, const double *d_periods, int64_t n_periods, double *d_ell,
                               void *work, int64_t work_bytes) {
-    return stringlength_scan_impl(device, stream, d_t, d_m, n, d_periods, n_periods, d_ell, work, work_bytes, true);
+    return stringlength_scan_impl(device, stream, d_t, d_m, n, d_periods, n_periods, d_ell, work, work_bytes, kHintLists);
 }
 
 }  // extern "C"
@@ -3184,7 +3270,8 @@ int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const
 namespace {
 int stringlength_scan_impl(int device, void *stream, const double *d_t, const double *d_m,
                            int64_t n, const double *d_periods, int64_t n_periods, double *d_ell,
-                           void *work, int64_t work_bytes, bool lists) {
+                           void *work, int64_t work_bytes, int hints) {
+    const bool lists = (hints & kHintLists) != 0;
     PDC_REQUIRE(d_t && d_m && (d_periods || n_periods == 0) && (d_ell || n_periods == 0),
                 "stringlength: NULL argument");
     PDC_REQUIRE(n >= 0 && n_periods >= 0, "stringlength: negative size");
@@ -3221,10 +3308,10 @@ int stringlength_scan_impl(int device, void *stream, const double *d_t, const do
                      duo_bytes(n_periods) + onecycle_bytes(n_periods);
         stream::StreamArgs sa = stream_args(h, area, d_t, d_m, d_periods, n, d_ell);
         sa.no_lists = lists ? 0 : 1;
-        PDC_HIP(hipMemsetAsync(area + h.o_bad, 0, 256, st));
         PDC_HIP(hipMemsetAsync(sa.todo_count, 0, 256, st));
-        hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, d_m, const_cast<fast::rec_t *>(sa.tm), n,
-                           const_cast<unsigned *>(sa.bad_t));
+        PDC_TRY(stream_intake(st, h, area, d_t, d_m, n, hints, sa));
+        a.t = sa.t;     // (the general kernel's few periods see the samples the streamed kernels saw: one tie order)
+        a.m = sa.m;
         PDC_TRY(stream_allow_lds(h));
         for (int64_t p0 = 0; p0 < n_periods; p0 += h.batch) {
             const int64_t bc = n_periods - p0 < h.batch ? n_periods - p0 : h.batch;
@@ -3289,7 +3376,7 @@ int stringlength_scan_impl(int device, void *stream, const double *d_t, const do
         o.ell = d_ell;
         PDC_HIP(hipMemsetAsync(flags, 0, 512, st));
         hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(n < 65536 ? 64 : 512), dim3(256), 0, st, d_t, d_m,
-                           static_cast<fast::rec_t *>(nullptr), n, flags);
+                           static_cast<fast::rec_t *>(nullptr), static_cast<double *>(nullptr), static_cast<double *>(nullptr), n, flags);
         hipLaunchKernelGGL(onecycle::sl_onecycle_mark_kernel, dim3((unsigned)((n_periods + 255) / 256)), dim3(256), 0, st, o);
         hipLaunchKernelGGL(onecycle::sl_onecycle_kernel, dim3(64), dim3(kBlock), 0, st, o);
         a.skip = o.skip;
@@ -3410,8 +3497,8 @@ int pdc_stringlength_scan(const double *t, const double *m, int64_t n, const dou
     PDC_TRY(use_device(device));
     DeviceLock lock(device);
     // (time-ordered samples and periods that all take the slices / one-cycle modes: no lists in the workspace)
-    const bool lists = !host_all_slices(t, n, periods, n_periods, stream_min_n());
-    const int64_t wb = stringlength_work_bytes(n, n_periods, lists);
+    const int hints = host_hints(t, n, periods, n_periods, stream_min_n());
+    const int64_t wb = stringlength_work_bytes(n, n_periods, (hints & kHintLists) != 0);
     void *d_t, *d_m, *d_p, *d_e, *d_w;
     PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
     PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_m));
@@ -3424,7 +3511,7 @@ int pdc_stringlength_scan(const double *t, const double *m, int64_t n, const dou
     PDC_HIP(hipMemcpyAsync(d_m, m, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_p, periods, n_periods * 8, hipMemcpyHostToDevice, st));
     PDC_TRY(stringlength_scan_impl(device, st, (double *)d_t, (double *)d_m, n, (double *)d_p,
-                                   n_periods, (double *)d_e, d_w, wb, lists));
+                                   n_periods, (double *)d_e, d_w, wb, hints));
     PDC_HIP(hipMemcpyAsync(ell_out, d_e, n_periods * 8, hipMemcpyDeviceToHost, st));
     PDC_HIP(hipStreamSynchronize(st));
     return PDC_OK;
@@ -3441,7 +3528,7 @@ int64_t pdc_supersmoother_work_bytes(int64_t n, int64_t n_periods) {
 namespace {
 int supersmoother_scan_impl(int device, void *stream, const double *d_t, const double *d_y, int64_t n,
                             const double *d_periods, int64_t n_periods, double alpha, double *d_stat, void *work,
-                            int64_t work_bytes, bool lists);
+                            int64_t work_bytes, int hints);
 }
 
 extern "C" {
@@ -3449,7 +3536,7 @@ extern "C" {
 int pdc_supersmoother_scan_dev(int device, void *stream, const double *d_t, const double *d_y, int64_t n,
                                const double *d_periods, int64_t n_periods, double alpha, double *d_stat, void *work,
                                int64_t work_bytes) {
-    return supersmoother_scan_impl(device, stream, d_t, d_y, n, d_periods, n_periods, alpha, d_stat, work, work_bytes, true);
+    return supersmoother_scan_impl(device, stream, d_t, d_y, n, d_periods, n_periods, alpha, d_stat, work, work_bytes, kHintLists);
 }
 
 }  // extern "C"
@@ -3457,7 +3544,8 @@ int pdc_supersmoother_scan_dev(int device, void *stream, const double *d_t, cons
 namespace {
 int supersmoother_scan_impl(int device, void *stream, const double *d_t, const double *d_y, int64_t n,
                             const double *d_periods, int64_t n_periods, double alpha, double *d_stat, void *work,
-                            int64_t work_bytes, bool lists) {
+                            int64_t work_bytes, int hints) {
+    const bool lists = (hints & kHintLists) != 0;
     PDC_REQUIRE(d_t && d_y && (d_periods || n_periods == 0) && (d_stat || n_periods == 0), "supersmoother: NULL argument");
     PDC_REQUIRE(n >= 5 && n < ((int64_t)1 << 30), "supersmoother: between 5 and 2^30 samples (the woofer window spans "
                                                   "half the curve)");
@@ -3472,8 +3560,6 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
     char *base = static_cast<char *>(work);
     fast::rec_t *sorted = reinterpret_cast<fast::rec_t *>(base + z.o_sorted);
     unsigned *bad = reinterpret_cast<unsigned *>(base + (z.streamed ? z.h.o_bad : z.o_bad));
-    PDC_HIP(hipMemsetAsync(bad, 0, 256, st));
-    hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, d_y, z.streamed ? reinterpret_cast<fast::rec_t *>(base + z.h.o_tm) : nullptr, n, bad);
     stream::StreamArgs sa;
     if (z.streamed) {
         sa = stream_args(z.h, base, d_t, d_y, d_periods, n, nullptr);
@@ -3481,10 +3567,15 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
         sa.direct = sa.slices;             // (one-cycle periods are marked by the bin table kernel: ss_direct_kernel writes them)
         sa.no_lists = lists ? 0 : 1;
         PDC_TRY(stream_allow_lds(z.h));
+        PDC_TRY(stream_intake(st, z.h, base, d_t, d_y, n, hints, sa));   // (samples in any order: ordered by time first)
+    } else {
+        PDC_HIP(hipMemsetAsync(bad, 0, 256, st));
+        hipLaunchKernelGGL(stream::sl_tame_kernel, dim3(512), dim3(256), 0, st, d_t, d_y, static_cast<fast::rec_t *>(nullptr),
+                           static_cast<double *>(nullptr), static_cast<double *>(nullptr), n, bad);
     }
     ss::SsSortArgs fa;
-    fa.t = d_t;
-    fa.y = d_y;
+    fa.t = z.streamed ? sa.t : d_t;
+    fa.y = z.streamed ? sa.m : d_y;
     fa.periods = d_periods;
     fa.bad_t = bad;
     fa.n = n;
@@ -3577,8 +3668,8 @@ int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const do
     PDC_TRY(use_device(device));
     DeviceLock lock(device);
     // (time-ordered samples and periods that all take the slices mode: no lists in the workspace, as pdc_stringlength_scan)
-    const bool lists = !host_all_slices(t, n, periods, n_periods, 4096);
-    const int64_t wb = ss_shape(n, n_periods, lists).total;
+    const int hints = host_hints(t, n, periods, n_periods, 4096);
+    const int64_t wb = ss_shape(n, n_periods, (hints & kHintLists) != 0).total;
     void *d_t, *d_y, *d_p, *d_s, *d_w;
     PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
     PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_y));
@@ -3591,7 +3682,7 @@ int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const do
     PDC_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
     PDC_HIP(hipMemcpyAsync(d_p, periods, n_periods * 8, hipMemcpyHostToDevice, st));
     PDC_TRY(supersmoother_scan_impl(device, st, (double *)d_t, (double *)d_y, n, (double *)d_p, n_periods, alpha,
-                                    (double *)d_s, d_w, wb, lists));
+                                    (double *)d_s, d_w, wb, hints));
     PDC_HIP(hipMemcpyAsync(stat_out, d_s, n_periods * 8, hipMemcpyDeviceToHost, st));
     PDC_HIP(hipStreamSynchronize(st));
     return PDC_OK;
@@ -3604,17 +3695,18 @@ int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const do
 // workspace needs no bin lists (~12 GB at a million samples) - what pdc_stringlength_scan / pdc_supersmoother_scan
 // do for themselves.  kind 3 = StringLength, 5 = Supersmoother (alpha).
 namespace pdc {
-bool sorted_scan_needs_lists(int kind, const double *t, int64_t n, const double *periods, int64_t n_periods) {
-    return !host_all_slices(t, n, periods, n_periods, kind == 5 ? (int64_t)4096 : stream_min_n());
+int sorted_scan_hints(int kind, const double *t, int64_t n, const double *periods, int64_t n_periods) {
+    return host_hints(t, n, periods, n_periods, kind == 5 ? (int64_t)4096 : stream_min_n());
 }
-int64_t sorted_scan_work_bytes(int kind, int64_t n, int64_t n_periods, bool lists) {
+int64_t sorted_scan_work_bytes(int kind, int64_t n, int64_t n_periods, int hints) {
+    const bool lists = (hints & kHintLists) != 0;
     if (n < 0 || n_periods < 0) return -1;
     return kind == 5 ? ss_shape(n, n_periods, lists).total : stringlength_work_bytes(n, n_periods, lists);
 }
 int sorted_scan_dev(int kind, int device, void *stream, const double *d_t, const double *d_v, int64_t n, const double *d_periods,
-                    int64_t n_periods, double alpha, double *d_out, void *work, int64_t work_bytes, bool lists) {
-    if (kind == 5) return supersmoother_scan_impl(device, stream, d_t, d_v, n, d_periods, n_periods, alpha, d_out, work, work_bytes, lists);
-    return stringlength_scan_impl(device, stream, d_t, d_v, n, d_periods, n_periods, d_out, work, work_bytes, lists);
+                    int64_t n_periods, double alpha, double *d_out, void *work, int64_t work_bytes, int hints) {
+    if (kind == 5) return supersmoother_scan_impl(device, stream, d_t, d_v, n, d_periods, n_periods, alpha, d_out, work, work_bytes, hints);
+    return stringlength_scan_impl(device, stream, d_t, d_v, n, d_periods, n_periods, d_out, work, work_bytes, hints);
 }
 }  // namespace pdc
 

@@ -317,6 +317,28 @@ def test_streamed_stringlength_full_batches_per_group_count(groups):
     _sl_oracle_full(["262144x384", "300000x384d", "280000x352o", "270000x384s", "262144x320ds"], PDC_SL_STREAM_GROUPS=groups)
 
 
+@pytest.mark.parametrize("dev", ["", "1"])
+def test_streamed_stringlength_samples_in_any_order(dev):
+    """Samples handed over in a random order at N >= 262 144 (the C ABI allows it; a TSeries never is): ordered by time on
+    the device first (csrc/timesort.inc: stable radix sort - duplicates of a time stamp keep the caller's order), then
+    the kernels a TSeries gets; every period against the oracle's result for the time-ordered series.  Duplicates + gaps
+    + a negative start, a Julian-date offset, times that straddle zero with -0.0 / +0.0 stamps, N = 1e6.  Through the
+    host entry (which sees that the samples are out of order) and through the _dev entry (which cannot: the decision is
+    the device's)."""
+    _sl_oracle_full(["300000x384u", "262144x320du", "280000x352ou", "1000000x96uz"], SL_FULL_DEV=dev)
+
+
+def test_streamed_stringlength_dev_entry_with_samples_in_order():
+    """The _dev entry enqueues the time sort's launches whatever the order: for samples in order each of them returns at
+    once and the copies the kernels read are the samples as they stand."""
+    _sl_oracle_full(["300000x384", "262144x320d"], SL_FULL_DEV="1")
+
+
+def test_streamed_stringlength_samples_in_any_order_without_the_time_sort():
+    """PDC_SL_TIMESORT=0: the lists mode (what such samples got up to round 4) is still right."""
+    _sl_oracle_full(["300000x96u", "262144x64du"], PDC_SL_TIMESORT="0")
+
+
 def test_several_slice_stringlength_every_period_against_the_oracle():
     """The several-slice instances of sl_fast_kernel (52 112 < N < 262 144; 16-bit indices + bit planes): all periods."""
     _sl_oracle_full(["74326x2048", "131000x1024d", "200000x1024o", "261000x512"])

@@ -107,6 +107,26 @@ def test_supersmoother_scan_matches_the_oracle_at_the_sizes_it_runs(n):
 
 
 @pytest.mark.gpu
+def test_supersmoother_samples_in_any_order_at_the_streamed_sizes():
+    """N >= 262 144 handed over in a random order (the C ABI allows it; a TSeries never is): the device orders the
+    samples by time first (csrc/timesort.inc, stable - duplicates of a time stamp keep the caller's order) and the
+    result is the one for TSeries(t, y); periods beyond the baseline (written as the samples stand) included."""
+    n = 300_000
+    t, y = curve(n, 99)
+    t[5:n:9] = t[4:n - 1:9]
+    rng = np.random.default_rng(5)
+    order = rng.permutation(n)
+    ts, ys = t[order], y[order]
+    back = np.argsort(ts, kind="stable")
+    periods = np.array([2.1, 7.3, 33.3, 0.31 * t[-1], 1.7 * t[-1], 12.0 * t[-1]])
+    got = _cabi.supersmoother_scan(ts, ys, periods, 0.0)
+    np.testing.assert_allclose(got, so.supersmoother_scan(ts[back], ys[back], periods, 0.0), rtol=RTOL)
+    assert np.array_equal(got, _cabi.supersmoother_scan(ts, ys, periods, 0.0))
+    # in order, the same samples take the same kernels: the same bits
+    assert np.array_equal(got, _cabi.supersmoother_scan(ts[back], ys[back], periods, 0.0))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,alpha", [(30_000, 0.0), (30_000, 7.0), (8_192, 0.0), (4_096, 3.0)])
 def test_tiled_smoother_short_runs_of_equal_phases(n, alpha):
     """Duplicate time stamps give runs of two and three equal phases at every period: the tiled kernels (n >= 4096)

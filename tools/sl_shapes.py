@@ -1,5 +1,5 @@
 """StringLength kernel time over a few (N, n_periods) shapes (developer tool; PDC_SL_GENERAL=1 for the
-general kernel)."""
+general kernel; SHUFFLE=1: the samples in a random order - the device orders them by time first, timesort.inc)."""
 import ctypes as C
 import os
 import sys
@@ -24,6 +24,9 @@ for n, n_per in SHAPES:
     t, y, _ = bench.synth_curve(n, 5, period=13.7)
     m = (y - y.max()) / (2 * (y.max() - y.min())) + 0.25
     df = 0.1 / (t[-1] - t[0])
+    if os.environ.get("SHUFFLE"):
+        order = np.random.default_rng(n).permutation(n)
+        t, m = t[order], m[order]
     periods = 1 / np.linspace(n_per * df, df, n_per)
     bt, bm, bp, be = DB.from_array(t, 0), DB.from_array(m, 0), DB.from_array(periods, 0), DB(n_per * 8, 0)
     wb = lib.pdc_stringlength_work_bytes(n, n_per)
