@@ -143,6 +143,12 @@ constexpr int kPkMaxKTotal = 1024;
 #endif
 constexpr int kPkSortFrom = PDC_PK_SORT_FROM;      // rankings of more than this many entries sort the candidate list instead of m reduction rounds   // ... per call: chunks of 64, each launch ranking what comes AFTER the chunk before
 constexpr int kPkPre = 68;           // by prominence: the first walks go to the k + 4 highest maxima
+#ifndef PDC_PK_WALK_LOADS
+#define PDC_PK_WALK_LOADS 8
+#endif
+constexpr int kPkWalkLoads = PDC_PK_WALK_LOADS;   // loads a lane of a walk has in flight: 16 lanes x 4 = 64 bins per memory latency.
+                                                  // (Round 5: 6 / 8 / 16 - a 256-bin block in one latency instead of four - cost
+                                                  // 81 / 85 / 96 registers, i.e. the sixth workgroup per CU: not taken)
 constexpr int kPkChunk = 1024;       // bins per sweep step
 constexpr int kPkFusedShift = 8;     // 256-bin blocks = one wave's stretch of a chunk: extrema come with the sweep
 static_assert(kPkChunk / kPkBlock * 64 == 1 << kPkFusedShift, "a wave's stretch is one block");
@@ -175,9 +181,29 @@ __device__ __forceinline__ double wave_min_to_lane63(double v) {
     return v;
 }
 
+__device__ __forceinline__ int wave_min_int_to_lane63(int v) {
+#define PDC_PK_STEP(ctrl)                                                            \
+    {                                                                                \
+        const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);      \
+        v = o < v ? o : v;                                                           \
+    }
+    PDC_PK_STEP(0x111) PDC_PK_STEP(0x112) PDC_PK_STEP(0x114) PDC_PK_STEP(0x118) PDC_PK_STEP(0x142) PDC_PK_STEP(0x143)
+#undef PDC_PK_STEP
+    return v;
+}
+
 __device__ __forceinline__ bool cand_before(double ka, long long ia, double kb, long long ib) {
     return ib < 0 || (ia >= 0 && (ka > kb || (ka == kb && ia < ib)));
 }
+
+// PDC_PK_DBG (developer builds, tools/peaks_stamps.py): s_memrealtime stamps (10 ns ticks) of every row's phases
+#ifdef PDC_PK_DBG
+__device__ unsigned long long pk_dbg[8192 * 16];
+#define PK_STAMP(i)                                                                                   \
+    if (tid == 0 && blockIdx.x < 8192) pk_dbg[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define PK_STAMP(i)
+#endif
 
 // SORT: the instance for launches of more than kPkSortFrom ranks (its rankings sort the candidate list; four more
 // registers, five workgroups per CU instead of six - which cost the few-ranks launches 10 %, so they keep their own)
@@ -192,11 +218,13 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
     __shared__ int s_ncand;
     __shared__ double s_thr;
     __shared__ double red_k[kPkBlock / 64];
-    __shared__ long long red_i[kPkBlock / 64];
     __shared__ int red_e[kPkBlock / 64];
     __shared__ long long s_count[kPkBlock / 64];
-    __shared__ double win_key[kPkPre], win_h[kPkPre], win_p[kPkPre];
-    __shared__ long long win_idx[kPkPre];
+    constexpr int kWin = SORT ? kPkPre : kPkSortFrom + 4;     // winners a ranking of this instance can be asked for
+    __shared__ double win_key[kWin], win_h[kWin], win_p[kWin];
+    __shared__ long long win_idx[kWin];
+    __shared__ int wtop[kPkBlock / 64 * kWin];
+    __shared__ double s_low[2][8][2];                         // the walks of a pass: lowest sample met leftwards / rightwards               // few ranks: every wave's winners (slots of the candidate list)
     __shared__ unsigned s_need[32];   // second sweep: chunks that can hold a candidate at the initial tau
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double *x = a.power + (int64_t)blockIdx.x * a.nf;
@@ -250,19 +278,22 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
     auto group_ballot = [&](bool p) __attribute__((always_inline)) -> unsigned {
         return (unsigned)((__ballot(p) >> gbase) & 0xffffull);
     };
-    auto walk = [&](int64_t from, int dir, double h) __attribute__((always_inline)) -> double {
+    // (32-bit bin numbers inside a walk - rows have < 2^31 bins -: the row pointer stays a scalar base and a load takes
+    // one address register)
+    auto walk = [&](int from, int dir, double h) __attribute__((always_inline)) -> double {
         double low = h;
+        const int nfi = (int)nf, nblki = (int)a.nblk;
         // `count` bins from `start` on in direction dir; true when the walk ended among them
-        auto run = [&](int64_t start, int64_t count) __attribute__((always_inline)) -> bool {
-            for (int64_t o = 0; o < count; o += 64) {
-                double v[4];
+        auto run = [&](int start, int count) __attribute__((always_inline)) -> bool {
+            for (int o = 0; o < count; o += 16 * kPkWalkLoads) {
+                double v[kPkWalkLoads];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int64_t k = o + 16 * u + gl;
-                    v[u] = k < count ? x[start + dir * k] : 0.0;
+                for (int u = 0; u < kPkWalkLoads; ++u) {
+                    const int k = o + 16 * u + gl;
+                    v[u] = k < count ? x[(unsigned)(start + dir * k)] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kPkWalkLoads; ++u) {
                     const bool valid = o + 16 * u + gl < count;
                     const unsigned sb = group_ballot(valid && !(v[u] <= h));
                     const int first = sb ? __builtin_ctz(sb) : 16;
@@ -273,13 +304,13 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
             }
             return false;
         };
-        const int64_t b0 = from >> sh;
-        const int64_t b0_end = ((b0 + 1) << sh) < nf ? ((b0 + 1) << sh) : nf;
+        const int b0 = from >> sh;
+        const int b0_end = ((b0 + 1) << sh) < nfi ? ((b0 + 1) << sh) : nfi;
         if (run(from, dir > 0 ? b0_end - from : from - (b0 << sh) + 1)) return low;
-        int64_t b = b0 + dir;
+        int b = b0 + dir;
         for (;;) {
-            const int64_t bb = b + dir * gl;
-            const bool pass = bb >= 0 && bb < a.nblk && bmax[bb] <= h;
+            const int bb = b + dir * gl;
+            const bool pass = bb >= 0 && bb < nblki && bmax[bb] <= h;
             const unsigned fb = group_ballot(!pass);
             const int first = fb ? __builtin_ctz(fb) : 16;
             const double m = group_min(gl < first ? bmin[bb] : inf);   // (the lanes below `first` pass: in range)
@@ -290,20 +321,36 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
             }
             b += 16 * dir;
         }
-        if (b < 0 || b >= a.nblk) return low;   // reached the border of the signal
-        const int64_t b_end = ((b + 1) << sh) < nf ? ((b + 1) << sh) : nf;
+        if (b < 0 || b >= nblki) return low;   // reached the border of the signal
+        const int b_end = ((b + 1) << sh) < nfi ? ((b + 1) << sh) : nfi;
         run(dir > 0 ? b << sh : b_end - 1, b_end - (b << sh));   // this block holds a sample > h (or a NaN)
         return low;
     };
-    // prominences of the candidates that have none yet: one group of 16 lanes per candidate
+    // prominences of the candidates that have none yet, eight candidates at a time: the groups of waves 0 and 1 walk
+    // left, those of waves 2 and 3 right (round 5: one group walked left, then right - the walks are chains of dependent
+    // loads, and half of the sixteen groups had nothing to do for the eight candidates of a k = 4 call).  The direction
+    // is the wave's, so both walks keep a compile-time stride (a stride per group cost 14 registers = the sixth
+    // workgroup per CU).
     auto walk_candidates = [&]() __attribute__((always_inline)) {
         const int n = s_ncand;
-        for (int e = tid >> 4; e < n; e += kPkBlock / 16) {
-            if (cp[e] == cp[e]) continue;
-            const double v = ch[e];
-            const int64_t at = ci[e];
-            const double lo = walk(at, -1, v), hi = walk(at, +1, v);
-            if (gl == 0) cp[e] = v - (lo > hi ? lo : hi);
+        const int slot = (tid >> 4) & 7;
+        const bool right = __builtin_amdgcn_readfirstlane(wave) >= 2;
+        int par = 0;
+        for (int base = 0; base < n; base += 8, par ^= 1) {
+            const int e = base + slot;
+            if (e < n && !(cp[e] == cp[e])) {
+                const double v = ch[e];
+                const int at = ci[e];
+                const double low = right ? walk(at, +1, v) : walk(at, -1, v);
+                if (gl == 0) s_low[par][slot][right ? 1 : 0] = low;
+            }
+            __syncthreads();
+            if (tid < 8 && base + tid < n && !(cp[base + tid] == cp[base + tid])) {
+                const double lo = s_low[par][tid][0], hi = s_low[par][tid][1];
+                cp[base + tid] = ch[base + tid] - (lo > hi ? lo : hi);
+            }
+            // (the next pass writes the other half of s_low and other candidates; its barrier orders these reads before
+            // the pass after it)
         }
         __syncthreads();
     };
@@ -388,57 +435,93 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
                 __syncthreads();
             }
             found = taken < m ? taken : m;
-        } else
-        for (int round = 0; round < m; ++round) {
-            double wk = 0.0;
-            long long wi = -1;
-            int we = -1;
-            for (int e = tid; e < n; e += kPkBlock) {
-                const double key = by_prom ? cp[e] : ch[e];
-                const long long bin = ci[e];
-                const bool after = (round == 0 && !ex) || key < pk || (key == pk && bin > pidx);
-                if (after && cand_before(key, bin, wk, wi)) {
-                    wk = key;
-                    wi = bin;
-                    we = e;
+        } else {
+            // Few ranks.  Round 5: two phases without a barrier inside - (1) every wave ranks the m best of ITS share of
+            // the list (entry e belongs to wave (e / 64) mod 4), m rounds of "best entry strictly after the wave's previous
+            // winner", the winners' slots to wtop[wave][]; (2) after one barrier every wave ranks the <= 4 m slots of
+            // wtop the same way - all four get the same answer, so none waits for another.  A round is a maximum of the
+            // keys over the wave by DPP, the lowest bin among the lanes that hold it, and a ballot: no LDS crossbar, no
+            // barrier (round 4: 3 block reductions with 2 barriers per round - 11.7 us for the 8 rounds of a k = 4 call
+            // by prominence, three rankings per row).
+            // best (key descending, bin ascending) over the wave of every lane's (key, bin >= 0 or -1: none, slot)
+            auto wave_best = [&](double key, int bin, int slot, double &bk, int &bi, int &be) __attribute__((always_inline)) -> bool {
+                const double kk = bin >= 0 ? key : -inf;
+                const long long tb = __double_as_longlong(wave_min_to_lane63(-kk));
+                const double top = -__longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(tb >> 32), 63) << 32) |
+                                                         (unsigned)__builtin_amdgcn_readlane((int)tb, 63));
+                const bool tied = bin >= 0 && kk == top;
+                const int lowest = __builtin_amdgcn_readlane(wave_min_int_to_lane63(tied ? bin : 0x7fffffff), 63);
+                const unsigned long long who = __ballot(tied && bin == lowest);
+                if (who == 0ull) return false;
+                const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(who));
+                // (the winner's own bits: a tie of -0.0 and +0.0 keys is a tie, but the half-maximum level downstream takes
+                // the sign along - tools/fuzz_peaks.py case 23)
+                const long long kb = __double_as_longlong(key);
+                bk = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(kb >> 32), src) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)kb, src));
+                bi = lowest;
+                be = __builtin_amdgcn_readlane(slot, src);
+                return true;
+            };
+            {   // phase 1
+                double wpk = pk;
+                int wpi = (int)pidx;
+                bool any_prev = ex;
+                int r = 0;
+                for (; r < m; ++r) {
+                    double lk = 0.0;
+                    int li = -1, le = -1;
+                    for (int e = tid; e < n; e += kPkBlock) {
+                        const double key = by_prom ? cp[e] : ch[e];
+                        const int bin = ci[e];
+                        const bool after = !any_prev || key < wpk || (key == wpk && bin > wpi);
+                        if (after && cand_before(key, bin, lk, li)) {
+                            lk = key;
+                            li = bin;
+                            le = e;
+                        }
+                    }
+                    double bk;
+                    int bi, be;
+                    if (!wave_best(lk, li, le, bk, bi, be)) break;    // (wave-uniform)
+                    if (lane == 0) wtop[wave * kWin + r] = be;
+                    wpk = bk;
+                    wpi = bi;
+                    any_prev = true;
                 }
-            }
-            for (int o = 32; o > 0; o >>= 1) {
-                const double ok = __shfl_down(wk, o, 64);
-                const long long oi = __shfl_down(wi, o, 64);
-                const int oe = __shfl_down(we, o, 64);
-                if (cand_before(ok, oi, wk, wi)) {
-                    wk = ok;
-                    wi = oi;
-                    we = oe;
-                }
+                for (int q = r + lane; q < kWin; q += 64) wtop[wave * kWin + q] = -1;
             }
             __syncthreads();
-            if (lane == 0) {
-                red_k[wave] = wk;
-                red_i[wave] = wi;
-                red_e[wave] = we;
-            }
-            __syncthreads();
-            wk = red_k[0];
-            wi = red_i[0];
-            we = red_e[0];
-            for (int w = 1; w < kPkBlock / 64; ++w)
-                if (cand_before(red_k[w], red_i[w], wk, wi)) {
-                    wk = red_k[w];
-                    wi = red_i[w];
-                    we = red_e[w];
+            bool any_prev = ex;
+            for (int round = 0; round < m; ++round) {
+                double lk = 0.0;
+                int li = -1, le = -1;
+                for (int q = lane; q < (kPkBlock / 64) * kWin; q += 64) {
+                    const int e = wtop[q];
+                    if (e < 0) continue;
+                    const double key = by_prom ? cp[e] : ch[e];
+                    const int bin = ci[e];
+                    const bool after = !any_prev || key < pk || (key == pk && bin > pidx);
+                    if (after && cand_before(key, bin, lk, li)) {
+                        lk = key;
+                        li = bin;
+                        le = e;
+                    }
                 }
-            if (wi < 0) break;   // (workgroup-uniform) no entry left
-            if (tid == 0) {
-                win_key[round] = wk;
-                win_idx[round] = wi;
-                win_h[round] = ch[we];
-                win_p[round] = cp[we];
+                double bk;
+                int bi, be;
+                if (!wave_best(lk, li, le, bk, bi, be)) break;        // (the same in every wave)
+                if (tid == 0) {
+                    win_key[round] = bk;
+                    win_idx[round] = bi;
+                    win_h[round] = ch[be];
+                    win_p[round] = cp[be];
+                }
+                pk = bk;
+                pidx = bi;
+                any_prev = true;
+                ++found;
             }
-            pk = wk;
-            pidx = wi;
-            ++found;
         }
         __syncthreads();
         for (int e = tid; e < found; e += kPkBlock) {
@@ -613,7 +696,9 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
         }
     }
     static_assert(kPkMaxK + 4 <= kPkPre && kPkPre <= kPkCap / 4, "win_* and the candidate list hold the first walks");
+    PK_STAMP(0)
     sweep(std::true_type{}, a.by_prominence ? pre : K);
+    PK_STAMP(1)
     // lowest sample of the row (NaN aside): prominence <= height - row_min
     for (int64_t b = tid; b < a.nblk; b += kPkBlock) row_min = bmin[b] < row_min ? bmin[b] : row_min;
     for (int o = 32; o > 0; o >>= 1) {
@@ -630,16 +715,24 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
     int nwin;
     if (!a.by_prominence) {
         nwin = rank_candidates(K, false);
+        PK_STAMP(2)
         walk_candidates();                       // the winners' prominences
+        PK_STAMP(3)
         if (tid < nwin) win_p[tid] = cp[tid];
     } else {
         rank_candidates(pre, false);
+        PK_STAMP(2)
         walk_candidates();                       // the highest maxima
+        PK_STAMP(3)
         nwin = rank_candidates(K, true);
+        PK_STAMP(4)
         if (tid == 0) s_thr = nwin == K ? win_key[K - 1] : -inf;   // tau
         sweep(std::false_type{}, K);
+        PK_STAMP(5)
         walk_candidates();
+        PK_STAMP(6)
         nwin = rank_candidates(K, true);
+        PK_STAMP(7)
     }
     __syncthreads();
     if (tid == 0) {
@@ -657,6 +750,7 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
     // ---- D: half-maximum crossings of every ranked peak (periods_at_half_max) -------------------
     // One wave per ranked peak (the k searches run side by side, no workgroup barriers): 256 bins per step
     // outwards from the peak, four loads per lane in flight, the nearest sign change by ballot.
+    PK_STAMP(8)
     if (!a.half_lo && !a.half_hi) return;
     for (int r = wave; r < a.k; r += kPkBlock / 64) {
         const long long idmax = r < nwin ? win_idx[r] : -1;
@@ -700,9 +794,16 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
             if (a.half_hi) a.half_hi[ob + r] = hi_abs;
         }
     }
+    PK_STAMP(9)
 }
 
 }  // namespace
+
+#ifdef PDC_PK_DBG
+extern "C" int pdc_debug_peaks_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(pk_dbg), sizeof(pk_dbg)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" {
 

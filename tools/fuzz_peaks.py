@@ -84,8 +84,10 @@ def one_case(rng):
                 want = (-1, -1) if idx[r] < 0 else half_max(x[b], idx[r], key)
                 ok = ok and (got["half_lo"][b, r], got["half_hi"][b, r]) == want
         if not ok:
-            return False, dict(n=n, k=k, by_prominence=by_prominence, row=b, want=(count, idx, prom),
-                               got=(got["count"][b], got["indices"][b], got["prominences"][b]))
+            wh = [(-1, -1) if idx[r] < 0 else half_max(x[b], idx[r], prom[r] if by_prominence else height[r]) for r in range(k)]
+            return False, dict(n=n, k=k, by_prominence=by_prominence, row=b, want=(count, idx, height, prom, wh),
+                               got=(got["count"][b], got["indices"][b], got["heights"][b], got["prominences"][b],
+                                    list(zip(got["half_lo"][b].tolist(), got["half_hi"][b].tolist()))))
     return True, None
 
 
