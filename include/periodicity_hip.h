@@ -351,15 +351,16 @@ int pdc_phase_plan_destroy(void *plan);
  * fold ((t - 0)/period) % 1 (core.py:543-544) and the stable sort by phase of the TSeries
  * constructor (core.py:473-477); the closing segment is not phase-wrapped. `m` is the scaled
  * signal of phase.py:65-66.  Samples may come in any order (equal phases keep the order given, as the
- * stable sort does); time-ordered samples - what a TSeries holds - are faster than samples in another order: the
+ * stable sort does).  Time-ordered samples - what a TSeries holds - are what the kernels are built around: the
  * periods that outlast them need no sort at all (at any size), and from 262 144 samples on a bin's samples are
- * fetched as slices of t / m (nothing is re-ordered: the kernels check and pick their way).
- * What samples in ANOTHER order cost (measured, profiles/r04_sl_shapes.txt): from 262 144 samples on every bin goes
- * through the partition lists - 1.4x at N = 1e6 (34.9 against 24.4 ms for 2048 periods) - and every period that
- * outlasts the samples takes the general kernel, ~0.1 s EACH at N = 2e6 (118 against 13 ms for the 512 periods of the
- * reference's grid, whose last ten outlast the samples): a caller with millions of unordered samples should order
- * them by time first, as the TSeries constructor does (core.py:473-477) - results are the same as long as no two
- * samples share a phase. */
+ * fetched as slices of t / m.  Samples in ANOTHER order, from 262 144 on, are ordered by time on the device first
+ * (round 5; a stable radix sort of (t, m), once per call, 0.4 ms at N = 2e6 - csrc/timesort.inc) and take the same
+ * kernels: the result is the one for TSeries(t, m), i.e. samples that share a time stamp keep the caller's order, and
+ * samples that share a phase at some period without sharing a time stamp are taken in time order there (up to
+ * round 4 such samples went through the partition lists and the general kernel - N = 2e6 x 512 periods: 118 ms;
+ * now 13.7 against 13.3 ms in order; profiles/r05_sl_shapes.txt).  Non-finite or |t| beyond 1e+-150: no time sort,
+ * the lists as before.  Below 262 144 samples the order never mattered, except that the periods which outlast the
+ * samples are then sorted like any other. */
 int pdc_stringlength_scan(const double *t, const double *m, int64_t n,
                           const double *periods, int64_t n_periods,
                           double *ell_out, int device);

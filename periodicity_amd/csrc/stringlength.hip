@@ -3108,7 +3108,7 @@ int fast_sort_batch(hipStream_t st, const double *d_t, const double *d_y, int64_
 struct SsShape {
     StreamShape h;
     bool streamed, tiled, fastsort;
-    int batch, grid_ss, grid_fb, sb, seg, seg_len;
+    int batch, grid_ss, grid_fb, sb, seg, seg_len, seg34, seg_len34;
     int64_t stride, n_pad, o_sorted, o_scratch, o_gk, o_gi, o_bad, o_sm, o_arec, o_srec, o_flag, o_part, o_fast, total;
 };
 SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
@@ -3184,6 +3184,10 @@ SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     const int seg_max = env_seg >= 1 && env_seg <= ss2::kSegMax ? env_seg : seg_rule;
     z.seg = (int)(tiles < seg_max ? (tiles < 1 ? 1 : tiles) : seg_max);
     z.seg_len = (int)((tiles + z.seg - 1) / z.seg * ss2::kSegUnit);
+    static const int env_seg34 = [] { const char *e = getenv("PDC_SS_SEG34"); return e ? atoi(e) : 0; }();
+    const int seg34_max = env_seg34 >= 1 && env_seg34 <= ss2::kSegMax ? env_seg34 : z.seg;
+    z.seg34 = (int)(tiles < seg34_max ? (tiles < 1 ? 1 : tiles) : seg34_max);
+    z.seg_len34 = (int)((tiles + z.seg34 - 1) / z.seg34 * ss2::kSegUnit);
     z.o_sorted = at;
     z.o_scratch = z.o_sorted + up((int64_t)z.batch * n * 16);
     z.o_gk = z.o_scratch + up((int64_t)z.grid_ss * ss::kArrays * z.stride * 8);
@@ -3632,9 +3636,14 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
                 const unsigned grid = (unsigned)((ta.nq + 7) / 8 * z.seg * 8);
                 hipLaunchKernelGGL(ss2::ss2_stage_kernel<1>, dim3(grid), dim3(ss2::kTh), 0, st, ta);
                 hipLaunchKernelGGL(ss2::ss2_stage_kernel<2>, dim3(grid), dim3(ss2::kTh), 0, st, ta);
-                hipLaunchKernelGGL(ss2::ss2_stage_kernel<3>, dim3(grid), dim3(ss2::kTh), 0, st, ta);
-                hipLaunchKernelGGL(ss2::ss2_stage_kernel<4>, dim3(grid), dim3(ss2::kTh), 0, st, ta);
-                hipLaunchKernelGGL(ss2::ss2_finish_kernel, dim3((unsigned)((ta.nq + 63) / 64)), dim3(64), 0, st, ta);
+                // (the last two sweeps keep up to four workgroups per CU: they may take more segments per period)
+                ss2::Args tb = ta;
+                tb.seg = z.seg34;
+                tb.seg_len = z.seg_len34;
+                const unsigned grid34 = (unsigned)((ta.nq + 7) / 8 * z.seg34 * 8);
+                hipLaunchKernelGGL(ss2::ss2_stage_kernel<3>, dim3(grid34), dim3(ss2::kTh), 0, st, tb);
+                hipLaunchKernelGGL(ss2::ss2_stage_kernel<4>, dim3(grid34), dim3(ss2::kTh), 0, st, tb);
+                hipLaunchKernelGGL(ss2::ss2_finish_kernel, dim3((unsigned)((ta.nq + 63) / 64)), dim3(64), 0, st, tb);
             }
         }
 #ifdef PDC_SS_DBG   // (developer builds: s_memrealtime stamps of one tile of sweep PDC_SS_DBG, 10 ns ticks)
