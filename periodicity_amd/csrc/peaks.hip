@@ -146,9 +146,15 @@ constexpr int kPkPre = 68;           // by prominence: the first walks go to the
 #ifndef PDC_PK_WALK_LOADS
 #define PDC_PK_WALK_LOADS 8
 #endif
-constexpr int kPkWalkLoads = PDC_PK_WALK_LOADS;   // loads a lane of a walk has in flight: 16 lanes x 4 = 64 bins per memory latency.
-                                                  // (Round 5: 6 / 8 / 16 - a 256-bin block in one latency instead of four - cost
-                                                  // 81 / 85 / 96 registers, i.e. the sixth workgroup per CU: not taken)
+constexpr int kPkWalkLoads = PDC_PK_WALK_LOADS;   // loads a lane of a walk has in flight: 16 lanes x 8 = 128 bins per memory latency
+                                                  // (round 5, with 32-bit bin numbers inside a walk: 4 / 8 / 16 loads = 70 / 77 / 95
+                                                  // registers; with 64-bit ones 8 cost the sixth workgroup per CU)
+#ifndef PDC_PK_AHEAD
+#define PDC_PK_AHEAD 2               // chunks in flight ahead of the one examined (first sweep).  Round 5: 2 - with the walks'
+                                     // 32-bit bin numbers it fits the 80 registers of six workgroups per CU (round 3: it cost the
+                                     // sixth and measured the same); same box k = 1 / 4 / 8 by height 0.362 / 0.438 / 0.473 ->
+                                     // 0.340 / 0.428 / 0.455 ms, by prominence 0.532 / 0.592 / 0.703 -> 0.50 / 0.59 / 0.693
+#endif
 constexpr int kPkChunk = 1024;       // bins per sweep step
 constexpr int kPkFusedShift = 8;     // 256-bin blocks = one wave's stretch of a chunk: extrema come with the sweep
 static_assert(kPkChunk / kPkBlock * 64 == 1 << kPkFusedShift, "a wave's stretch is one block");
@@ -208,14 +214,14 @@ __device__ unsigned long long pk_dbg[8192 * 16];
 // SORT: the instance for launches of more than kPkSortFrom ranks (its rankings sort the candidate list; four more
 // registers, five workgroups per CU instead of six - which cost the few-ranks launches 10 %, so they keep their own)
 template <bool SORT>
-__global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(PeakArgs a) {
+__global__ __launch_bounds__(kPkBlock, SORT ? PDC_PK_WAVES : PDC_PK_WAVES + 1) void peaks_topk_kernel(PeakArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *bmin = reinterpret_cast<double *>(lds_raw);   // [nblk]
     double *bmax = bmin + a.nblk;                         // [nblk]
     double *ch = bmax + a.nblk;                           // [kPkCap] candidates: height,
     double *cp = ch + kPkCap;                             //          prominence (NaN: not walked yet),
     int *ci = reinterpret_cast<int *>(cp + kPkCap);               //  bin (rows have < 2^31 bins: launch_topk)
-    __shared__ int s_ncand;
+    __shared__ int s_ncand, s_first;
     __shared__ double s_thr;
     __shared__ double red_k[kPkBlock / 64];
     __shared__ int red_e[kPkBlock / 64];
@@ -333,10 +339,30 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
     // workgroup per CU).
     auto walk_candidates = [&]() __attribute__((always_inline)) {
         const int n = s_ncand;
+        // the entries without a prominence start at t0 (a ranking leaves its winners - walked - in front, a sweep appends)
+        if (tid == 0) s_first = n;
+        __syncthreads();
+        for (int e = tid; e < n; e += kPkBlock)
+            if (!(cp[e] == cp[e])) atomicMin(&s_first, e);
+        __syncthreads();
+        const int t0 = s_first;
+        if (n - t0 > 16) {
+            // many (a later launch of a k > 64 call, a second sweep that found a lot): one group per candidate, left then
+            // right, no barrier between candidates
+            for (int e = t0 + (tid >> 4); e < n; e += kPkBlock / 16) {
+                if (cp[e] == cp[e]) continue;
+                const double v = ch[e];
+                const int at = ci[e];
+                const double lo = walk(at, -1, v), hi = walk(at, +1, v);
+                if (gl == 0) cp[e] = v - (lo > hi ? lo : hi);
+            }
+            __syncthreads();
+            return;
+        }
         const int slot = (tid >> 4) & 7;
         const bool right = __builtin_amdgcn_readfirstlane(wave) >= 2;
         int par = 0;
-        for (int base = 0; base < n; base += 8, par ^= 1) {
+        for (int base = t0; base < n; base += 8, par ^= 1) {
             const int e = base + slot;
             if (e < n && !(cp[e] == cp[e])) {
                 const double v = ch[e];
@@ -588,7 +614,13 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
         // (first sweep: one chunk ahead of the one being examined; two ahead measured the same and cost the
         // registers that decide between five and six workgroups per CU)
         double v[kPer], halo_lo, halo_hi, vn[kPer], next_lo = nan, next_hi = nan;
+#if PDC_PK_AHEAD == 2
+        double vnn[kPer], nn_lo = nan, nn_hi = nan;
+#endif
         if (FIRST) load(0, v, halo_lo, halo_hi);
+#if PDC_PK_AHEAD == 2
+        if (FIRST) load(kPkChunk, vn, next_lo, next_hi);
+#endif
         // Second sweep: tau only rises, so a chunk whose block maxima rule a candidate out at the INITIAL tau
         // never needs a look - found for all chunks at once, and those chunks cost neither a barrier nor an
         // LDS scan below (of 49 chunks of a C3 row a handful remain)
@@ -609,7 +641,11 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
         for (int64_t c0 = 0; c0 < nf; c0 += kPkChunk) {
             const int64_t c1 = c0 + kPkChunk < nf ? c0 + kPkChunk : nf;
             if (masked && !((s_need[(c0 / kPkChunk) >> 5] >> ((c0 / kPkChunk) & 31)) & 1u)) continue;   // (workgroup-uniform)
+#if PDC_PK_AHEAD == 2
+            if (FIRST) load(c0 + 2 * kPkChunk, vnn, nn_lo, nn_hi);
+#else
             if (FIRST) load(c0 + kPkChunk, vn, next_lo, next_hi);
+#endif
             __syncthreads();   // everyone is done with the previous chunk (and sees s_thr / s_ncand)
             if (s_ncand > kPkCap / 2) {   // (workgroup-uniform) a chunk adds at most kPkChunk / 2 maxima
                 if (!FIRST) walk_candidates();
@@ -673,6 +709,12 @@ __global__ __launch_bounds__(kPkBlock, PDC_PK_WAVES) void peaks_topk_kernel(Peak
                 for (int j = 0; j < kPer; ++j) v[j] = vn[j];
                 halo_lo = next_lo;
                 halo_hi = next_hi;
+#if PDC_PK_AHEAD == 2
+#pragma unroll
+                for (int j = 0; j < kPer; ++j) vn[j] = vnn[j];
+                next_lo = nn_lo;
+                next_hi = nn_hi;
+#endif
             }
         }
         __syncthreads();
