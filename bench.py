@@ -508,6 +508,30 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
         out[key] = entry
         for b in bl + [bel, wl]:
             b.free()
+    # -- samples in any order (the C ABI allows it, a TSeries never is): ordered by time on the device first
+    # (csrc/timesort.inc), then the kernels a TSeries gets.  N = 2e6 x 512 is the shape the round-4 review measured at
+    # 118 ms (lists mode + the general kernel for the periods that outlast the samples) against 13 ms in order.
+    n_l, np_l = 2_000_000, 512
+    tl, yl, _ = synth_curve(n_l, 5, period=13.7)
+    ml = (yl - yl.max()) / (2 * (yl.max() - yl.min())) + 0.25
+    dfl = 0.1 / (tl[-1] - tl[0])
+    pl = 1 / np.linspace(np_l * dfl, dfl, np_l)
+    order = np.random.default_rng(n_l).permutation(n_l)
+    wbl = lib.pdc_stringlength_work_bytes(n_l, np_l)
+    bel, wl = DB(np_l * 8, dev), DB(wbl, dev)
+    ms_by_order = {}
+    for name, tt_, mm_ in (("in_order", tl, ml), ("shuffled", tl[order], ml[order])):
+        bl = [DB.from_array(a_, dev) for a_ in (tt_, mm_, pl)]
+        ms_by_order[name] = tm.ms(lambda: cabi.check(lib.pdc_stringlength_scan_dev(dev, stream, bl[0].ptr, bl[1].ptr, n_l, bl[2].ptr,
+                                                                                   np_l, bel.ptr, wl.ptr, wbl)), reps=3)
+        for b in bl:
+            b.free()
+    out["sl_any_order_2e6"] = {"ms": round(ms_by_order["shuffled"], 3), "ms_in_order": round(ms_by_order["in_order"], 3),
+                               "n_samples": n_l, "n_periods": np_l, "round4_ms": 117.3,
+                               "note": "samples shuffled: stable radix sort by time on the device (8 passes of 8 bits), then the "
+                                       "streamed kernels' slices mode; round 4 took the lists mode and the general kernel"}
+    bel.free()
+    wl.free()
     # (all GPU legs run back to back; the CPU baselines of C5 follow at the end of this function)
     ms = tm.ms(lambda: cabi.check(lib.pdc_aov_scan_dev(dev, stream, bt5.ptr, bx.ptr, n, bp.ptr, n_per, 10, bth.ptr)),
                reps=5, warm=4)

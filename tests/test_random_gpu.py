@@ -227,6 +227,50 @@ def test_stringlength_random_cases(seed=13):
         np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12, err_msg=str(case))
 
 
+def test_streamed_samples_in_any_order_random(seed=29):
+    """N >= 262 144 handed over out of order (shuffled, reversed, two ordered halves swapped, a few strays): the device
+    orders the samples by time first (csrc/timesort.inc, stable) - the result is the oracle's for the time-ordered
+    series, duplicates of a time stamp in the caller's order.  Time stamps: uniform, integer (many duplicates), with
+    gaps, negative, straddling zero, a narrow range on a large offset."""
+    rng = np.random.default_rng(seed)
+    for case in range(6):
+        n = int(rng.choice([262_144, 263_001, 300_000, 420_000]))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            t = rng.uniform(0.0, float(n), n)
+        elif kind == 1:
+            t = rng.integers(0, n // 3, n).astype(float)                  # every stamp ~3 times
+        elif kind == 2:
+            t = rng.uniform(0.0, float(n), n)
+            t[t > 0.4 * n] += 0.8 * n                                      # a gap of many periods
+            t -= 0.7 * n
+        elif kind == 3:
+            t = rng.uniform(-0.5 * n, 0.5 * n, n)
+            t[rng.integers(0, n, 8)] = rng.choice([0.0, -0.0], 8)
+        else:
+            t = 2454953.5 + rng.uniform(0.0, 400.0, n)
+        how = int(rng.integers(0, 4))
+        ts = np.sort(t)
+        if how == 0:
+            t = ts[rng.permutation(n)]
+        elif how == 1:
+            t = ts[::-1].copy()
+        elif how == 2:
+            t = np.concatenate([ts[n // 2:], ts[:n // 2]])
+        else:
+            t = ts.copy()
+            stray = rng.integers(0, n, 5)
+            t[stray] = ts[rng.integers(0, n, 5)]
+        y = np.sin(2 * np.pi * t / 13.7) + 0.2 * rng.standard_normal(n)
+        m = so.stringlength_scale(y)
+        base = ts[-1] - ts[0]
+        periods = np.concatenate([rng.uniform(base / 180.0, base / 3.0, 4), [base * 1.7, 13.7]])
+        back = np.argsort(t, kind="stable")
+        got = _cabi.stringlength_scan(t, m, periods)
+        want = so.stringlength_scan(t[back], m[back], periods)
+        np.testing.assert_allclose(got, want, rtol=1e-9, err_msg=f"case {case} kind {kind} how {how}")
+
+
 def test_nan_and_inf_inputs_propagate_like_numpy():
     rng = np.random.default_rng(3)
     t, y, dy = random_curve(rng, 200)
