@@ -3125,7 +3125,8 @@ SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     // n = 5e4 -, but at least one full sub-batch of the smoother, and the streamed kernels' own 384 from n = 18 000 down)
     static const int64_t env_cap = [] { const char *e = getenv("PDC_SS_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
     int64_t sub = ((int64_t)3 << 29) / (72 * (n > 0 ? n : 1)) / 8 * 8;     // the smoother's sub-batch (below)
-    const int64_t sub_max = n >= 40000 ? ss2::kSubBatch : (n >= 10000 ? 128 : 384);
+    static const int64_t env_submax = [] { const char *e = getenv("PDC_SS_SUBMAX"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
+    const int64_t sub_max = env_submax >= 8 ? env_submax : (n >= 40000 ? ss2::kSubBatch : (n >= 10000 ? 128 : 384));
     sub = sub < 8 ? 8 : (sub > sub_max ? sub_max : sub);
     int64_t list_cap = 7000000 / (n > 0 ? n : 1);
     list_cap = list_cap < sub ? sub : (list_cap > 384 ? 384 : list_cap / sub * sub);

@@ -9,9 +9,11 @@ bash tools/collect_pmc.sh "$out/pmc" > "$out/pmc.log" 2>&1
 cp "$out/pmc/pmc_summary.json" profiles/r05_pmc_summary.json     # bench.py reads it from there (this lease only)
 python3 bench.py > "$out/bench_n1.json" 2> "$out/bench_n1.err"
 python3 bench.py --loopback 8 > "$out/bench_loopback8.json" 2> "$out/bench_loopback8.err"
-(LARGE=1 python3 tools/sl_shapes.py; SHAPES=29000x300,50000x1000,74326x1000,60000x20000,131000x8192,250000x4096,300000x4096,400000x2048,1000000x8192,2000000x512,3000000x256 python3 tools/sl_shapes.py; echo "== lists mode only (PDC_SL_SLICES=0: what samples in any order get)"; PDC_SL_SLICES=0 SHAPES=300000x4096,400000x2048,1000000x2048,2000000x512 python3 tools/sl_shapes.py; echo "== samples in a random order (ordered by time on the device first: timesort.inc)"; SHUFFLE=1 SHAPES=300000x4096,400000x2048,1000000x2048,2000000x512 python3 tools/sl_shapes.py; echo "== no streamed kernels, no bit planes (round-3 dispatch)"; PDC_SL_STREAM=0 PDC_SL_P17=0 LARGE=1 python3 tools/sl_shapes.py) > "$out/sl_shapes.txt" 2>&1
+(LARGE=1 python3 tools/sl_shapes.py; SHAPES=29000x300,50000x1000,74326x1000,60000x20000,131000x8192,250000x4096,300000x4096,400000x2048,1000000x8192,2000000x512,3000000x256 python3 tools/sl_shapes.py; echo "== lists mode only (PDC_SL_SLICES=0: what samples in any order got up to round 4)"; PDC_SL_SLICES=0 SHAPES=300000x4096,400000x2048,1000000x2048,2000000x512 python3 tools/sl_shapes.py; echo "== samples in a random order (ordered by time on the device first: timesort.inc)"; SHUFFLE=1 SHAPES=300000x4096,400000x2048,1000000x2048,2000000x512 python3 tools/sl_shapes.py; echo "== no streamed kernels, no bit planes (round-3 dispatch)"; PDC_SL_STREAM=0 PDC_SL_P17=0 LARGE=1 python3 tools/sl_shapes.py) > "$out/sl_shapes.txt" 2>&1
 python3 tools/bootstrap_e2e.py 20000 1000 > "$out/bootstrap_e2e.txt" 2>&1
 python3 tools/pdm_shapes.py > "$out/pdm_shapes.txt" 2>&1
 SHAPES=2000x10000,4096x20000,10000x8192,50000x4096,74326x2048,200000x512,1000000x96 python3 tools/ss_timing.py > "$out/ss_timing.txt" 2>&1
 python3 tools/peaks_timing.py > "$out/peaks_timing.txt" 2>&1
+# where a row of peaks_topk_kernel spends its time: stamps of all rows from a -DPDC_PK_DBG build (built here, removed again)
+(bash tools/ab_build.sh pkdbg "-DPDC_PK_DBG=1" peaks.hip && for a in "4 1" "4 0" "1 0"; do PDC_LIBRARY=periodicity_amd/libpdc_ab_pkdbg.so python3 tools/peaks_stamps.py $a; done; rm -f periodicity_amd/libpdc_ab_pkdbg.so) > "$out/peaks_stamps.txt" 2>&1
 cut -c1-160 "$out/bench_n1.json"
