@@ -150,7 +150,8 @@ def test_phase_plan_takes_the_workspace_without_lists_when_the_host_sees_it_can(
     """the phase plan sized every StringLength / Supersmoother slot for the streamed kernels' bin
     lists (~12 GB per slot from 262 144 samples on) even for time-ordered input.  The plan holds the host arrays at
     scan time, so it now runs the host's test (every period takes the slices / one-cycle modes?) per slab and asks
-    for the workspace without lists; unordered samples keep the lists.  Same values either way."""
+    for the workspace without lists; samples out of order are ordered by time on the device first (round 5) and need none
+    either, non-tame time stamps keep them.  Same values either way."""
     rng = np.random.default_rng(44)
     n = 300_000
     t = np.sort(rng.uniform(0, float(n), n))
@@ -167,6 +168,16 @@ def test_phase_plan_takes_the_workspace_without_lists_when_the_host_sees_it_can(
     order = rng.permutation(n)
     np.testing.assert_allclose(_cabi.stringlength_scan(t[order], m[order], periods[:4], devices=(0, 0)),
                                co.stringlength_scan(t[order], m[order], periods[:4]), rtol=1e-9)
+    # (round 5) out of order the samples are ordered by time on every slot's device first: the same bits as one device,
+    # the oracle's result for the time-ordered series, and no lists in the slots' workspaces either
+    back = np.argsort(t[order], kind="stable")
+    shuffled_one = _cabi.stringlength_scan(t[order], m[order], periods)
+    assert np.array_equal(shuffled_one, _cabi.stringlength_scan(t[order], m[order], periods, devices=(0, 0, 0)))
+    np.testing.assert_allclose(shuffled_one, co.stringlength_scan(t[order][back], m[order][back], periods), rtol=1e-9)
+    ss_p = np.array([2.1, 13.7, 0.31 * t[-1], 1.7 * t[-1]])
+    ss_shuffled = _cabi.supersmoother_scan(t[order], y[order], ss_p, 0.0, devices=(0, 0))
+    assert np.array_equal(ss_shuffled, _cabi.supersmoother_scan(t[order], y[order], ss_p, 0.0))
+    np.testing.assert_allclose(ss_shuffled, _cabi.supersmoother_scan(t, y, ss_p, 0.0), rtol=1e-12)
     ss_one = _cabi.supersmoother_scan(t[:60_000], y[:60_000], periods[:6] / 50.0, 0.0)
     ss_two = _cabi.supersmoother_scan(t[:60_000], y[:60_000], periods[:6] / 50.0, 0.0, devices=(0, 0))
     np.testing.assert_allclose(ss_two, ss_one, rtol=1e-12)
