@@ -339,6 +339,22 @@ def test_streamed_stringlength_samples_in_any_order_without_the_time_sort():
     _sl_oracle_full(["300000x96u", "262144x64du"], PDC_SL_TIMESORT="0")
 
 
+def test_time_sort_at_the_largest_streamed_size():
+    """N = 5e6 (the streamed kernels serve up to 5.5 M samples; 2442 tiles in the time sort): shuffled samples give the
+    bits of the same samples in order - no time stamp is repeated here, so the sorted arrays are the same arrays."""
+    rng = np.random.default_rng(8)
+    n = 5_000_000
+    t = np.sort(rng.uniform(-1e6, 4e6, n))
+    assert np.all(np.diff(t) > 0)
+    m = so.stringlength_scale(np.sin(2 * np.pi * t / 1234.5) + 0.2 * rng.standard_normal(n))
+    df = 0.1 / (t[-1] - t[0])
+    periods = 1 / np.linspace(24 * df, df, 24)
+    want = _cabi.stringlength_scan(t, m, periods)
+    order = rng.permutation(n)
+    assert np.array_equal(_cabi.stringlength_scan(t[order], m[order], periods), want)
+    np.testing.assert_allclose(want[[0, 23]], co.stringlength_scan(t, m, periods[[0, 23]]), rtol=RTOL)
+
+
 def test_several_slice_stringlength_every_period_against_the_oracle():
     """The several-slice instances of sl_fast_kernel (52 112 < N < 262 144; 16-bit indices + bit planes): all periods."""
     _sl_oracle_full(["74326x2048", "131000x1024d", "200000x1024o", "261000x512"])
