@@ -388,9 +388,16 @@ def test_gls_shared_time_axis_random(seed=23):
         offsets = np.arange(B + 1) * n
         power, amax, argmax = _cabi.gls_scan_batch(t, y.ravel(), None if dy is None else dy.ravel(), offsets, f0, delta, nf,
                                                    fit_mean, psd, shared_t=True, want_peaks=True)
+        # bins with less than half a cycle over the baseline are ill-conditioned (the sinusoid is nearly the constant
+        # / a line: the normal equations cancel to ~1e-7 of their terms) - there two kernels that sum in different
+        # orders agree to Tier E's 1e-6, not to 1e-9 (seed 20004 of tools/fuzz_gpu.py: f T = 0.015, 9e-9 apart, each
+        # within 1e-8 of the long-double sums)
+        well = (f0 + delta * np.arange(nf)) * (t[-1] - t[0]) >= 0.5
         for b in rng.choice(B, 6, replace=False):
             single = _cabi.gls_scan(t, y[b], None if dy is None else dy[b], f0, delta, nf, fit_mean, psd)
-            np.testing.assert_allclose(power[b], single, rtol=1e-9, atol=1e-12 * np.nanmax(np.abs(single)))
+            atol = 1e-12 * np.nanmax(np.abs(single))
+            np.testing.assert_allclose(power[b][well], single[well], rtol=1e-9, atol=atol)
+            np.testing.assert_allclose(power[b][~well], single[~well], rtol=1e-6, atol=atol)
             assert argmax[b] == np.nanargmax(power[b]) and amax[b] == np.nanmax(power[b])
 
 
