@@ -339,6 +339,22 @@ def test_streamed_stringlength_samples_in_any_order_without_the_time_sort():
     _sl_oracle_full(["300000x96u", "262144x64du"], PDC_SL_TIMESORT="0")
 
 
+def test_untame_time_stamps_out_of_order_keep_the_lists_mode():
+    """Out of order AND a time stamp the exact fold cannot take the fast way (|t| beyond 1e150), or a NaN: no time sort on
+    the device (sl_tame_kernel's first flag), the lists mode as before - values as the oracle's on the arrays as given."""
+    rng = np.random.default_rng(19)
+    n = 262_144
+    t = rng.uniform(0.0, 5000.0, n)
+    m = so.stringlength_scale(np.sin(2 * np.pi * t / 13.7) + 0.2 * rng.standard_normal(n))
+    periods = np.array([3.3, 13.7, 47.0, 900.0])
+    t[12345] = 1e200
+    np.testing.assert_allclose(_cabi.stringlength_scan(t, m, periods), co.stringlength_scan(t, m, periods), rtol=RTOL)
+    t[777] = np.nan
+    with np.errstate(all="ignore"):
+        want = so.stringlength_scan(t, m, periods)
+    np.testing.assert_allclose(_cabi.stringlength_scan(t, m, periods), want, rtol=RTOL, equal_nan=True)
+
+
 def test_time_sort_at_the_largest_streamed_size():
     """N = 5e6 (the streamed kernels serve up to 5.5 M samples; 2442 tiles in the time sort): shuffled samples give the
     bits of the same samples in order - no time stamp is repeated here, so the sorted arrays are the same arrays."""
