@@ -383,7 +383,9 @@ int pdc_stringlength_scan_multi(const double *t, const double *m, int64_t n,
  * oracle restates the published Fortran (oracle/scan_oracle.py: supersmoother*) in exact-to-rounding window sums -
  * for phases crowded into a sliver of the cycle (periods thousands of baselines long) the Fortran's own
  * double-precision updating formulas lose the windows' variances; the device follows the oracle there, not them.
- * The device form takes resident inputs and a workspace of pdc_supersmoother_work_bytes(n, n_periods) bytes. */
+ * Samples may come in any order, as for pdc_stringlength_scan (from 262 144 samples on they are ordered by time on the
+ * device first).  The device form takes resident inputs and a workspace of pdc_supersmoother_work_bytes(n, n_periods)
+ * bytes. */
 int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const double *periods, int64_t n_periods,
                            double alpha, double *stat_out, int device);
 int pdc_supersmoother_scan_multi(const double *t, const double *y, int64_t n, const double *periods, int64_t n_periods,
