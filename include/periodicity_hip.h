@@ -359,8 +359,9 @@ int pdc_phase_plan_destroy(void *plan);
  * samples that share a phase at some period without sharing a time stamp are taken in time order there (up to
  * round 4 such samples went through the partition lists and the general kernel - N = 2e6 x 512 periods: 118 ms;
  * now 13.7 against 13.3 ms in order; profiles/r05_sl_shapes.txt).  Non-finite or |t| beyond 1e+-150: no time sort,
- * the lists as before.  Below 262 144 samples the order never mattered, except that the periods which outlast the
- * samples are then sorted like any other. */
+ * the lists as before.  Below 262 144 samples the kernels sort any order by phase directly: the periods which outlast
+ * the samples are then sorted like any other, and two samples that share a phase WITHOUT sharing a time stamp keep the
+ * caller's order there (above: the time order, as the reference's TSeries would have it - core.py:473-477). */
 int pdc_stringlength_scan(const double *t, const double *m, int64_t n,
                           const double *periods, int64_t n_periods,
                           double *ell_out, int device);
