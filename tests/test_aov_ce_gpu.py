@@ -4,6 +4,7 @@ the PDM binning kernel, against oracle/scan_oracle.py's restatement of the publi
 import numpy as np
 import pytest
 
+from oracle import c_oracle as co
 from oracle import scan_oracle as so
 from periodicity_amd import _cabi, phase
 from periodicity_amd.core import TSeries
@@ -102,17 +103,32 @@ def test_classes_find_the_period():
 
 
 def test_full_size_c5_aov_and_entropy():
-    """BASELINE configs[4] shape (N=5e4 x 1e5 trial periods) through both new scans; spot-checked."""
+    """BASELINE configs[4] shape (N=5e4 x 1e5 trial periods) through the scans the reference only names: EVERY
+    period against the C restatement of the published formulas (`oracle/scan_oracle.c`, itself tied to the numpy
+    form in tests/test_oracle_golden.py) - round 6, was 25 periods - and the optimum's index identical."""
     n, n_per = 50_000, 100_000
     t, x = curve(n, 20241012)
     periods = np.linspace(1.0, 100.0, n_per)
     pick = np.random.default_rng(0).integers(0, n_per, 25)
     aov = _cabi.aov_scan(t, x, periods, 10)
-    np.testing.assert_allclose(aov[pick], so.aov_scan(t, x, periods[pick], 10), rtol=RTOL)
+    np.testing.assert_allclose(co.aov_scan(t, x, periods[pick], 10), so.aov_scan(t, x, periods[pick], 10), rtol=1e-11)
+    want = co.aov_scan(t, x, periods, 10)
+    np.testing.assert_allclose(aov, want, rtol=RTOL)
+    assert int(np.argmax(aov)) == int(np.argmax(want))
     mag = so.magnitude_bins(x, 5)
     ce = _cabi.cond_entropy_scan(t, mag, periods, 10, 5)
-    np.testing.assert_allclose(ce[pick], so.cond_entropy_scan(t, mag, periods[pick], 10, 5), rtol=RTOL)
+    np.testing.assert_allclose(co.cond_entropy_scan(t, mag, periods[pick], 10, 5),
+                               so.cond_entropy_scan(t, mag, periods[pick], 10, 5), rtol=1e-12)
+    want = co.cond_entropy_scan(t, mag, periods, 10, 5)
+    np.testing.assert_allclose(ce, want, rtol=RTOL)
+    assert int(np.argmin(ce)) == int(np.argmin(want))
     assert abs(periods[np.argmax(aov)] - 13.7) < 0.05 and abs(periods[np.argmin(ce)] - 13.7) < 0.05
+    # Gregory-Loredo on the same stamps (the statistic of arrival times: only `t` enters), m = 6 bins x 4 offsets
+    gl = _cabi.gl_scan(t, periods, 6, 4)
+    np.testing.assert_allclose(co.gl_scan(t, periods[pick], 6, 4), so.gl_scan(t, periods[pick], 6, 4), rtol=1e-11, atol=1e-9)
+    want = co.gl_scan(t, periods, 6, 4)
+    np.testing.assert_allclose(gl, want, rtol=RTOL, atol=1e-9)
+    assert int(np.argmax(gl)) == int(np.argmax(want))
 
 
 # ---- Gregory-Loredo (phase.py:13, TODO upstream): counts-only histogram path -----------------------------------

@@ -460,6 +460,17 @@ def test_full_size_c2_properties():
     rel = np.abs(power[pick] - exact) / np.abs(exact)
     assert rel.max() <= RTOL, rel.max()
     assert peak == pick[np.argmax(exact)]                 # the oracle's maximum over the sampled bins is the peak
+    # round 6 - EVERY bin: the double-precision direct sums (oracle_gls_sums_f64: pair-by-pair evaluation, exact
+    # cycle reduction; pinned to the long-double sums on goldens in tests/test_oracle_golden.py) first re-proved
+    # on the 4400 stratified bins against the long-double oracle, then trusted on all 1e6 (1e11 pairs on the host)
+    fast = np.asarray(co.gls_power_f64(t, y, dy, freq[pick]))
+    assert np.max(np.abs(fast - exact) / np.abs(exact)) <= 1e-10
+    full = np.asarray(co.gls_power_f64(t, y, dy, freq))
+    assert full.shape == power.shape and np.all(full > 0)
+    rel = np.abs(power - full) / np.abs(full)
+    assert rel.max() <= RTOL, (rel.max(), int(np.argmax(rel)))
+    assert int(np.argmax(full)) == peak                   # peak-period index bit-exact over the whole grid
+    del full, rel
     # normalised power is invariant under y -> a*y + b
     again = _cabi.gls_scan(t, 3.0 * y - 7.0, 3.0 * dy, f0, delta, nf)
     np.testing.assert_allclose(again, power, rtol=1e-7, atol=1e-14)
@@ -508,6 +519,21 @@ def test_full_size_c3_batch_peaks_only():
         assert_tier_e(power[b], exact)
         assert argmax[b] == int(np.argmax(exact)) and abs(amax[b] / exact.max() - 1) < 1e-9
         assert argmax[b] == int(np.nanargmax(so.gls_power(t[b], y[b], dy[b], freq, delta, f0, sums="fft")))   # Tier R
+    # round 6 - EVERY curve at EVERY bin: 4096 spectra x 5e4 bins against the double-precision direct sums (4.1e11
+    # pairs on the host; the checker re-proved against the long-double oracle on the 8 curves above), and every
+    # curve's argmax / amax as the peaks-only launch reported them
+    worst = 0.0
+    for b in range(B):
+        fast = np.asarray(co.gls_power_f64(t[b], y[b], dy[b], freq))
+        if b in (0, B - 1):
+            exact = np.asarray(co.gls_power_exact(t[b], y[b], dy[b], freq))
+            ok = np.abs(exact) > 1e-13 * np.abs(exact).max()
+            assert np.max(np.abs(fast[ok] - exact[ok]) / np.abs(exact[ok])) <= 1e-10
+        worst = max(worst, assert_tier_e(power[b], fast))
+        k = int(np.argmax(fast))
+        assert argmax[b] == k, (b, argmax[b], k)
+        assert abs(amax[b] / fast[k] - 1) < 1e-9
+    assert worst <= RTOL
     del power
     # the same batch reduced to its 4 highest / most prominent find_peaks() maxima with prominences and
     # half-maximum crossings (core.py:283-317, 944-978): 1.64 GB of spectra stay in HBM
@@ -597,6 +623,16 @@ def test_full_size_c4_on_one_gpu_both_paths():
     exact = co.gls_power_exact(t, y, dy, f0 + delta * pick)
     assert np.max(np.abs(power[pick] - exact) / np.abs(exact)) <= RTOL
     assert peak == pick[np.argmax(exact)]
+    # round 6 - one FULL slab (the last: the highest frequencies, the longest phases) and the 8192 bins around the
+    # peak against the double-precision direct sums (1.26e12 pairs on the host), the checker first re-proved on
+    # the sampled bins against the long-double oracle
+    fast = np.asarray(co.gls_power_f64(t, y, dy, f0 + delta * pick))
+    assert np.max(np.abs(fast - exact) / np.abs(exact)) <= 1e-10
+    for a, b in ((nf - slab, nf), (max(0, peak - 4096), peak + 4096)):
+        full = np.asarray(co.gls_power_f64(t, y, dy, f0 + delta * np.arange(a, b)))
+        assert_tier_e(power[a:b], full)
+        assert int(np.argmax(full)) == int(np.argmax(power[a:b]))
+    assert a + int(np.argmax(full)) == peak
 
 
 _SHAPE_CHECK = """

@@ -208,3 +208,73 @@ def test_gregory_loredo_restatement_is_the_multinomial_multiplicity():
         want = math.log(sum(terms) / n_off)
         assert abs(so.gl_log_s(t, period, m, n_off) - want) < 1e-9 * abs(want)
     assert np.isnan(so.gl_log_s(np.array([np.nan, np.nan]), 3.0, 2, 2))
+
+
+# ---- the fast C checkers used for EXHAUSTIVE parity at the BASELINE sizes ------------------------------
+@pytest.mark.parametrize("n", [1000, 5000])
+def test_double_precision_direct_sums_are_pinned_to_the_long_double_ones(golden_dir, n):
+    """`oracle_gls_sums_f64` (pairwise evaluation in double: exact cycle reduction + Cephes polynomials) against
+    the goldens' long-double seam sums and spectrum - the chain that lets the GPU suite check ALL 1e6 bins of C2."""
+    g = load(golden_dir, f"g4_synth{n}")
+    t, y, dy, f = g["t"], g["y"], g["dy"], g["frequency"]
+    w, yc, _ = so.gls_weights(y, dy, True)
+    Sh, Ch, S, C, S2, C2 = co.gls_sums_f64(t, w * yc, w, f)
+    scale_h, scale_w = np.abs(w * yc).sum(), np.abs(w).sum()
+    assert np.max(np.abs(Sh - g["Sh_exact"])) <= 1e-13 * scale_h and np.max(np.abs(Ch - g["Ch_exact"])) <= 1e-13 * scale_h
+    Se, Ce = co.trig_sums_exact(t, w, f)
+    S2e, C2e = co.trig_sums_exact(t, w, 2 * f)
+    for got, want in ((S, Se), (C, Ce), (S2, S2e), (C2, C2e)):
+        assert np.max(np.abs(got - want)) <= 1e-13 * scale_w
+    for fit_mean in (True, False):
+        p = co.gls_power_f64(t, y, dy, f, fit_mean=fit_mean)
+        want = co.gls_power_exact(t, y, dy, f, fit_mean=fit_mean)
+        ok = np.abs(want) > 1e-13 * np.abs(want).max()
+        assert np.max(np.abs(p[ok] - want[ok]) / np.abs(want[ok])) <= 1e-10
+        assert np.argmax(p) == np.argmax(want)
+    np.testing.assert_allclose(co.gls_power_f64(t, y, dy, f), g["power_exact"], rtol=1e-8)
+
+
+def test_double_precision_direct_sums_at_large_phases():
+    """Julian-date stamps and frequencies to 50 cycles per unit: phases of 1e8 cycles, where the reduction (not the
+    polynomial) decides the accuracy.  Also every quadrant boundary and an odd sample count (SIMD remainder)."""
+    rng = np.random.default_rng(11)
+    n = 1031
+    t = np.sort(rng.uniform(0, 90.0, n)) + 2454900.5
+    h = rng.standard_normal(n)
+    f = np.concatenate([rng.uniform(0.001, 50.0, 300), [0.0, 0.125, 0.25, 0.5, 1.0]])
+    Sh, Ch, S, C, S2, C2 = co.gls_sums_f64(t, h, np.abs(h), f)
+    Se, Ce = co.trig_sums_exact(t, h, f)
+    # the long-double reference itself carries 2 pi f t rounded to 64 bits: |phase| 8e8 rad x 5.4e-20 = 4e-11
+    tol = 1e-10 * np.abs(h).sum()
+    assert np.max(np.abs(Sh - Se)) <= tol and np.max(np.abs(Ch - Ce)) <= tol
+    S2e, C2e = co.trig_sums_exact(t, np.abs(h), 2 * f)
+    assert np.max(np.abs(S2 - S2e)) <= 2 * tol and np.max(np.abs(C2 - C2e)) <= 2 * tol
+    # exact multiples of an eighth of a cycle at f = 1: the quadrant logic, against the known values 0, +-sqrt(1/2), +-1
+    known = {0: 0.0, 1: np.sqrt(0.5), 2: 1.0, 3: np.sqrt(0.5), 4: 0.0, 5: -np.sqrt(0.5), 6: -1.0, 7: -np.sqrt(0.5)}
+    for k in range(-8, 9):
+        s, c, *_ = co.gls_sums_f64(np.array([k / 8.0]), np.ones(1), np.ones(1), np.array([1.0]))
+        assert abs(s[0] - known[k % 8]) <= 1.2e-16 and abs(c[0] - known[(k + 2) % 8]) <= 1.2e-16, k
+
+
+def test_c_restatements_of_aov_entropy_gregory_loredo_equal_the_numpy_ones():
+    rng = np.random.default_rng(3)
+    n = 3000
+    t = np.sort(rng.uniform(0, 300.0, n)) - 50.0                  # negative stamps included
+    x = 1 + np.sin(2 * np.pi * t / 13.7) + 0.2 * rng.standard_normal(n)
+    periods = np.linspace(0.5, 40.0, 300)
+    for r in (3, 10, 7):
+        np.testing.assert_allclose(co.aov_scan(t, x, periods, r), so.aov_scan(t, x, periods, r), rtol=1e-11)
+    assert np.all(np.isnan(co.aov_scan(t[:5], x[:5], periods[:3], 10)))     # n <= r: nan, as the numpy form
+    mag = so.magnitude_bins(x, 5)
+    np.testing.assert_allclose(co.cond_entropy_scan(t, mag, periods, 10, 5),
+                               so.cond_entropy_scan(t, mag, periods, 10, 5), rtol=1e-13)
+    for m, n_off in ((4, 8), (12, 8), (2, 1), (7, 5)):
+        got, want = co.gl_scan(t, periods, m, n_off), so.gl_scan(t, periods, m, n_off)
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-9)
+        assert np.argmax(got) == np.argmax(want)
+    # a period that puts a phase on a bin edge and phi == 1.0 (t just below a multiple of the period)
+    te = np.array([0.0, 0.5, 1.0, 1.5, 2.0 - 2.0 ** -52, 3.0, 3.25, 7.75, 9.0, 9.5, 10.0, 11.0])
+    xe = np.arange(te.size, dtype=float) ** 1.5
+    pe = np.array([1.0, 2.0, 0.5, 2.5, 3.0])
+    np.testing.assert_allclose(co.aov_scan(te, xe, pe, 4), so.aov_scan(te, xe, pe, 4), rtol=1e-12)
+    np.testing.assert_allclose(co.gl_scan(te, pe, 2, 2), so.gl_scan(te, pe, 2, 2), rtol=1e-12)
