@@ -214,6 +214,20 @@ def valu_issue_block(kernel_substr, kernel_ms):
     return out, None
 
 
+def executed_flops(blk, kernel_ms):
+    """fp64 flops the kernel EXECUTED per second, from the typed counters of its profiled launch: (2 x FMA_F64 +
+    ADD_F64 + MUL_F64) wave instructions x 64 lanes / this run's kernel time.  Not the issue-slot figure (`frac`
+    prices every fp64 instruction at 4 cycles whether it is an fma or a mul) and not SURVEY 8d's 50 flop per pair
+    (`algorithmic`): the arithmetic that actually went through the DP units."""
+    mix = (blk or {}).get("mix")
+    if not mix or not all(k in mix for k in ("fma_f64", "add_f64", "mul_f64")):
+        return None
+    flops = (2.0 * mix["fma_f64"] + mix["add_f64"] + mix["mul_f64"]) * 64.0
+    tf = flops / (kernel_ms * 1e-3) / 1e12
+    return {"TFLOPs": round(tf, 2), "frac_of_peak": round(tf / PEAK_FP64_VECTOR_TFLOPS, 4), "flop_per_launch": flops,
+            "counted": "(2 x SQ_INSTS_VALU_FMA_F64 + ADD_F64 + MUL_F64) x 64 lanes of the profiled launch / this run's kernel time"}
+
+
 def two_fracs(kernel_substr, ms, algorithmic_frac, unit):
     """The two roofline fields every entry of the line carries (module docstring)."""
     blk, why = valu_issue_block(kernel_substr, ms)
@@ -227,6 +241,47 @@ def two_fracs(kernel_substr, ms, algorithmic_frac, unit):
     else:
         out["executed_issue_note"] = why
     return out, blk
+
+
+def fft_path_roofline(n, nf, ms, ngrid=3):
+    """`roofline` block of the device FFT-extirpolation path (HBM-bound: every Stockham pass streams the
+    grid).  Algorithmic bytes of one pdc_gls_scan_fft_dev launch: per grid the deposits write the live cells L (the
+    part of the 2^k grid the samples reach: 1/5 at five samples per peak), pass 1 reads L and writes nfft, the
+    middle passes read and write nfft, the last pass reads nfft and writes the nf outputs that are kept
+    (spectral.py:34 `[:nf]`), 16 B a cell; the epilogue reads ngrid x nf cells and writes nf doubles; the samples
+    are read twice (prologue, deposits).  `traffic` = HBM-side bytes of the path's kernels from the PMC summary
+    (FETCH_SIZE x 2 + WRITE_SIZE per dispatch x dispatches per launch; the 256 MiB Infinity Cache holds one grid's
+    ping-pong at C2, so traffic may lie BELOW the algorithmic bytes)."""
+    nfft = 1 << int(nf * 5 - 1).bit_length()
+    bits = nfft.bit_length() - 1
+    passes = -(-bits // 8)
+    live = min(nfft, nfft // 5 + 4)
+    per_grid = 16.0 * (live + (live + nfft) + 2.0 * nfft * max(0, passes - 2) + (nfft + nf))
+    algo = ngrid * per_grid + 16.0 * ngrid * nf + 8.0 * nf + 2 * 24.0 * n
+    gbps = algo / (ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s",
+           "frac": round(gbps / (HBM_PEAK_TBS * 1000), 4), "algorithmic_bytes": algo, "passes_per_grid": passes,
+           "grids": ngrid, "nfft": nfft, "traffic": None}
+    if os.path.isfile(PMC_SUMMARY):
+        summ = json.load(open(PMC_SUMMARY))
+        now, then = source_hashes(), summ.get("src_sha", {})
+        stale = [f for f in KERNEL_SOURCES["glsfft_"] if now.get(f) != then.get(f)]
+        ks = {name: k for name, k in summ.get("kernels", {}).items()
+              if ("fft_pass" in name or "glsfft_" in name) and "hbm_bytes" in k}
+        epi = [k for name, k in ks.items() if name.startswith("glsfft_epilogue_kernel") and
+               name.endswith(f"grid={-(-nf // 256) * 256}")]
+        if stale:
+            out["traffic_note"] = f"{os.path.relpath(PMC_SUMMARY, ROOT)} predates {', '.join(stale)}: refused as stale"
+        elif epi and epi[0].get("dispatches_per_pass"):
+            launches = epi[0]["dispatches_per_pass"]
+            per_kernel = {name: {"dispatches_per_launch": k["dispatches_per_pass"] / launches, "hbm_bytes_per_dispatch": k["hbm_bytes"],
+                                 "ms_per_dispatch": k["ms"]} for name, k in ks.items() if k["dispatches_per_pass"] % launches == 0}
+            out["traffic"] = int(sum(v["dispatches_per_launch"] * v["hbm_bytes_per_dispatch"] for v in per_kernel.values()))
+            out["traffic_GBps"] = round(out["traffic"] / (ms * 1e-3) / 1e9, 1)
+            out["traffic_by_kernel"] = per_kernel
+        else:
+            out["traffic_note"] = "no profiled glsfft_epilogue_kernel launch of this grid in the PMC summary"
+    return out
 
 
 def gls_algorithmic_frac(pairs, ms):
@@ -394,7 +449,7 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
         return fn
     for key, shared, peaks, kern in (("c3_power", False, False, "gls_scan_kernel"),
                                      ("c3_peaks_only", False, True, "gls_scan_kernel"),
-                                     ("c3_shared_t_peaks_only", True, True, "gls_shared_kernel")):
+                                     ("c3_shared_t_peaks_only", True, True, "gls_shared")):
         ms = tm.ms(c3(shared, peaks), reps=3)
         fr, _ = two_fracs(kern, ms, gls_algorithmic_frac(pairs, ms), "50 flop/(pair, curve) vs 78.6 TFLOP/s")
         out[key] = {"ms": round(ms, 3), "Gpair_per_s": round(pairs / ms / 1e6, 1), **fr}
@@ -1420,6 +1475,10 @@ def main():
             "roofline": {"bound": "valu",
                          "achieved": None if achieved is None else round(achieved, 3),
                          "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s", "frac": frac,
+                         "achieved_is": "issue slots: frac x 78.6 (every fp64 / int64 VALU instruction priced at its 4 "
+                                        "issue cycles) - NOT flops; the flops are achieved_flops_TFLOPs",
+                         "achieved_flops_TFLOPs": (executed_flops(blk, kernel_ms_now) or {}).get("TFLOPs"),
+                         "achieved_flops": executed_flops(blk, kernel_ms_now),
                          "traffic": traffic,
                          "kernel": "gls_scan_kernel (+ prologue kernels, <0.1%)",
                          "kernel_ms": round(kernel_ms_now, 4),
@@ -1484,6 +1543,7 @@ def main():
             out["fft_path"] = {"ms": round(fms, 4),
                                "effective_Gpair_per_s": round(pairs_per_step / fms / 1e6, 1),
                                "peak_bin": int(np.nanargmax(fft_power)),
+                               "roofline": fft_path_roofline(n, nf_total, fms),
                                "note": "pdc_gls_scan_fft_dev: the reference's extirpolation + FFT "
                                        "algorithm on the device (approximate, like upstream); not "
                                        "the headline metric, which counts exact pair evaluations"}

@@ -95,6 +95,30 @@ def gls_sums_f64(t, hy, h, frequency):
     return out
 
 
+def gls_power_f64_batch(t, values, err, frequency, fit_mean=True, psd=False):
+    """Rows of ``gls_power_f64`` for curves of equal length (2-D ``t``, ``values``, ``err``): one OpenMP region
+    over (curve, frequency tile), the reference's prologue / epilogue per row."""
+    from . import scan_oracle as so
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    B, n = t.shape
+    w = np.empty((B, n))
+    y = np.empty((B, n))
+    for b in range(B):
+        w[b], y[b], _ = so.gls_weights(values[b], err[b], fit_mean)
+    hy = w * y
+    f = _f(frequency)
+    out = [np.empty((B, f.size)) for _ in range(6)]
+    offsets = np.arange(B + 1, dtype=np.int64) * n
+    lib().oracle_gls_sums_f64_batch(_p(t), _p(hy), _p(w), _p(offsets), C.c_int64(B), _p(f), C.c_int64(f.size),
+                                    *[_p(o) for o in out])
+    Sh, Ch, S, Cc, S2, C2 = out
+    power = np.empty((B, f.size))
+    for b in range(B):
+        power[b] = so.gls_epilogue(Sh[b], Ch[b], S2[b], C2[b], S[b] if fit_mean else None, Cc[b] if fit_mean else None,
+                                   np.dot(w[b], y[b] ** 2), fit_mean, psd, err[b])
+    return power
+
+
 def gls_power_f64(t, values, err, frequency, fit_mean=True, psd=False):
     """Reference prologue / epilogue (numpy restatement, spectral.py:99-132) around the double-precision direct
     sums: what ``gls_power_exact`` computes, ~100x faster, for exhaustive checks of 1e6-bin grids."""

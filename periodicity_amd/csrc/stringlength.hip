@@ -1831,6 +1831,23 @@ __device__ __forceinline__ bool period_and_group(const StreamArgs &a, int &q, in
     return q < a.batch;
 }
 
+// One LDS add per RUN of equal buckets among consecutive lanes (round 6).  Consecutive lanes hold consecutive samples,
+// and time-ordered samples arrive in phase order inside a cycle: at the periods this path exists for (thousands of
+// samples per cycle) a wave's 64 buckets are a handful of runs, and 64 `ds_add_u32` on one or two addresses serialised
+// (r05 PMC: 95 % of the kernel's LDS-active cycles were bank conflicts).  A lane heads a run when the lane below holds
+// another bucket (DPP wave_shr:1, lane 0 always); the run's length is the distance to the next head in the ballot.
+// Any order is still correct - equal buckets that are not neighbours are simply separate adds.  `bucket` = ~0u: none.
+__device__ __forceinline__ void hist_add_runs(unsigned *h, unsigned bucket, int lane) {
+    const unsigned below = PDC_DPP(~bucket, bucket, 0x138, 0xf);
+    const bool head = below != bucket;
+    const unsigned long long heads = __ballot(head);
+    if (head && bucket != ~0u) {
+        const unsigned long long rest = (heads >> lane) >> 1;
+        const unsigned len = rest ? (unsigned)__builtin_ctzll(rest) + 1u : 64u - (unsigned)lane;
+        atomicAdd(&h[bucket], len);
+    }
+}
+
 // (Two periods per workgroup - every sample loaded once for both - was built and measured: 244 against 236 us per 256
 // periods at N = 1e6; the kernel is not short of L2 bandwidth.)
 __global__ __launch_bounds__(kBA) void sl_hist_kernel(StreamArgs a) {
@@ -1854,8 +1871,7 @@ __global__ __launch_bounds__(kBA) void sl_hist_kernel(StreamArgs a) {
         }
         phases4(tv, period, y, safe, phi);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (live[u]) atomicAdd(&h[coarse_of<kNC>(phi[u])], 1u);
+        for (int u = 0; u < 4; ++u) hist_add_runs(h, live[u] ? (unsigned)coarse_of<kNC>(phi[u]) : ~0u, tid & 63);
     }
     __syncthreads();
     unsigned *out = a.hist + ((int64_t)q * a.groups + w) * kNC;

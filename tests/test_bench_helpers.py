@@ -45,3 +45,46 @@ def test_cpu_pool_baseline_child_process_runs():
     assert res["cores"] == 2 and res["periods_sampled"] == 16
     for key in ("pdm", "stringlength"):
         assert res[key]["map_s"] > 0 and res[key]["Gpair_per_s"] > 0
+
+
+def test_shared_axis_entry_finds_whichever_shared_kernel_ran(tmp_path, monkeypatch):
+    """Round-5 defect: the c3_shared_t entry looked up "gls_shared_kernel" while `gls_shared2_kernel` is what runs
+    (individual weights), so its issue fraction came back None.  The lookup key is now the common prefix."""
+    mix = {c: 10 for c in bench.F64_COUNTERS}
+    summ = {"src_sha": bench.source_hashes(), "kernels": {
+        "gls_shared2_kernel<true> grid=12812288": dict(mix, SQ_INSTS_VALU=40_000_000_000, ms=88.0),
+        "gls_scan_kernel<16, 0, 2, true> grid=131072": dict(mix, SQ_INSTS_VALU=13_000_000_000, ms=27.0)}}
+    path = tmp_path / "pmc.json"
+    path.write_text(json.dumps(summ))
+    monkeypatch.setattr(bench, "PMC_SUMMARY", str(path))
+    fr, blk = bench.two_fracs("gls_shared", 87.0, 2.0, "unit")
+    assert blk is not None and blk["kernel"].startswith("gls_shared2_kernel") and fr["executed_issue_frac"] is not None
+    assert bench.two_fracs("gls_shared_kernel", 87.0, 2.0, "unit")[1] is None      # the old key: no match
+
+
+def test_executed_flops_are_counted_from_the_typed_counters():
+    blk = {"mix": {"fma_f64": 12_651_000_000, "add_f64": 486_000_000, "mul_f64": 9_000_000}}
+    got = bench.executed_flops(blk, 26.35)
+    assert abs(got["TFLOPs"] - (2 * 12.651e9 + 0.486e9 + 0.009e9) * 64 / 26.35e-3 / 1e12) < 0.01     # 62.7 (round-5 verdict)
+    assert 0.79 < got["frac_of_peak"] < 0.81
+    assert bench.executed_flops(None, 1.0) is None and bench.executed_flops({"mix": {"fma_f64": 1}}, 1.0) is None
+
+
+def test_fft_path_roofline_counts_passes_and_reads_the_traffic(tmp_path, monkeypatch):
+    r = bench.fft_path_roofline(100_000, 1_000_000, 0.5)
+    assert r["bound"] == "hbm" and r["nfft"] == 1 << 23 and r["passes_per_grid"] == 3 and r["grids"] == 3
+    assert 1.5e9 < r["algorithmic_bytes"] < 2.2e9 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+    summ = {"src_sha": bench.source_hashes(), "kernels": {
+        "fft_pass_lds_kernel<16> grid=524288": {"hbm_bytes": 200_000_000, "dispatches_per_pass": 36, "ms": 0.046},
+        "glsfft_epilogue_kernel grid=1000192": {"hbm_bytes": 50_000_000, "dispatches_per_pass": 6, "ms": 0.02},
+        "glsfft_epilogue_kernel grid=4096": {"hbm_bytes": 1_000, "dispatches_per_pass": 5, "ms": 0.002},
+        "gls_scan_kernel<16, 0, 2, true> grid=131072": {"hbm_bytes": 1, "dispatches_per_pass": 6, "ms": 27.0}}}
+    path = tmp_path / "pmc.json"
+    path.write_text(json.dumps(summ))
+    monkeypatch.setattr(bench, "PMC_SUMMARY", str(path))
+    r = bench.fft_path_roofline(100_000, 1_000_000, 0.5)
+    assert r["traffic"] == 6 * 200_000_000 + 50_000_000          # per launch: 36 / 6 pass dispatches + one epilogue
+    summ["src_sha"]["glsfft.hip"] = "0" * 16
+    path.write_text(json.dumps(summ))
+    r = bench.fft_path_roofline(100_000, 1_000_000, 0.5)
+    assert r["traffic"] is None and "stale" in r["traffic_note"]
