@@ -400,6 +400,81 @@ class EventTimer:
         return float(np.median(out))
 
 
+def host_api_small(with_cpu=True, reps=25):
+    """Wall clock of the CLASS calls at the sizes the reference's own tests and bundled data have (every one of them
+    100 ... 74 326 samples: /root/reference/tests/test_spectral.py:7-31, src/periodicity/data/__init__.py:6-46) - the
+    sizes at which a drop-in is actually dropped in -, median of `reps` calls after three warm-up calls, and the
+    reference's CPU path at the same size beside each (GLS: the single-threaded numpy FFT-extirpolation restatement
+    `so.gls`; the phase scans: `multiprocessing.Pool(all cores).map` of the numpy restatement, one Pool per call as
+    phase.py:69-70,185-186, in a child process)."""
+    from periodicity_amd.core import TSeries
+    from periodicity_amd.phase import PDM, StringLength
+    from periodicity_amd.spectral import GLS
+
+    def median_ms(fn, k=reps):
+        for _ in range(3):
+            fn()
+        w = []
+        for _ in range(k):
+            ta = time.perf_counter()
+            fn()
+            w.append(time.perf_counter() - ta)
+        return round(float(np.median(w)) * 1e3, 4), round(float(np.min(w)) * 1e3, 4)
+
+    out = {}
+    # C1: BASELINE configs[0], SURVEY 8d's inputs
+    t, y, dy = synth_curve(1000, 1)
+    freq, df, fmin = throughput_grid(t, 1000)
+    fmax = fmin + (1000 - 1.5) * df
+    sig = TSeries(t, y)
+    ms, lo = median_ms(lambda: GLS(fmin=fmin, fmax=fmax)(sig, dy))
+    ms_f, lo_f = median_ms(lambda: GLS(fmin=fmin, fmax=fmax, method="fft")(sig, dy))
+    out["c1_end_to_end"] = {"n_samples": 1000, "n_freq": 1000, "class_call_ms": ms, "class_call_min_ms": lo,
+                            "class_call_fft_method_ms": ms_f, "what": "GLS(fmin, fmax)(TSeries(t, y), dy): grid + H2D + kernels + D2H + FSeries"}
+    # SpottedStar's shape (N = 2148, default grid nf = 5680): the curve itself travels as a golden fixture's INPUT
+    g3 = os.path.join(ROOT, "tests", "golden", "g3_spotted_star.npz")
+    if os.path.isfile(g3):
+        g = np.load(g3)
+        ts, ys, dys, src = g["t"], g["y"], g["dy"], "tests/golden/g3_spotted_star.npz (the reference's bundled curve)"
+    else:
+        ts, ys, dys = synth_curve(2148, 3)
+        src = "synthetic, 2148 samples"
+    sig_s = TSeries(ts, ys)
+    ms, lo = median_ms(lambda: GLS()(sig_s, dys))
+    nf_s = GLS()(sig_s, dys).size
+    out["spotted_star_end_to_end"] = {"n_samples": int(ts.size), "n_freq": int(nf_s), "class_call_ms": ms, "class_call_min_ms": lo,
+                                      "data": src, "what": "GLS()(TSeries(t, y), dy) on the default grid"}
+    # SunSpots size (74 326 samples), the phase classes' defaults (1000 periods each)
+    n_ss = 74_326
+    tl, yl, _ = synth_curve(n_ss, 5, period=13.7)
+    sig_l = TSeries(tl, yl)
+    ms_sl, lo_sl = median_ms(lambda: StringLength()(sig_l), 20)
+    ms_pdm, lo_pdm = median_ms(lambda: PDM()(sig_l), 20)
+    out["sunspots_size_stringlength_defaults"] = {"n_samples": n_ss, "n_periods": 1000, "class_call_ms": ms_sl, "class_call_min_ms": lo_sl,
+                                                  "what": "StringLength()(TSeries(t, y)): scaling + grid + H2D + kernels + D2H + FSeries"}
+    out["sunspots_size_pdm_defaults"] = {"n_samples": n_ss, "n_periods": 1000, "class_call_ms": ms_pdm, "class_call_min_ms": lo_pdm,
+                                         "what": "PDM()(TSeries(t, y))"}
+    if with_cpu:
+        from oracle import scan_oracle as so
+        cpu, _ = median_ms(lambda: so.gls(t, y, dy, fmin=fmin, fmax=fmax), 20)
+        out["c1_end_to_end"].update({"cpu_reference_path_ms": cpu, "cpu_cores": 1, "cpu_kind": "port",
+                                     "class_call_vs_cpu": round(cpu / out["c1_end_to_end"]["class_call_ms"], 2)})
+        cpu, _ = median_ms(lambda: so.gls(ts, ys, dys), 20)
+        out["spotted_star_end_to_end"].update({"cpu_reference_path_ms": cpu, "cpu_cores": 1, "cpu_kind": "port",
+                                               "class_call_vs_cpu": round(cpu / out["spotted_star_end_to_end"]["class_call_ms"], 2)})
+        cores = host_cores()
+        try:
+            run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_pool_baseline.py"), "defaults", str(n_ss), str(cores)],
+                                 capture_output=True, text=True, timeout=600, cwd=ROOT)
+            res = json.loads(run.stdout.strip().splitlines()[-1])
+            for key, name in (("sunspots_size_stringlength_defaults", "stringlength"), ("sunspots_size_pdm_defaults", "pdm")):
+                out[key].update({"cpu_pool_wall_ms": round(res[name]["wall_s"] * 1e3, 1), "cpu_cores": cores, "cpu_kind": "port",
+                                 "class_call_vs_cpu": round(res[name]["wall_s"] * 1e3 / out[key]["class_call_ms"], 1)})
+        except Exception as exc:                              # informational: never fail the bench
+            out["sunspots_cpu_error"] = f"{type(exc).__name__}: {exc}"
+    return out
+
+
 def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=True):
     """Kernel-level numbers of the other single-GPU configs (BASELINE.json configs[2], [4]) and the
     PCIe-inclusive rate of the headline config, so that they appear in the driver's record."""
@@ -424,6 +499,9 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
                             "Gpair_per_s": round(t2.size * nf2 / (t2_ - t1) / 1e9, 1), **fr,
                             "note": "pdc_gls_scan on host buffers: H2D of (t, y, dy) + prologue + scan + "
                                     "D2H of power[1e6], wall clock, median of three calls (both fractions priced on the wall time)"}
+
+    # -- the reference's OWN sizes through the classes (round 6): wall clock of the class call, the CPU path beside it
+    out["host_api_small"] = host_api_small(with_cpu)
 
     # -- C3: 4096 light curves x 2000 samples, shared 5e4-frequency grid ---------------------------
     tt, yy, dd, f = c3_batch()

@@ -38,6 +38,39 @@ def set_threads(n):
         pass
 
 
+_tuned = None
+
+
+def tune_threads(candidates=None):
+    """Pick the OpenMP thread count that gives the double-precision direct sums the highest throughput HERE and set
+    it (returns it).  On the shared GPU boxes of the pool `os.cpu_count()` says 256 while a lease gets a fraction of
+    the machine: 32 threads ran the checker at 10 Gpair/s, 256 at 4 (profiles/r06_oracle_rate.txt).  Timed once per
+    process on a fixed 2e8-pair sample per candidate."""
+    global _tuned
+    if _tuned is not None:
+        return _tuned
+    import time
+    cpus = os.cpu_count() or 1
+    cands = candidates or sorted({max(1, cpus // 8), max(1, cpus // 4), max(1, cpus // 2), cpus})
+    rng = np.random.default_rng(0)
+    n, nf = 20_000, 10_000
+    t = np.sort(rng.uniform(0, n, n))
+    h = rng.uniform(0.5, 1.5, n)
+    f = 0.5 / n / 5 + np.arange(nf) / n / 5
+    best = None
+    for th in cands:
+        set_threads(th)
+        gls_sums_f64(t, h, h, f[:256])                  # (threads up)
+        t0 = time.perf_counter()
+        gls_sums_f64(t, h, h, f)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, th)
+    _tuned = best[1]
+    set_threads(_tuned)
+    return _tuned
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

@@ -273,6 +273,7 @@ __device__ __forceinline__ double gls_power(double Sh, double Ch, double S, doub
 template <int K, int MODE, int SPLIT, bool BAL = false>
 __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(GlsArgs a) {
     constexpr int FT = kBlock / SPLIT;        // frequency-owning threads per workgroup
+    constexpr bool TIGHT = BAL || K >= 16;    // 192 accumulators: nothing loop-invariant may stay in registers across the loops (see the table fill)
     constexpr int COLS = FT / 64;             // 64-lane columns of the tile
     constexpr int kChunk = SPLIT == 1 ? 64 : 128;  // samples per rotation-table chunk
     // per sample: {sin, cos} of theta_tile + 8 q Theta, q < 8 COLS (the seed of lanes 8q .. 8q+7 before
@@ -280,7 +281,9 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     __shared__ double2 tab[kChunk + 1][COLS * 8 + 8 + 1];  // + 1: rows start 16 B apart modulo 128 B (bank spread)
     __shared__ double red_v[4];
     __shared__ long long red_i[4];
-    const int tid = threadIdx.x;
+    __shared__ double2 sc_k[6];   // TIGHT: the sincos coefficients of the table fill (pdc_device.h: sincos_cycles_k)
+    const int tid_ = threadIdx.x;
+    if (TIGHT && tid_ < 6) sc_k[tid_] = sincos_coefficient(tid_);   // (read after the chunk loop's first barrier)
 
     // Workgroup p runs on XCD p % 8 (observed dispatch rule, used for speed only): hand each XCD a
     // contiguous run of logical tiles so the tiles of one curve share that XCD's L2.
@@ -316,20 +319,27 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         // the 4.8 MB of records stream through each XCD's L2 once, as in the unbalanced launch (pieces in run
         // order put every workgroup at another offset: 1.3 GB of L2 misses per launch instead of 0.07)
         curve = 0;
-        tile = (bal_hi - 1) / a.bal_chunks;
-        const int64_t t0 = tile * a.bal_chunks;
+        // (the divisors through an opaque copy per piece: the reciprocal sequences of these uniform divisions are
+        // otherwise computed once on the VALU, kept in VGPRs across the whole piece loop - and spilled, round 5)
+        int64_t b_chunks = a.bal_chunks, b_slots = a.bal_slots, b_units = a.bal_units;
+        asm volatile("" : "+s"(b_chunks), "+s"(b_slots), "+s"(b_units));
+        tile = (bal_hi - 1) / b_chunks;
+        const int64_t t0 = tile * b_chunks;
         bal_c0 = (bal_u > t0 ? bal_u : t0) - t0;
         bal_take = bal_hi - t0 - bal_c0;
-        bal_piece = (int)(L - bal_slot_of(a, t0));   // 0, 1 or 2: which of the tile's pieces
+        int64_t s_of = t0 * b_slots / b_units;              // bal_slot_of(a, t0)
+        while ((s_of + 1) * b_units / b_slots <= t0) ++s_of;
+        while (s_of * b_units / b_slots > t0) --s_of;
+        bal_piece = (int)(L - s_of);   // 0, 1 or 2: which of the tile's pieces
     }
 
     const int64_t off = a.offsets ? a.offsets[curve] : 0;
     const int64_t n = a.offsets ? a.offsets[curve + 1] - off : a.n_total;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), part = wave % SPLIT;
-    const int col = wave / SPLIT, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6), part = wave % SPLIT;
+    const int col = wave / SPLIT;
     // first local frequency of the tile and of this thread
     const int64_t jt = tile * FT * (int64_t)K;
-    const int64_t jl = jt + (col * 64 + lane) * (int64_t)K;
+    const int64_t jl = jt + (col * 64 + (tid_ & 63)) * (int64_t)K;
     // numpy's arange fill rule: start + i*delta, two roundings (no fma)
     const double f_tile = __dadd_rn(a.f0, __dmul_rn((double)(a.j_begin + jt), a.delta));
     const double kdelta = (double)K * a.delta;  // spacing of the threads' first frequencies (exact)
@@ -342,12 +352,18 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     auto rot = [](const double2 x, const double2 y) {
         return make_double2(__builtin_fma(x.x, y.y, x.y * y.x), __builtin_fma(x.y, y.y, -(x.x * y.x)));
     };
-    const int slot_a = col * 8 + (lane >> 3), slot_b = COLS * 8 + (lane & 7);
     const int64_t s_begin = BAL ? bal_c0 * kChunk : (a.partial ? (int64_t)zpart * a.z_len : 0);
     const int64_t s_stop = BAL ? s_begin + bal_take * kChunk : s_begin + a.z_len;
     const int64_t s_end = (BAL || a.partial) ? (s_stop < n ? s_stop : n) : n;
     for (int64_t base = s_begin; base < s_end; base += kChunk) {
         __syncthreads();  // everyone is done with the previous chunk's tables
+        // (TIGHT: the thread id through an opaque copy once per chunk - the LDS addresses and masks built from it are
+        // loop-invariant, and hoisted out of the piece loop they were spilled; rebuilt per chunk they cost a few
+        // 32-bit instructions per 128 samples)
+        int tid = tid_;
+        if (TIGHT) asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int slot_a = col * 8 + (lane >> 3), slot_b = COLS * 8 + (lane & 7);
         // ---- per-sample rotation tables (two threads per sample) ------------------------------------
         // Thread (col, lane) starts at phase theta_tile + (64 col + 8 a + b) Theta with a = lane / 8,
         // b = lane % 8 and Theta = 2 pi K delta t': its seed is tab[8 col + a] rotated by tab[8 COLS + b]
@@ -362,10 +378,21 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
             const double tp = live ? a.rec[(off + base + il) * 6 + 5] : 0.0;
             const double sqw = live ? a.rec[(off + base + il) * 6 + 1] : 0.0;
             double2 step1, cur;
+            double2 kk[6];
+            if (TIGHT) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) kk[q] = sc_k[q];
+            }
+            auto sincos_fill = [&](const double r, double &s_, double &c_) {
+                if (TIGHT) sincos_cycles_k(r, kk, s_, c_);
+                else sincos_cycles(r, s_, c_);
+            };
             if ((tid & 1) == 0) {
                 // lane offsets b Theta, b < 8; and the tile's base phase for the neighbour
-                sincos_cycles(frac_product(kdelta, tp), step1.x, step1.y);
-                tab[il][COLS * 8] = make_double2(0.0, 1.0);
+                sincos_fill(frac_product(kdelta, tp), step1.x, step1.y);
+                double one = 1.0, zero = 0.0;
+                if (TIGHT) asm volatile("" : "+v"(one), "+v"(zero));   // (made here, not kept in four registers across the loops)
+                tab[il][COLS * 8] = make_double2(zero, one);
                 tab[il][COLS * 8 + 1] = step1;
                 cur = step1;
 #pragma unroll
@@ -373,7 +400,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
                     cur = rot(cur, step1);
                     tab[il][COLS * 8 + q] = cur;
                 }
-                sincos_cycles(frac_product(f_tile, tp), cur.x, cur.y);
+                sincos_fill(frac_product(f_tile, tp), cur.x, cur.y);
                 if (MODE == MODE_FIT_MEAN || MODE == MODE_NO_MEAN) {
                     // carry u = sqrt(w) sin, v = sqrt(w) cos: rotations and the recurrence are linear,
                     // and every sum becomes one fma (the record holds sqrt(w) and sqrt(w) y)
@@ -381,7 +408,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
                     cur.y *= sqw;
                 }
             } else {
-                sincos_cycles(frac_product(8.0 * kdelta, tp), step1.x, step1.y);
+                sincos_fill(frac_product(8.0 * kdelta, tp), step1.x, step1.y);
             }
             // the odd thread walks the base in steps of 8 Theta
             double2 b0;
@@ -478,6 +505,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         if (i < i_end) accumulate(A);
     }
 
+    const int tid = tid_;
     if (SPLIT > 1) {
         // fold the partial sums of parts 1..S-1 into part 0, one frequency at a time, through the
         // rotation-table buffer (6 doubles per contributing thread)

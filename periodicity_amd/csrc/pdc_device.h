@@ -40,6 +40,45 @@ __device__ __forceinline__ void sincos_cycles(double r, double &s, double &c) {
     c = __longlong_as_double(__double_as_longlong(c1) ^ cflip);
 }
 
+// The same function with its twelve polynomial coefficients handed in ({sin, cos} coefficient of each Horner step,
+// highest degree first; sincos_coefficient(i) lists them) instead of written as literals.  A VOP3 instruction reads
+// ONE scalar operand, so literal coefficients live in SGPR pairs - and the head of each chain in a VGPR pair - that
+// the compiler hoists out of every loop: in gls_scan_kernel<16, ..., BAL> (192 accumulators, SGPRs full of record
+// fields) those hoisted pairs were the 17 spilled VGPRs of round 5.  Kept in LDS and read where the table fill
+// needs them, they are live for the fill only.  Same constants, same fmas, same bits.
+__device__ __forceinline__ double2 sincos_coefficient(int i) {
+    switch (i) {
+        case 0: return make_double2(1.58969099521155010221e-10, -1.13596475577881948265e-11);
+        case 1: return make_double2(-2.50507602534068634195e-08, 2.08757232129817482790e-09);
+        case 2: return make_double2(2.75573137070700676789e-06, -2.75573143513906633035e-07);
+        case 3: return make_double2(-1.98412698298579493134e-04, 2.48015872894767294178e-05);
+        case 4: return make_double2(8.33333333332248946124e-03, -1.38888888888741095749e-03);
+        default: return make_double2(-1.66666666666666324348e-01, 4.16666666666666019037e-02);
+    }
+}
+__device__ __forceinline__ void sincos_cycles_k(double r, const double2 (&k)[6], double &s, double &c) {
+    const double q = __builtin_rint(4.0 * r);
+    const double z = __builtin_fma(-0.25, q, r);
+    const double x = z * 6.283185307179586476925;
+    const double x2 = x * x;
+    double ps = k[0].x, pc = k[0].y;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) {
+        ps = __builtin_fma(ps, x2, k[i].x);
+        pc = __builtin_fma(pc, x2, k[i].y);
+    }
+    const double sx = __builtin_fma(x * x2, ps, x);
+    const double cx = __builtin_fma(x2 * x2, pc, __builtin_fma(-0.5, x2, 1.0));
+    const int qi = (int)q;
+    const bool swap = qi & 1;
+    const double s1 = swap ? cx : sx;
+    const double c1 = swap ? sx : cx;
+    const unsigned long long sflip = (unsigned long long)(qi & 2) << 62;
+    const unsigned long long cflip = (unsigned long long)((qi + 1) & 2) << 62;
+    s = __longlong_as_double(__double_as_longlong(s1) ^ sflip);
+    c = __longlong_as_double(__double_as_longlong(c1) ^ cflip);
+}
+
 // Hot-loop variant for |r| <= 0.5 cycle (always true after frac_product): evaluate at a quarter of
 // the angle, where |a| <= pi/4 needs no quadrant logic, then double the angle twice
 // (sin 2a = 2 s c, cos 2a = 1 - 2 s^2).  All fp64 VALU, no integer/select instructions; the two

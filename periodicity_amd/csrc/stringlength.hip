@@ -1831,20 +1831,23 @@ __device__ __forceinline__ bool period_and_group(const StreamArgs &a, int &q, in
     return q < a.batch;
 }
 
-// One LDS add per RUN of equal buckets among consecutive lanes (round 6).  Consecutive lanes hold consecutive samples,
-// and time-ordered samples arrive in phase order inside a cycle: at the periods this path exists for (thousands of
-// samples per cycle) a wave's 64 buckets are a handful of runs, and 64 `ds_add_u32` on one or two addresses serialised
-// (r05 PMC: 95 % of the kernel's LDS-active cycles were bank conflicts).  A lane heads a run when the lane below holds
-// another bucket (DPP wave_shr:1, lane 0 always); the run's length is the distance to the next head in the ballot.
-// Any order is still correct - equal buckets that are not neighbours are simply separate adds.  `bucket` = ~0u: none.
-__device__ __forceinline__ void hist_add_runs(unsigned *h, unsigned bucket, int lane) {
+// One LDS add per RUN of equal buckets (round 6).  A thread folds four CONSECUTIVE samples, consecutive lanes the next
+// four: time-ordered samples arrive in phase order inside a cycle, and at the periods this path exists for (thousands
+// of samples per cycle) a thread's four buckets are one value and a wave's 64 values a handful of runs - where 256
+// `ds_add_u32` on one or two addresses serialised (r05 PMC: 95 % of the kernel's LDS-active cycles were bank
+// conflicts).  Thread level: four equal buckets become one weight-4 value.  Wave level: a lane heads a run when the
+// lane below holds another value (DPP wave_shr:1, lane 0 always); the run's length is the distance to the next head
+// in the ballot; one add of 4 x length per run.  A thread whose four buckets differ (a bucket edge, a cycle wrap,
+// short periods, samples in any order) adds its own runs and stands out of the wave's: any order stays correct.
+// `bucket` = ~0u: nothing to add.
+__device__ __forceinline__ void hist_add_runs(unsigned *h, unsigned bucket, unsigned weight, int lane) {
     const unsigned below = PDC_DPP(~bucket, bucket, 0x138, 0xf);
     const bool head = below != bucket;
     const unsigned long long heads = __ballot(head);
     if (head && bucket != ~0u) {
         const unsigned long long rest = (heads >> lane) >> 1;
         const unsigned len = rest ? (unsigned)__builtin_ctzll(rest) + 1u : 64u - (unsigned)lane;
-        atomicAdd(&h[bucket], len);
+        atomicAdd(&h[bucket], len * weight);
     }
 }
 
@@ -1860,18 +1863,38 @@ __global__ __launch_bounds__(kBA) void sl_hist_kernel(StreamArgs a) {
     const bool safe = period_is_safe(period, a.bad_t[0] == 0u);
     for (int c = tid; c < kNC; c += kBA) h[c] = 0u;
     __syncthreads();
+    const int64_t g0 = (int64_t)w * a.tiles_w * kTA;      // the group's first sample (the same run of tiles as before)
     for (int64_t kappa = 0; kappa < a.tiles_w; ++kappa) {
+        const int64_t i0 = g0 + kappa * kTA + (int64_t)tid * 4;   // four consecutive samples per thread
+        if (g0 + kappa * kTA >= a.n) break;                // (workgroup-uniform)
         double tv[4], phi[4];
-        bool live[4];
+        if (i0 + 4 <= a.n) {   // two 16-byte loads (8-byte aligned: t is the caller's pointer)
+            typedef double pair_t __attribute__((ext_vector_type(2), aligned(8)));
+            const pair_t t01 = *reinterpret_cast<const pair_t *>(a.t + i0), t23 = *reinterpret_cast<const pair_t *>(a.t + i0 + 2);
+            tv[0] = t01.x; tv[1] = t01.y; tv[2] = t23.x; tv[3] = t23.y;
+        } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t i = sample_of(kappa, u * kBA + tid, w, a.tiles_w);
-            live[u] = i < a.n;
-            tv[u] = a.t[live[u] ? i : a.n - 1];
+            for (int u = 0; u < 4; ++u) tv[u] = a.t[i0 + u < a.n ? i0 + u : a.n - 1];
         }
         phases4(tv, period, y, safe, phi);
+        unsigned b[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) hist_add_runs(h, live[u] ? (unsigned)coarse_of<kNC>(phi[u]) : ~0u, tid & 63);
+        for (int u = 0; u < 4; ++u) b[u] = i0 + u < a.n ? (unsigned)coarse_of<kNC>(phi[u]) : ~0u;
+        const bool same = b[0] == b[1] && b[1] == b[2] && b[2] == b[3];
+        hist_add_runs(h, same ? b[0] : ~0u, 4u, tid & 63);
+        if (!same) {
+            unsigned cnt = 1u;
+#pragma unroll
+            for (int u = 1; u < 4; ++u) {
+                if (b[u] == b[u - 1]) {
+                    ++cnt;
+                } else {
+                    if (b[u - 1] != ~0u) atomicAdd(&h[b[u - 1]], cnt);
+                    cnt = 1u;
+                }
+            }
+            if (b[3] != ~0u) atomicAdd(&h[b[3]], cnt);
+        }
     }
     __syncthreads();
     unsigned *out = a.hist + ((int64_t)q * a.groups + w) * kNC;
@@ -2151,10 +2174,15 @@ __global__ __launch_bounds__(kBA) void sl_part_kernel(StreamArgs a) {
 // of consecutive samples and the table is written where the key steps up (a step over several keys = empty cells,
 // all starting at the same sample).  Same groups of tiles as the histogram kernel; nothing but t is read (8 bytes a
 // sample, from the caches) and one word per cell written - the partition kernel moves 36 bytes a sample.
+//
+// Round 6: every WAVE walks a contiguous run of the group's samples by itself, 256 at a time (four consecutive samples
+// per lane), the key of the sample before a lane's first from the lane below (DPP wave_shr:1; lane 0: the wave's own
+// last key of the step before, carried in an SGPR) - no LDS exchange and no barrier per tile (round 5: the neighbour's
+// key through LDS, two barriers per tile of 2048 samples, 0.33 ms per 256 periods at N = 1e6), and the next step's
+// time stamps are requested before the current step's keys are worked off.
 __global__ __launch_bounds__(kBA) void sl_bound_kernel(StreamArgs a) {
     __shared__ unsigned short lut[kNC];
-    __shared__ int last[kBA];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int q, w;
     if (!period_and_group(a, q, w)) return;               // (workgroup-uniform)
     const int K = a.ncyc[q];
@@ -2179,31 +2207,39 @@ __global__ __launch_bounds__(kBA) void sl_bound_kernel(StreamArgs a) {
             tb[b * kCycS + c] = (unsigned)i;
         }
     };
-    const int64_t g0 = (int64_t)w * a.tiles_w * kTA;
-    if (g0 >= a.n) return;
+    constexpr int kStep = 256;                             // samples a wave takes per step
+    constexpr int kWavesA = kBA / 64;
+    static_assert(kTA == kWavesA * kStep, "a tile of the group = one step of each of the workgroup's waves");
+    // this wave's run of samples: tiles_w steps from s0 on (the group's tiles_w * kTA samples in kWavesA equal runs)
+    const int64_t s0 = ((int64_t)w * kWavesA + wave) * a.tiles_w * kStep;
     __syncthreads();                                       // (the table read by key_of is complete)
-    int carry = g0 == 0 ? -1 : 0;                          // key of the sample before this thread's first
-    if (g0 > 0) carry = key_of(a.t[g0 - 1]);
-    for (int64_t kappa = 0; kappa < a.tiles_w; ++kappa) {
-        const int64_t i0 = g0 + kappa * kTA + (int64_t)tid * 4;   // four consecutive samples per thread
-        if (g0 + kappa * kTA >= a.n) break;                // (workgroup-uniform)
-        int key[4];
+    if (s0 > a.n) return;                                  // (wave-uniform; s0 == n: this wave closes the table)
+    typedef double pair_t __attribute__((ext_vector_type(2), aligned(8)));
+    auto fetch = [&](int64_t i0, double (&tv)[4]) {
         if (i0 + 4 <= a.n) {   // two 16-byte loads (8-byte aligned: t is the caller's pointer)
-            typedef double pair_t __attribute__((ext_vector_type(2), aligned(8)));
             const pair_t t01 = *reinterpret_cast<const pair_t *>(a.t + i0), t23 = *reinterpret_cast<const pair_t *>(a.t + i0 + 2);
-            key[0] = key_of(t01.x);
-            key[1] = key_of(t01.y);
-            key[2] = key_of(t23.x);
-            key[3] = key_of(t23.y);
+            tv[0] = t01.x; tv[1] = t01.y; tv[2] = t23.x; tv[3] = t23.y;
         } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) key[u] = i0 + u < a.n ? key_of(a.t[i0 + u]) : key_end;
+            for (int u = 0; u < 4; ++u) tv[u] = a.t[i0 + u < a.n ? i0 + u : a.n - 1];
         }
-        last[tid] = key[3];
-        __syncthreads();
-        int prev = tid > 0 ? last[tid - 1] : carry;
-        carry = last[kBA - 1];
-        __syncthreads();
+    };
+    int carry = s0 == 0 ? -1 : __builtin_amdgcn_readfirstlane(key_of(a.t[s0 - 1]));   // key of the sample before the run
+    double tn[4];
+    fetch(s0 + (int64_t)lane * 4, tn);
+    for (int64_t step = 0; step < a.tiles_w; ++step) {
+        const int64_t b0 = s0 + step * kStep;
+        if (b0 > a.n) break;                               // (wave-uniform; a step that starts AT n closes the table)
+        const int64_t i0 = b0 + (int64_t)lane * 4;
+        double tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tv[u] = tn[u];
+        if (step + 1 < a.tiles_w && b0 + kStep <= a.n) fetch(i0 + kStep, tn);   // (wave-uniform) the next step's stamps
+        int key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = i0 + u < a.n ? key_of(tv[u]) : key_end;
+        int prev = (int)PDC_DPP((unsigned)carry, (unsigned)key[3], 0x138, 0xf);   // the lane below's last key; lane 0: the carry
+        carry = __builtin_amdgcn_readlane(key[3], 63);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             // (a sample past the end carries the key behind the last cell: the step up to it closes the table at n)
@@ -2211,11 +2247,9 @@ __global__ __launch_bounds__(kBA) void sl_bound_kernel(StreamArgs a) {
             prev = key[u] > prev ? key[u] : prev;
         }
     }
-    // (n a multiple of the tile: no sample past the end stands in - the last sample's thread closes the table)
-    if ((a.n % kTA) == 0 && g0 + (int64_t)a.tiles_w * kTA >= a.n && g0 < a.n) {
-        const int64_t il = a.n - 1 - g0;                   // the last sample, counted inside this group
-        if ((il % kTA) / 4 == tid) put(key_of(a.t[a.n - 1]), key_end, a.n);
-    }
+    // (n = all the groups' tiles exactly: no step starts at n - the last sample's lane closes the table)
+    if (a.n == (int64_t)a.groups * a.tiles_w * kTA && s0 + (int64_t)a.tiles_w * kStep == a.n && lane == 63)
+        put(carry, key_end, a.n);
 }
 
 // Persistent: a workgroup per CU walks the (period, bin) items.  Built and measured against this kernel (N = 1e6 x

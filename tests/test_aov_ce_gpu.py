@@ -106,6 +106,7 @@ def test_full_size_c5_aov_and_entropy():
     """BASELINE configs[4] shape (N=5e4 x 1e5 trial periods) through the scans the reference only names: EVERY
     period against the C restatement of the published formulas (`oracle/scan_oracle.c`, itself tied to the numpy
     form in tests/test_oracle_golden.py) - round 6, was 25 periods - and the optimum's index identical."""
+    co.tune_threads()        # the host is shared: the thread count the C checker runs fastest with, measured once
     n, n_per = 50_000, 100_000
     t, x = curve(n, 20241012)
     periods = np.linspace(1.0, 100.0, n_per)

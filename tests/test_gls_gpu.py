@@ -433,6 +433,7 @@ def test_entry_points_are_reentrant_across_python_threads():
 def test_full_size_c2_properties():
     """BASELINE configs[1] at full size (1e11 pairs): a random subset of bins against the exact
     oracle, plus invariances the domain offers (amplitude scaling, slab consistency)."""
+    co.tune_threads()        # the host is shared: the thread count the C checker runs fastest with, measured once
     n, nf = 100_000, 1_000_000
     t, y, dy = synth(n, 20241010)
     df = 1.0 / (t[-1] - t[0]) / 5
@@ -483,6 +484,7 @@ def test_full_size_c2_properties():
 def test_full_size_c3_batch_peaks_only():
     """BASELINE configs[2]: 4096 curves x 2k samples on a shared 5e4 grid (4.1e11 pairs), reduced on
     the device to (amax, argmax, highest peak); spot-checked against single-curve calls."""
+    co.tune_threads()        # the host is shared: the thread count the C checker runs fastest with, measured once
     B, n, nf = 4096, 2000, 50_000
     rng = np.random.default_rng(20241011)
     t = np.sort(rng.uniform(0, float(n), (B, n)), axis=1)
@@ -592,6 +594,7 @@ def test_full_size_c4_on_one_gpu_both_paths():
     """BASELINE configs[3] (N=1e6 x nf=1e7 = 1e13 pairs) on ONE GPU: the grid in 8 slabs exactly as
     the 8-GPU run shards it, cross-checked against the FFT path (which reproduces the reference's own
     algorithm) and, on a few bins, against the long-double oracle."""
+    co.tune_threads()        # the host is shared: the thread count the C checker runs fastest with, measured once
     n, nf, world = 1_000_000, 10_000_000, 8
     t, y, dy = synth(n, 20241013)
     df = 1.0 / (t[-1] - t[0]) / 5

@@ -426,6 +426,7 @@ def test_phase_scans_full_size_c5():
     """BASELINE configs[4]: N=5e4 samples x 1e5 trial periods, both scans, EVERY period against the C oracle
     (round 6: the 600-period sample is gone - 5e9 pairs per scan through `oracle/scan_oracle.c`, OpenMP over the
     periods), the argmin index identical, plus invariances of the statistics."""
+    co.tune_threads()        # the host is shared: the thread count the C checker runs fastest with, measured once
     n, n_per = 50_000, 100_000
     t, y = synth(n, 20241012)
     periods = np.linspace(1.0, 100.0, n_per)

@@ -5,6 +5,9 @@ of the C5 period grid.  bench.py starts this as a CHILD process (it never touche
 its workers itself) and scales the result linearly; SURVEY.md 8d (iii).
 
     python tools/cpu_pool_baseline.py [n_periods_sampled] [cores]  ->  one JSON line
+    python tools/cpu_pool_baseline.py defaults N [cores]           ->  the classes' DEFAULT calls at N samples
+        (StringLength(): dphi = 0.1, 1000 periods, phase.py:38,67-68; PDM(): nb = 5, nc = 2, 1000 periods between
+        2 median dt and the baseline, phase.py:108-118,167-180), whole grids, one Pool per call as upstream
 """
 import json
 import multiprocessing as mp
@@ -37,7 +40,30 @@ class StringWorker:
         return so.stringlength_one(self.t, self.m, period)
 
 
+def defaults_main():
+    n = int(sys.argv[2])
+    cores = int(sys.argv[3]) if len(sys.argv) > 3 else (os.cpu_count() or 1)
+    rng = np.random.default_rng(20241008 + 5)                 # bench.synth_curve(n, 5, 13.7)
+    t = np.sort(rng.uniform(0, float(n), n))
+    dy = rng.uniform(0.05, 0.2, n)
+    y = 1.0 + 0.5 * np.sin(2 * np.pi * t / 13.7) + dy * rng.standard_normal(n)
+    m = so.stringlength_scale(y)
+    grids = {"pdm": so.pdm_periods(t)[0], "stringlength": so.stringlength_periods(t[-1] - t[0])}
+    workers = {"pdm": PdmWorker(t, y, 5, 2), "stringlength": StringWorker(t, m)}
+    out = {"cores": cores, "n_samples": n, "start_method": mp.get_start_method()}
+    for name in ("pdm", "stringlength"):
+        t0 = time.perf_counter()
+        with mp.Pool(cores) as pool:
+            values = pool.map(workers[name], grids[name])
+        wall = time.perf_counter() - t0
+        assert len(values) == grids[name].size
+        out[name] = {"wall_s": round(wall, 3), "n_periods": int(grids[name].size)}
+    print(json.dumps(out))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "defaults":
+        return defaults_main()
     sub = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     cores = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
     n, n_full = 50_000, 100_000
