@@ -49,6 +49,12 @@ int pdc_release(void);                                   /* free all cached devi
  * this process so far: a cached path (plans, the one-shot `_multi` entry points, the per-device
  * workspaces) shows no increase on its second call with the same sizes. */
 int pdc_alloc_counts(int64_t *device_allocs, int64_t *pinned_allocs);
+/* TEST HOOKS (not for callers): pin / unpin the scratch block the library keeps per (device, stream) for the `_dev`
+ * entry points that take no workspace.  Rule they let the tests drive: ONE holder at a time per (device, stream) -
+ * a second pdc_test_scratch_pin on the same stream WAITS until the first is unpinned (so never pin twice from one
+ * thread without unpinning: it would wait for itself). */
+int pdc_test_scratch_pin(int device, void *stream, int64_t bytes, void **dptr);
+int pdc_test_scratch_unpin(int device, void *stream);
 
 /* device memory + events for callers that keep data resident (bench.py, tests) */
 int pdc_malloc(int device, int64_t bytes, void **dptr);

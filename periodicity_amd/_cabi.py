@@ -37,6 +37,8 @@ PROTOTYPES = {
     "pdc_stream_destroy": (_I, [_I, _VP]),
     "pdc_stream_sync": (_I, [_I, _VP]),
     "pdc_device_sync": (_I, [_I]),
+    "pdc_test_scratch_pin": (_I, [_I, _VP, _L, C.POINTER(_VP)]),
+    "pdc_test_scratch_unpin": (_I, [_I, _VP]),
     "pdc_event_create": (_I, [_I, C.POINTER(_VP)]),
     "pdc_event_destroy": (_I, [_I, _VP]),
     "pdc_event_record": (_I, [_I, _VP, _VP]),

@@ -202,6 +202,14 @@ int plan_build(GlsPlan *p, const int *devices, int n_devices, int64_t n_max, int
         const ncclResult_t rc = force_rccl_fail() ? ncclSystemError : ncclCommInitAll(p->comms.data(), n_devices, devices);
         if (rc == ncclSuccess) {
             p->exchange = EX_RCCL;
+        } else if (rc == ncclInvalidArgument || rc == ncclInvalidUsage) {
+            // a caller bug (a device listed twice, an ordinal that does not exist): an error, not something to paper
+            // over with the copy exchange
+            for (ncclComm_t &c : p->comms)
+                if (c) (void)ncclCommAbort(c);
+            p->comms.clear();
+            set_error("ncclCommInitAll failed: %s (check the device list)", ncclGetErrorString(rc));
+            return PDC_ERR_RCCL;
         } else {
             // No communicator: the job must not die for it.  The all-gather is the same data movement as the copy
             // exchange (slot i pulls slab j from slot j: hipMemcpyPeerAsync over xGMI once peer access is on), so
@@ -209,17 +217,26 @@ int plan_build(GlsPlan *p, const int *devices, int n_devices, int64_t n_max, int
             p->init_error = std::string("ncclCommInitAll failed: ") + (force_rccl_fail() ? "PDC_FORCE_RCCL_FAIL=1 (injected)" : ncclGetErrorString(rc));
             fprintf(stderr, "periodicity_hip: WARNING: %s - the plan exchanges slabs by device-to-device copies instead of an RCCL all-gather\n",
                     p->init_error.c_str());
-            for (ncclComm_t &c : p->comms) c = nullptr;
+            for (ncclComm_t &c : p->comms) {   // (communicators a failed ncclCommInitAll left half-made)
+                if (c) (void)ncclCommAbort(c);
+                c = nullptr;
+            }
             p->comms.clear();
             for (int i = 0; i < n_devices; ++i)
                 for (int j = 0; j < n_devices; ++j) {
                     if (devices[i] == devices[j]) continue;
+                    // (peer access is an optimisation: without it hipMemcpyPeerAsync stages through the host - a failure
+                    // to query or enable it must not abort the plan after the fallback has been announced)
                     int can = 0;
-                    PDC_HIP(hipDeviceCanAccessPeer(&can, devices[i], devices[j]));
-                    if (!can) continue;                       // (hipMemcpyPeerAsync then stages through the host)
+                    if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) {
+                        (void)hipGetLastError();
+                        continue;
+                    }
                     PDC_TRY(use_device(devices[i]));
                     const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) PDC_HIP(e);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                        fprintf(stderr, "periodicity_hip: WARNING: peer access %d -> %d not enabled (%s): copies between them go through the host\n",
+                                devices[i], devices[j], hipGetErrorString(e));
                     (void)hipGetLastError();
                 }
             p->exchange = n_devices > 1 ? EX_COPY : EX_NONE;
@@ -626,7 +643,27 @@ int phase_scan_enqueue(PhasePlan *p, int kind, const double *periods, int64_t n_
         // this slab's periods need the streamed kernels' bin lists at all - ~12 GB per slot at a million samples)
         const bool sorted_kind = kind == 3 || kind == 5;
         const int hints = sorted_kind ? sorted_scan_hints(kind, static_cast<const double *>(p->pin_in.p), p->n, pp + sb.begin, sb.count) : 0;
-        const int64_t wb = sorted_kind ? sorted_scan_work_bytes(kind, p->n, sb.count, hints) : pdc_phase_work_bytes(kind, p->n, sb.count, nb, nc);
+        // (round 6: this slot's workspace fitted to PDC_WORK_BUDGET_GB and to this slot's share of what its device has
+        // free - eight loopback slots of one GPU used to ask for eight times the built-in caps; the scope stays open
+        // over the launch below, so the scan lays the workspace out with the same scale)
+        int64_t budget = work_budget();
+        if (sorted_kind) {
+            int sharing = 0;
+            for (int j = i; j < nd; ++j)
+                if (p->slot[j].device == s.device && slab_of(n_periods, nd, j).count > 0) ++sharing;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const int64_t avail = (int64_t)(0.9 * ((double)free_b / (double)(sharing > 0 ? sharing : 1) + (double)s.b[B_WORK].cap));
+                if (avail > 0 && (budget == 0 || avail < budget)) budget = avail;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        WorkScale ws(sorted_kind ? budget : 0, [&] {
+            return sorted_kind ? sorted_scan_work_bytes(kind, p->n, sb.count, hints) : pdc_phase_work_bytes(kind, p->n, sb.count, nb, nc);
+        });
+        PDC_REQUIRE_FITS(ws, "phase_plan_scan");
+        const int64_t wb = ws.need;
         PDC_REQUIRE(wb >= 0, "phase_plan_scan: bad size");
         PDC_TRY(ensure(s.b[B_WORK], wb + 8));
         PDC_HIP(hipMemcpyAsync(s.b[B_PER].p, pp + sb.begin, sb.count * 8, hipMemcpyHostToDevice, s.stream));

@@ -39,7 +39,9 @@ int pinned_alloc(void **hptr, int64_t bytes);
 // caller unpins it (stream_scratch_done, or the ScratchPin guard) once all launches that use it are enqueued:
 // from then on the stream itself is busy until they have run.  Entry points that take an
 // explicit workspace (pdc_phase_scan_dev, pdc_gls_scan_dev, pdc_stringlength_scan_dev) never come here.
-int host_stream(int device, hipStream_t *st);   // the device's stream for host entry points (caller holds DeviceLock)
+// RULE: no nested pin on one (device, stream) - a caller that takes stream_scratch() twice before stream_scratch_done()
+// waits for itself.  Every `_dev` entry takes the block once, enqueues, unpins (ScratchPin).
+int host_stream(int device, hipStream_t *st);   // the device's stream for host entry points (caller holds DeviceLock); destroyed by pdc_release()
 int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr);
 void stream_scratch_done(int device, hipStream_t stream);
 int drop_stream_scratch(int device, hipStream_t stream);
@@ -66,6 +68,43 @@ int sorted_scan_hints(int kind, const double *t, int64_t n, const double *period
 int64_t sorted_scan_work_bytes(int kind, int64_t n, int64_t n_periods, int hints);
 int sorted_scan_dev(int kind, int device, void *stream, const double *d_t, const double *d_v, int64_t n, const double *d_periods,
                     int64_t n_periods, double alpha, double *d_out, void *work, int64_t work_bytes, int hints);
+
+// ---- workspace budget (round 6) -------------------------------------------------------------------------------
+// The StringLength / Supersmoother workspaces are sized by built-in caps (12 GB of bin lists, 2 GB of sorted curves,
+// 1 GB pools, 1024 workgroups' scratch ...) chosen for a 288 GB device that the caller owns.  On a shared device, or
+// with eight loopback slots on one GPU, those caps are what made hipMalloc fail.  A budget - PDC_WORK_BUDGET_GB for
+// every entry point, and for the HOST entry points also 0.9 x (free device memory + the cached workspace they would
+// replace) from hipMemGetInfo - scales ALL of those caps by the largest power of two <= 1 for which the workspace
+// fits: smaller batches, fewer resident workgroups, same results.  The scale is a thread-local set for the duration
+// of one entry point (WorkScale; an inner entry keeps the outer one's), and every size function reads it, so
+// `pdc_*_work_bytes` and the launch that follows agree as long as PDC_WORK_BUDGET_GB does not change in between.
+int64_t work_budget();                          // PDC_WORK_BUDGET_GB in bytes (0: none)
+int64_t host_work_budget(int device);           // min(work_budget(), 0.9 x (free + cached SLOT_WORK)) - caller holds the DeviceLock
+double work_scale();                            // 1 outside a WorkScale scope
+double *work_scale_slot(int **depth);           // (the thread-local pair behind WorkScale)
+struct WorkScale {
+    int64_t budget, need;
+    template <typename Total>
+    WorkScale(int64_t budget_, Total total) : budget(budget_), need(0) {
+        int *depth;
+        double *scale = work_scale_slot(&depth);
+        if ((*depth)++ == 0) {
+            *scale = 1.0;
+            if (budget > 0)
+                while (total() > budget && *scale > 1.0 / 65536.0) *scale *= 0.5;
+        }
+        need = total();
+    }
+    ~WorkScale() {
+        int *depth;
+        double *scale = work_scale_slot(&depth);
+        if (--(*depth) == 0) *scale = 1.0;
+    }
+    bool fits() const { return budget <= 0 || need <= budget; }
+};
+#define PDC_REQUIRE_FITS(ws, what)                                                                                      \
+    PDC_REQUIRE((ws).fits(), "%s: even the smallest batch needs %lld bytes of workspace, over the budget of %.3f GB "     \
+                             "(PDC_WORK_BUDGET_GB / free device memory)", what, (long long)(ws).need, (double)(ws).budget / (double)(1 << 30))
 
 // hipSetDevice + range check; every entry point starts here.
 int use_device(int device);

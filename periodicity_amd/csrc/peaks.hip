@@ -383,6 +383,7 @@ __global__ __launch_bounds__(kPkBlock, SORT ? PDC_PK_WAVES : PDC_PK_WAVES + 1) v
     const bool excl = a.k_off > 0;
     double prev_key = inf;
     long long prev_idx = -1;
+    double h_cut = inf;   // (later chunks by prominence) lowest height among the winners already output
     // The m best candidates (by height or by prominence; ties: lower bin first; the same bin only once)
     // into win_*[0 .. m), by m rounds of "best entry strictly after the previous winner"; the list is then
     // cut down to those.  Returns how many there are.
@@ -391,10 +392,21 @@ __global__ __launch_bounds__(kPkBlock, SORT ? PDC_PK_WAVES : PDC_PK_WAVES + 1) v
         double pk = inf;          // previous winner (key, bin): everything is "after" (+inf, -1)
         long long pidx = -1;
         // a later chunk of a call with k > 64: rankings by the call's own key start after the chunk before's last winner
-        const bool ex = excl && by_prom == (a.by_prominence != 0);
+        bool ex = excl && by_prom == (a.by_prominence != 0);
         if (ex) {
             pk = prev_key;
             pidx = prev_idx;
+        } else if (excl && a.by_prominence) {
+            // ... and (round 6) the SEEDS of a later chunk by prominence - the rankings by height that pick the maxima
+            // walked first, whose K-th prominence becomes the threshold tau of the second sweep - are the highest
+            // maxima BELOW the lowest height any earlier chunk has output: none of them is an earlier winner, so all
+            // of them count towards tau.  (Up to round 5 the seeds were the `pre` highest maxima of the row - mostly the
+            // winners already output, dropped again by the exclusion above - so fewer than K were left, tau stayed
+            // -inf and the second sweep collected and walked EVERY maximum of the row: 5.5 ms per 64 ranks on the C3
+            // batch against 0.5 for the first 64.)  Any set of seeds gives a valid tau; this one gives a useful one.
+            ex = true;
+            pk = h_cut;
+            pidx = 0x7fffffff;   // (strictly below h_cut)
         }
         int found = 0;
         if (SORT && m > kPkSortFrom) {
@@ -726,6 +738,25 @@ __global__ __launch_bounds__(kPkBlock, SORT ? PDC_PK_WAVES : PDC_PK_WAVES + 1) v
     if (excl) {
         prev_key = (a.by_prominence ? a.prom : a.height)[ob - 1];
         prev_idx = a.idx[ob - 1];
+        if (a.by_prominence) {   // lowest height among the winners of the chunks before (their bins are in idx[])
+            double lowest = inf;
+            for (int j = tid; j < a.k_off; j += kPkBlock) {
+                const long long b = a.idx[ob - a.k_off + j];
+                if (b >= 0) {
+                    const double hb = x[b];
+                    lowest = hb < lowest ? hb : lowest;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double om = __shfl_xor(lowest, o, 64);
+                lowest = om < lowest ? om : lowest;
+            }
+            if (lane == 0) red_k[wave] = lowest;
+            __syncthreads();
+            for (int w = 0; w < kPkBlock / 64; ++w) lowest = red_k[w] < lowest ? red_k[w] : lowest;
+            __syncthreads();
+            h_cut = lowest;
+        }
         if (prev_idx < 0) {   // (workgroup-uniform) the chunk before already ran out of peaks
             if (tid < a.k) {
                 if (a.idx) a.idx[ob + tid] = -1;

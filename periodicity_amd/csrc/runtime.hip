@@ -1,6 +1,7 @@
 // Runtime side of the C ABI: errors, device selection, cached workspaces, memory/stream/event
 // wrappers.  Nothing here is on the hot path.
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
@@ -96,6 +97,36 @@ int cached(int device, Slot slot, int64_t bytes, void **dptr) {
     return PDC_OK;
 }
 
+int64_t work_budget() {
+    // (read at every call: a test - or a caller - may set it between calls; the size query and the launch of ONE scan
+    // must see the same value)
+    const char *e = getenv("PDC_WORK_BUDGET_GB");
+    if (!e || !e[0]) return 0;
+    const double gb = atof(e);
+    return gb > 0.0 ? (int64_t)(gb * (double)(1 << 30)) : 0;
+}
+
+int64_t host_work_budget(int device) {
+    int64_t b = work_budget();
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const DeviceState *st = g_devices[device];
+        const int64_t avail = (int64_t)((double)((int64_t)free_b + (st ? st->cap[SLOT_WORK] : 0)) * 0.9);
+        if (avail > 0 && (b == 0 || avail < b)) b = avail;
+    } else {
+        (void)hipGetLastError();
+    }
+    return b;
+}
+
+static thread_local double t_work_scale = 1.0;
+static thread_local int t_work_depth = 0;
+double work_scale() { return t_work_scale; }
+double *work_scale_slot(int **depth) {
+    *depth = &t_work_depth;
+    return &t_work_scale;
+}
+
 // The host entry points (numpy in, numpy out) run on ONE non-blocking stream per device, not on the legacy NULL
 // stream: a thread that drives its own streams through the `_dev` entries is no longer serialised against them by
 // the default stream's implicit synchronisation.  The caller holds the device's DeviceLock.
@@ -111,8 +142,7 @@ struct StreamScratch {
     hipStream_t stream;
     void *buf;
     int64_t cap;
-    int pins;   // callers between stream_scratch() and stream_scratch_done(): their launches are not enqueued yet
-    std::vector<void *> retired;   // blocks outgrown while pinned: freed when the last of those callers is done
+    int pins;   // 1 between stream_scratch() and stream_scratch_done() (the holder's launches are not enqueued yet), else 0
 };
 static std::mutex g_scratch_mutex;
 static std::condition_variable g_scratch_cv;   // signalled by stream_scratch_done()
@@ -123,12 +153,11 @@ constexpr size_t kScratchPerDevice = 64;
 static int free_scratch_entry(size_t i) {
     StreamScratch s = g_scratch[i];
     g_scratch.erase(g_scratch.begin() + (long)i);
-    if (s.buf || !s.retired.empty()) {
+    if (s.buf) {
         int now = -1;
         PDC_HIP(hipGetDevice(&now));
         PDC_HIP(hipSetDevice(s.device));
-        if (s.buf) PDC_HIP(hipFree(s.buf));
-        for (void *r : s.retired) PDC_HIP(hipFree(r));
+        PDC_HIP(hipFree(s.buf));
         PDC_HIP(hipSetDevice(now));
     }
     return PDC_OK;
@@ -173,7 +202,7 @@ int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
                 ++i;
             }
         }
-        g_scratch.push_back({device, stream, nullptr, 0, 0, {}});
+        g_scratch.push_back({device, stream, nullptr, 0, 0});
     } else if (at + 1 != g_scratch.size()) {   // a hit moves to the back: true LRU order
         const StreamScratch hit = g_scratch[at];
         g_scratch.erase(g_scratch.begin() + (long)at);
@@ -181,15 +210,9 @@ int stream_scratch(int device, hipStream_t stream, int64_t bytes, void **dptr) {
     }
     StreamScratch *e = &g_scratch.back();
     if (e->cap < bytes) {
-        // Another thread on the same (device, stream) may hold the block pinned with its launches not enqueued yet:
-        // hipFree's device synchronisation cannot protect launches that do not exist yet, so a pinned block is only
-        // RETIRED here and freed by the stream_scratch_done() that brings the pins back to zero.
-        if (e->buf) {
-            if (e->pins > 0)
-                e->retired.push_back(e->buf);
-            else
-                PDC_HIP(hipFree(e->buf));       // (synchronises the device: no kernel still uses it)
-        }
+        // (the entry is unpinned here - the wait above -: nobody is between taking the block and enqueuing on it, and
+        // hipFree synchronises the device, so no kernel still uses it)
+        if (e->buf) PDC_HIP(hipFree(e->buf));
         e->buf = nullptr;
         e->cap = 0;
         const int64_t want = bytes + bytes / 4;
@@ -205,26 +228,7 @@ void stream_scratch_done(int device, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_scratch_mutex);
     g_scratch_cv.notify_all();
     for (StreamScratch &e : g_scratch)
-        if (e.device == device && e.stream == stream && e.pins > 0) {
-            --e.pins;
-            if (e.pins == 0 && !e.retired.empty()) {
-                // every caller that could hold an outgrown block has enqueued its launches: hipFree waits for them
-                int now = -1;
-                if (hipGetDevice(&now) == hipSuccess && hipSetDevice(e.device) == hipSuccess) {
-                    for (void *r : e.retired) (void)hipFree(r);
-                    (void)hipSetDevice(now);
-                }
-                e.retired.clear();
-            }
-        }
-}
-
-// (tests) blocks retired but not yet freed, over all entries
-int64_t stream_scratch_retired() {
-    std::lock_guard<std::mutex> lk(g_scratch_mutex);
-    int64_t c = 0;
-    for (const StreamScratch &e : g_scratch) c += (int64_t)e.retired.size();
-    return c;
+        if (e.device == device && e.stream == stream && e.pins > 0) --e.pins;
 }
 
 int drop_stream_scratch(int device, hipStream_t stream) {
@@ -237,11 +241,9 @@ int drop_stream_scratch(int device, hipStream_t stream) {
 static int release_stream_scratch() {
     std::lock_guard<std::mutex> lk(g_scratch_mutex);
     for (StreamScratch &s : g_scratch) {
-        if (!s.buf && s.retired.empty()) continue;
+        if (!s.buf) continue;
         PDC_HIP(hipSetDevice(s.device));
-        if (s.buf) PDC_HIP(hipFree(s.buf));
-        for (void *r : s.retired) PDC_HIP(hipFree(r));
-        s.retired.clear();
+        PDC_HIP(hipFree(s.buf));
         s.buf = nullptr;
         s.cap = 0;
     }
@@ -357,16 +359,34 @@ int pdc_release(void) {
     for (size_t d = 0; d < g_devices.size(); ++d) {
         DeviceState *st = g_devices[d];
         std::lock_guard<std::mutex> lk2(st->call_mutex);
-        bool any = false;
+        bool any = st->host_stream != nullptr;
         for (int s = 0; s < SLOT_COUNT; ++s) any |= st->buf[s] != nullptr;
         if (!any) continue;
         PDC_HIP(hipSetDevice((int)d));
+        if (st->host_stream) {   // (the host entry points' stream: idle - every host entry ends with a synchronise and holds call_mutex)
+            PDC_HIP(hipStreamDestroy(st->host_stream));
+            st->host_stream = nullptr;
+        }
         for (int s = 0; s < SLOT_COUNT; ++s) {
             if (st->buf[s]) PDC_HIP(hipFree(st->buf[s]));
             st->buf[s] = nullptr;
             st->cap[s] = 0;
         }
     }
+    return PDC_OK;
+}
+
+// Test hooks for the per-(device, stream) scratch table behind the `_dev` entry points that take no workspace
+// (pdc_internal.h: stream_scratch): pin the stream's block / unpin it.  Not for callers - tests/test_multi_gpu.py
+// drives the table's waiting rule with them (they replace the mangled C++ names the test bound to up to round 5).
+int pdc_test_scratch_pin(int device, void *stream, int64_t bytes, void **dptr) {
+    PDC_REQUIRE(dptr && bytes >= 0, "test_scratch_pin: bad argument");
+    PDC_TRY(use_device(device));
+    return stream_scratch(device, (hipStream_t)stream, bytes, dptr);
+}
+int pdc_test_scratch_unpin(int device, void *stream) {
+    PDC_TRY(use_device(device));
+    stream_scratch_done(device, (hipStream_t)stream);
     return PDC_OK;
 }
 

@@ -2174,15 +2174,15 @@ __global__ __launch_bounds__(kBA) void sl_part_kernel(StreamArgs a) {
 // of consecutive samples and the table is written where the key steps up (a step over several keys = empty cells,
 // all starting at the same sample).  Same groups of tiles as the histogram kernel; nothing but t is read (8 bytes a
 // sample, from the caches) and one word per cell written - the partition kernel moves 36 bytes a sample.
-//
-// Round 6: every WAVE walks a contiguous run of the group's samples by itself, 256 at a time (four consecutive samples
-// per lane), the key of the sample before a lane's first from the lane below (DPP wave_shr:1; lane 0: the wave's own
-// last key of the step before, carried in an SGPR) - no LDS exchange and no barrier per tile (round 5: the neighbour's
-// key through LDS, two barriers per tile of 2048 samples, 0.33 ms per 256 periods at N = 1e6), and the next step's
-// time stamps are requested before the current step's keys are worked off.
+// (Round 6 experiment, measured and withdrawn - profiles/r06_sl_bound_wave_runs_experiment.patch: every WAVE walking its
+// own contiguous run of the group's samples, the neighbour's key by DPP and the carry in an SGPR, no LDS exchange and
+// no barrier per tile, the next step's stamps requested ahead: 364 against 331 us per 256 periods at N = 1e6.  The
+// kernel is bound by its ~75 VALU instructions per sample - the exact quotient, floor, the 64-bit index arithmetic -,
+// not by the two barriers per tile.)
 __global__ __launch_bounds__(kBA) void sl_bound_kernel(StreamArgs a) {
     __shared__ unsigned short lut[kNC];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int last[kBA];
+    const int tid = threadIdx.x;
     int q, w;
     if (!period_and_group(a, q, w)) return;               // (workgroup-uniform)
     const int K = a.ncyc[q];
@@ -2207,39 +2207,31 @@ __global__ __launch_bounds__(kBA) void sl_bound_kernel(StreamArgs a) {
             tb[b * kCycS + c] = (unsigned)i;
         }
     };
-    constexpr int kStep = 256;                             // samples a wave takes per step
-    constexpr int kWavesA = kBA / 64;
-    static_assert(kTA == kWavesA * kStep, "a tile of the group = one step of each of the workgroup's waves");
-    // this wave's run of samples: tiles_w steps from s0 on (the group's tiles_w * kTA samples in kWavesA equal runs)
-    const int64_t s0 = ((int64_t)w * kWavesA + wave) * a.tiles_w * kStep;
+    const int64_t g0 = (int64_t)w * a.tiles_w * kTA;
+    if (g0 >= a.n) return;
     __syncthreads();                                       // (the table read by key_of is complete)
-    if (s0 > a.n) return;                                  // (wave-uniform; s0 == n: this wave closes the table)
-    typedef double pair_t __attribute__((ext_vector_type(2), aligned(8)));
-    auto fetch = [&](int64_t i0, double (&tv)[4]) {
+    int carry = g0 == 0 ? -1 : 0;                          // key of the sample before this thread's first
+    if (g0 > 0) carry = key_of(a.t[g0 - 1]);
+    for (int64_t kappa = 0; kappa < a.tiles_w; ++kappa) {
+        const int64_t i0 = g0 + kappa * kTA + (int64_t)tid * 4;   // four consecutive samples per thread
+        if (g0 + kappa * kTA >= a.n) break;                // (workgroup-uniform)
+        int key[4];
         if (i0 + 4 <= a.n) {   // two 16-byte loads (8-byte aligned: t is the caller's pointer)
+            typedef double pair_t __attribute__((ext_vector_type(2), aligned(8)));
             const pair_t t01 = *reinterpret_cast<const pair_t *>(a.t + i0), t23 = *reinterpret_cast<const pair_t *>(a.t + i0 + 2);
-            tv[0] = t01.x; tv[1] = t01.y; tv[2] = t23.x; tv[3] = t23.y;
+            key[0] = key_of(t01.x);
+            key[1] = key_of(t01.y);
+            key[2] = key_of(t23.x);
+            key[3] = key_of(t23.y);
         } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) tv[u] = a.t[i0 + u < a.n ? i0 + u : a.n - 1];
+            for (int u = 0; u < 4; ++u) key[u] = i0 + u < a.n ? key_of(a.t[i0 + u]) : key_end;
         }
-    };
-    int carry = s0 == 0 ? -1 : __builtin_amdgcn_readfirstlane(key_of(a.t[s0 - 1]));   // key of the sample before the run
-    double tn[4];
-    fetch(s0 + (int64_t)lane * 4, tn);
-    for (int64_t step = 0; step < a.tiles_w; ++step) {
-        const int64_t b0 = s0 + step * kStep;
-        if (b0 > a.n) break;                               // (wave-uniform; a step that starts AT n closes the table)
-        const int64_t i0 = b0 + (int64_t)lane * 4;
-        double tv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) tv[u] = tn[u];
-        if (step + 1 < a.tiles_w && b0 + kStep <= a.n) fetch(i0 + kStep, tn);   // (wave-uniform) the next step's stamps
-        int key[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) key[u] = i0 + u < a.n ? key_of(tv[u]) : key_end;
-        int prev = (int)PDC_DPP((unsigned)carry, (unsigned)key[3], 0x138, 0xf);   // the lane below's last key; lane 0: the carry
-        carry = __builtin_amdgcn_readlane(key[3], 63);
+        last[tid] = key[3];
+        __syncthreads();
+        int prev = tid > 0 ? last[tid - 1] : carry;
+        carry = last[kBA - 1];
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             // (a sample past the end carries the key behind the last cell: the step up to it closes the table at n)
@@ -2247,9 +2239,11 @@ __global__ __launch_bounds__(kBA) void sl_bound_kernel(StreamArgs a) {
             prev = key[u] > prev ? key[u] : prev;
         }
     }
-    // (n = all the groups' tiles exactly: no step starts at n - the last sample's lane closes the table)
-    if (a.n == (int64_t)a.groups * a.tiles_w * kTA && s0 + (int64_t)a.tiles_w * kStep == a.n && lane == 63)
-        put(carry, key_end, a.n);
+    // (n a multiple of the tile: no sample past the end stands in - the last sample's thread closes the table)
+    if ((a.n % kTA) == 0 && g0 + (int64_t)a.tiles_w * kTA >= a.n && g0 < a.n) {
+        const int64_t il = a.n - 1 - g0;                   // the last sample, counted inside this group
+        if ((il % kTA) / 4 == tid) put(key_of(a.t[a.n - 1]), key_end, a.n);
+    }
 }
 
 // Persistent: a workgroup per CU walks the (period, bin) items.  Built and measured against this kernel (N = 1e6 x
@@ -2726,7 +2720,13 @@ int64_t pad_pow2(int64_t n) {
     return p;
 }
 
-int64_t grid_for(int64_t n_periods) { return n_periods < kMaxGrid ? n_periods : kMaxGrid; }
+// (resident workgroups of the one-workgroup-per-period kernels - each owns 12 bytes a padded sample of scratch, 17 GB for
+// 1024 of them at N = 1e6 -, fewer under a workspace budget: pdc_internal.h, WorkScale)
+int64_t grid_for(int64_t n_periods) {
+    int64_t cap = (int64_t)((double)kMaxGrid * work_scale());
+    cap = cap < 1 ? 1 : cap;
+    return n_periods < cap ? n_periods : cap;
+}
 
 // ranges: one per window of every slice, plus one per slice / oversized bucket
 int64_t range_slots(int64_t n) { return (n / kWin + n / 8192 + 64 + 3) & ~(int64_t)3; }   // (multiple of 4: keeps every array 16-byte aligned)
@@ -2862,9 +2862,11 @@ StreamShape stream_shape(int64_t n, int64_t n_periods, bool lists = true) {
     h.tiles_w = (int)((tiles + groups - 1) / groups);
     static const int64_t env_batch = [] { const char *e = getenv("PDC_SL_STREAM_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
     const int64_t list_bytes = (int64_t)h.s1 * stream::kCap * 20;                 // one period's lists
-    int64_t batch = ((int64_t)12 << 30) / list_bytes / 32 * 32;
-    batch = batch > 384 ? 384 : (batch < 32 ? 32 : batch);
-    if (!lists) batch = 384;
+    const double scale = work_scale();                                            // (< 1 under a workspace budget)
+    int64_t batch = (int64_t)((double)((int64_t)12 << 30) * scale) / list_bytes / 32 * 32;
+    batch = batch > 384 ? 384 : (batch < 32 ? (scale < 1.0 ? (int64_t)((double)((int64_t)12 << 30) * scale) / list_bytes : 32) : batch);
+    if (!lists) batch = (int64_t)(384.0 * scale);
+    batch = batch < 1 ? 1 : batch;
     if (env_batch > 0) batch = env_batch;
     batch = batch > n_periods ? n_periods : batch;
     batch = batch < 1 ? 1 : (batch > stream::kBatchMax ? stream::kBatchMax : batch);   // (the sort kernel keeps a prefix over the batch's periods in LDS)
@@ -3169,23 +3171,24 @@ SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     z.streamed = !z.fastsort && n >= 4096 && n <= kStreamMaxN;
     z.tiled = n >= ss2::kMinN && n <= ss2::kMaxN;
     // the sorted batch - 16 bytes a point and period - stays within 2 GB (batches of >= 8 periods)
-    int64_t cap = ((int64_t)2 << 30) / (16 * (n > 0 ? n : 1));
+    const double scale = work_scale();                                     // (< 1 under a workspace budget)
+    int64_t cap = (int64_t)((double)((int64_t)2 << 30) * scale) / (16 * (n > 0 ? n : 1));
     cap = cap < 8 ? 8 : cap;
     // (the bin lists of the streamed sort take ~49 bytes per point and period: ~350 MB of them - 136 periods at
     // n = 5e4 -, but at least one full sub-batch of the smoother, and the streamed kernels' own 384 from n = 18 000 down)
     static const int64_t env_cap = [] { const char *e = getenv("PDC_SS_BATCH"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
-    int64_t sub = ((int64_t)3 << 29) / (72 * (n > 0 ? n : 1)) / 8 * 8;     // the smoother's sub-batch (below)
+    int64_t sub = (int64_t)((double)((int64_t)3 << 29) * scale) / (72 * (n > 0 ? n : 1)) / 8 * 8;     // the smoother's sub-batch (below)
     static const int64_t env_submax = [] { const char *e = getenv("PDC_SS_SUBMAX"); return e ? (int64_t)atoll(e) : (int64_t)0; }();
     const int64_t sub_max = env_submax >= 8 ? env_submax : (n >= 40000 ? ss2::kSubBatch : (n >= 10000 ? 128 : 384));
     sub = sub < 8 ? 8 : (sub > sub_max ? sub_max : sub);
-    int64_t list_cap = 7000000 / (n > 0 ? n : 1);
+    int64_t list_cap = (int64_t)(7000000.0 * scale) / (n > 0 ? n : 1);
     list_cap = list_cap < sub ? sub : (list_cap > 384 ? 384 : list_cap / sub * sub);
     if (z.fastsort) {
         // (no lists: one workgroup per period - 256 periods a launch fill the CUs - within ~600 MB of sorted curves
         // + the kernels' per-workgroup scratch, and at least one sub-batch of the smoother)
         const int64_t partition = may_need_partition(n) ? pad_pow2(n) * 4 + kBucketsLarge * 4 : 0;
         const int64_t per = 16 * n + pad_pow2(n) * 12 + range_slots(n) * 44 + partition;
-        int64_t b = ((int64_t)600 << 20) / per;
+        int64_t b = (int64_t)((double)((int64_t)600 << 20) * scale) / per;
         b = b > 256 ? 256 : b;
         list_cap = b / sub * sub > 0 ? b / sub * sub : sub;
     }
@@ -3209,14 +3212,14 @@ SsShape ss_shape(int64_t n, int64_t n_periods, bool lists = true) {
     z.stride = (n + n / 2 + 24 + 7) & ~(int64_t)7;   // (prefix arrays run over the curve extended by a quarter on either side)
     // The generic smoother (ss_smooth_kernel: fifteen arrays of 1.5 n doubles per workgroup) is the whole path below
     // ss2::kMinN samples and, above, takes only the periods the tiled kernels hand back: 1 GB of arrays for it.
-    int64_t g = ((int64_t)1 << 30) / (ss::kArrays * z.stride * 8);
+    int64_t g = (int64_t)((double)((int64_t)1 << 30) * scale) / (ss::kArrays * z.stride * 8);
     g = g < 1 ? 1 : (g > (z.tiled ? 16 : 512) ? (z.tiled ? 16 : 512) : g);
     z.grid_ss = (int)(g < z.batch ? g : z.batch);
     z.grid_fb = z.batch < (z.streamed ? 64 : 256) ? z.batch : (z.streamed ? 64 : 256);
     if (z.fastsort) z.grid_fb = 1;   // (the whole-period bitonic fallback is not used)
     // Periods whose phases cluster are sorted by one workgroup each in global scratch (12 bytes a padded point): the
     // pool of such workgroups stays within 1 GB
-    const int64_t fb_cap = ((int64_t)1 << 30) / (pad_pow2(n) * 12);
+    const int64_t fb_cap = (int64_t)((double)((int64_t)1 << 30) * scale) / (pad_pow2(n) * 12);
     z.grid_fb = (int)(z.grid_fb < fb_cap ? z.grid_fb : (fb_cap < 1 ? 1 : fb_cap));
     z.n_pad = pad_pow2(n);
     // tiled smoother: sub-batches of <= 64 periods from n = 4e4 on (short curves take more per launch - a period of
@@ -3312,7 +3315,10 @@ int stringlength_scan_impl(int device, void *stream, const double *d_t, const do
 
 extern "C" {
 
-int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) { return stringlength_work_bytes(n, n_periods, true); }
+int64_t pdc_stringlength_work_bytes(int64_t n, int64_t n_periods) {
+    WorkScale ws(work_budget(), [&] { return stringlength_work_bytes(n, n_periods, true); });   // (PDC_WORK_BUDGET_GB)
+    return ws.need;
+}
 
 int pdc_stringlength_scan_dev(int device, void *stream, const double *d_t, const double *d_m,
                               int64_t n, const double *d_periods, int64_t n_periods, double *d_ell,
@@ -3332,8 +3338,10 @@ int stringlength_scan_impl(int device, void *stream, const double *d_t, const do
     PDC_REQUIRE(n >= 0 && n_periods >= 0, "stringlength: negative size");
     PDC_REQUIRE(n < ((int64_t)1 << 31), "stringlength: at most 2^31-1 samples");
     PDC_REQUIRE(n_periods < ((int64_t)1 << 32), "stringlength: at most 2^32-1 trial periods per call");
-    PDC_REQUIRE(work && work_bytes >= stringlength_work_bytes(n, n_periods, lists),
-                "stringlength: workspace too small");
+    WorkScale ws(work_budget(), [&] { return stringlength_work_bytes(n, n_periods, lists); });   // (a host entry's scope, if any, stays)
+    PDC_REQUIRE_FITS(ws, "stringlength");
+    PDC_REQUIRE(work && work_bytes >= ws.need, "stringlength: workspace too small (%lld < %lld bytes)", (long long)work_bytes,
+                (long long)ws.need);
     if (n_periods == 0) return PDC_OK;
     PDC_TRY(use_device(device));
     const int64_t grid = grid_for(n_periods);
@@ -3553,7 +3561,10 @@ int pdc_stringlength_scan(const double *t, const double *m, int64_t n, const dou
     DeviceLock lock(device);
     // (time-ordered samples and periods that all take the slices / one-cycle modes: no lists in the workspace)
     const int hints = host_hints(t, n, periods, n_periods, stream_min_n());
-    const int64_t wb = stringlength_work_bytes(n, n_periods, (hints & kHintLists) != 0);
+    // (the workspace fitted to PDC_WORK_BUDGET_GB and to what the device has free right now)
+    WorkScale ws(host_work_budget(device), [&] { return stringlength_work_bytes(n, n_periods, (hints & kHintLists) != 0); });
+    PDC_REQUIRE_FITS(ws, "stringlength");
+    const int64_t wb = ws.need;
     void *d_t, *d_m, *d_p, *d_e, *d_w;
     PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
     PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_m));
@@ -3575,7 +3586,8 @@ int pdc_stringlength_scan(const double *t, const double *m, int64_t n, const dou
 // ---- Supersmoother period search (spectral.py:8, a TODO upstream; Friedman 1984 + Reimann 1994) -----------------
 int64_t pdc_supersmoother_work_bytes(int64_t n, int64_t n_periods) {
     if (n < 0 || n_periods < 0) return -1;
-    return ss_shape(n, n_periods).total;
+    WorkScale ws(work_budget(), [&] { return ss_shape(n, n_periods).total; });   // (PDC_WORK_BUDGET_GB)
+    return ws.need;
 }
 
 }  // extern "C"
@@ -3606,6 +3618,8 @@ int supersmoother_scan_impl(int device, void *stream, const double *d_t, const d
                                                   "half the curve)");
     PDC_REQUIRE(n_periods >= 0, "supersmoother: negative size");
     PDC_REQUIRE(alpha >= 0.0 && alpha <= 10.0, "supersmoother: the bass control alpha lies in [0, 10] (0 = off)");
+    WorkScale ws(work_budget(), [&] { return ss_shape(n, n_periods, lists).total; });   // (a host entry's scope, if any, stays)
+    PDC_REQUIRE_FITS(ws, "supersmoother");
     const SsShape z = ss_shape(n, n_periods, lists);
     PDC_REQUIRE(work && work_bytes >= z.total, "supersmoother: workspace too small (%lld < %lld bytes)",
                 (long long)work_bytes, (long long)z.total);
@@ -3729,7 +3743,10 @@ int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const do
     DeviceLock lock(device);
     // (time-ordered samples and periods that all take the slices mode: no lists in the workspace, as pdc_stringlength_scan)
     const int hints = host_hints(t, n, periods, n_periods, 4096);
-    const int64_t wb = ss_shape(n, n_periods, (hints & kHintLists) != 0).total;
+    // (the workspace fitted to PDC_WORK_BUDGET_GB and to what the device has free right now)
+    WorkScale ws(host_work_budget(device), [&] { return ss_shape(n, n_periods, (hints & kHintLists) != 0).total; });
+    PDC_REQUIRE_FITS(ws, "supersmoother");
+    const int64_t wb = ws.need;
     void *d_t, *d_y, *d_p, *d_s, *d_w;
     PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
     PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_y));
@@ -3761,7 +3778,8 @@ int sorted_scan_hints(int kind, const double *t, int64_t n, const double *period
 int64_t sorted_scan_work_bytes(int kind, int64_t n, int64_t n_periods, int hints) {
     const bool lists = (hints & kHintLists) != 0;
     if (n < 0 || n_periods < 0) return -1;
-    return kind == 5 ? ss_shape(n, n_periods, lists).total : stringlength_work_bytes(n, n_periods, lists);
+    WorkScale ws(work_budget(), [&] { return kind == 5 ? ss_shape(n, n_periods, lists).total : stringlength_work_bytes(n, n_periods, lists); });
+    return ws.need;   // (may still exceed the budget: the scan itself then says so - PDC_REQUIRE_FITS)
 }
 int sorted_scan_dev(int kind, int device, void *stream, const double *d_t, const double *d_v, int64_t n, const double *d_periods,
                     int64_t n_periods, double alpha, double *d_out, void *work, int64_t work_bytes, int hints) {
