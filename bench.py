@@ -500,6 +500,28 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
                             "note": "pdc_gls_scan on host buffers: H2D of (t, y, dy) + prologue + scan + "
                                     "D2H of power[1e6], wall clock, median of three calls (both fractions priced on the wall time)"}
 
+    # -- BGLST at C2's shape (round 6): gls_scan_kernel<8, MODE_TREND, 1> - eight running sums per pair + the marginal
+    # log-likelihood as epilogue -, inputs resident
+    try:
+        from periodicity_amd.spectral import BGLST
+        sc = BGLST._scalars(t2, y2, dy2, 1.0, 1.0, 2.0, 0.5 * (t2[0] + t2[-1]))
+        bb = [DB.from_array(a_, dev) for a_ in (t2, y2, dy2)]
+        wbb = lib.pdc_gls_work_bytes(t2.size, 1, nf2)
+        bw, bo = DB(wbb, dev), DB(nf2 * 8, dev)
+        ms = tm.ms(lambda: cabi.check(lib.pdc_bglst_scan_dev(dev, stream, bb[0].ptr, bb[1].ptr, bb[2].ptr, t2.size, f0, delta, 0, nf2,
+                                                             sc.ctypes.data_as(C.c_void_p), bo.ptr, bw.ptr, wbb)), reps=3)
+        ll = bo.to_array(np.float64, nf2)
+        fr, _ = two_fracs(("gls_scan_kernel<8, 3, 1",), ms, float(t2.size) * nf2 * 54.0 / (ms * 1e-3) / 1e12 / PEAK_FP64_VECTOR_TFLOPS,
+                          "54 flop/pair (SURVEY 8d's 50 + two more fmas) vs 78.6 TFLOP/s")
+        out["c2_bglst"] = {"ms": round(ms, 3), "Gpair_per_s": round(t2.size * nf2 / ms / 1e6, 1), "peak_bin": int(np.nanargmax(ll)), **fr,
+                           "note": "pdc_bglst_scan_dev on the C2 inputs: Bayesian GLS with linear trend (the reference exports the name "
+                                   "for an empty class, spectral.py:207-208); parity unpinned by the reference, oracle = the published "
+                                   "marginal likelihood"}
+        for b_ in bb + [bw, bo]:
+            b_.free()
+    except Exception as exc:                                  # informational: never cost the headline line
+        out["c2_bglst"] = {"error": f"{type(exc).__name__}: {exc}"}
+
     # -- the reference's OWN sizes through the classes (round 6): wall clock of the class call, the CPU path beside it
     out["host_api_small"] = host_api_small(with_cpu)
 

@@ -184,6 +184,25 @@ int pdc_trig_sums(const double *t, const double *w, int64_t n,
                   double f0, double delta, int64_t nf,
                   double *S_out, double *C_out, int device);
 
+/* ---- BGLST: Bayesian generalised Lomb-Scargle with linear trend -----------------------------------------------
+ * The reference exports the name (spectral.py:7 `__all__ = ["GLS", "BGLST"]`) for an empty class (:207-208, README:
+ * "Bayesian Lomb-Scargle with linear Trend (soon)"); there is nothing upstream to replace or to pin against -
+ * PARITY UNPINNED BY THE REFERENCE.  What is computed is the published statistic (Olspert, Pelt, Kapyla & Lehtinen
+ * 2018, A&A 615, A111): per trial frequency f_j = f0 + (j_begin + j) delta the log marginal likelihood of
+ *     y_i = A cos(2 pi f t_i) + B sin(2 pi f t_i) + alpha tau_i + beta + eps_i,   eps_i ~ N(0, dy_i^2),
+ * with independent zero-mean Gaussian priors on A, B (one sigma_A), alpha, beta integrated out analytically;
+ * tau = (t - t_ref) / span.  Same kernel skeleton as pdc_gls_scan (eight running sums per pair instead of six).
+ * scalars[12] = {W = sum dy^-2, then over the normalised weights w = dy^-2 / W: sum w y^2, sum w y, sum w tau y,
+ * sum w tau^2, sum w tau; (t[0] - t_ref) / span; 1 / span; 1 / sigma_A^2, 1 / sigma_alpha^2 (alpha per span),
+ * 1 / sigma_beta^2; sum log(2 pi dy_i^2) + log(sigma_A^4 sigma_alpha^2 sigma_beta^2)} - O(N) host work in fp64
+ * (periodicity_amd/spectral.py:BGLST).  dy == NULL: unit uncertainties.  Workspace: pdc_gls_work_bytes(n, 1, nf). */
+int pdc_bglst_scan(const double *t, const double *y, const double *dy, int64_t n,
+                   double f0, double delta, int64_t j_begin, int64_t nf, const double *scalars,
+                   double *loglik_out, int device);
+int pdc_bglst_scan_dev(int device, void *stream, const double *d_t, const double *d_y, const double *d_dy, int64_t n,
+                       double f0, double delta, int64_t j_begin, int64_t nf, const double *scalars,
+                       double *d_loglik, void *work, int64_t work_bytes);
+
 /* Device-resident form used by bench.py: inputs already in HBM, no synchronisation.
  * `work` is scratch of at least pdc_gls_work_bytes(n_total, n_curves, nf) bytes on the same
  * device (non-decreasing in n_total and in nf: a buffer sized for the largest call serves all; for a

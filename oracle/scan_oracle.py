@@ -575,3 +575,53 @@ def supersmoother_stat(t, y, period, alpha=0.0):
 
 def supersmoother_scan(t, y, periods, alpha=0.0):
     return np.array([supersmoother_stat(t, y, p, alpha) for p in np.asarray(periods, dtype=float)])
+
+
+# ---- BGLST (spectral.py:7,207-208: the name is exported, the class body is `pass`) -------------------------------------
+# PARITY UNPINNED BY THE REFERENCE.  Restates the published statistic - Olspert, Pelt, Kapyla & Lehtinen 2018, A&A 615,
+# A111, "Bayesian generalised Lomb-Scargle periodogram with trend": data y_i = A cos(2 pi f t_i) + B sin(2 pi f t_i) +
+# alpha tau_i + beta + eps_i, eps_i ~ N(0, err_i^2), independent zero-mean Gaussian priors on the four linear
+# parameters, which are integrated out - by the two textbook routes that must agree: the dense one (y ~ N(0, Phi Sigma
+# Phi^T + N), scipy's multivariate normal: the third-party pin, small n only) and the 4 x 4 one (Woodbury + the matrix
+# determinant lemma) in 80-bit arithmetic for whole grids.  tau = (t - t_ref) / (t[-1] - t[0]).
+def bglst_design(t, frequency, t_ref):
+    t = np.asarray(t, dtype=np.longdouble)
+    span = t[-1] - t[0] if t[-1] != t[0] else np.longdouble(1)
+    arg = TWO_PI_L * np.longdouble(frequency) * t
+    return np.stack([np.cos(arg), np.sin(arg), (t - np.longdouble(t_ref)) / span, np.ones_like(t)], axis=1)
+
+
+def bglst_loglik_dense(t, y, err, frequency, sigma_A, sigma_alpha, sigma_beta, t_ref):
+    """log N(y; 0, Phi Sigma Phi^T + diag err^2) for ONE frequency, by scipy (O(n^3): the pin, not the oracle)."""
+    from scipy.stats import multivariate_normal
+    phi = bglst_design(t, frequency, t_ref).astype(float)
+    cov = phi @ np.diag([sigma_A ** 2, sigma_A ** 2, sigma_alpha ** 2, sigma_beta ** 2]) @ phi.T + np.diag(np.asarray(err, float) ** 2)
+    return float(multivariate_normal(mean=np.zeros(len(y)), cov=cov, allow_singular=False).logpdf(np.asarray(y, float)))
+
+
+def bglst_loglik(t, y, err, frequency, sigma_A, sigma_alpha, sigma_beta, t_ref):
+    """log p(y | f) for every frequency of ``frequency``: -1/2 [y^T N^-1 y - b^T M^-1 b + log|M| + log|Sigma| +
+    sum log(2 pi err^2)], M = Phi^T N^-1 Phi + Sigma^-1, b = Phi^T N^-1 y, in long double with an explicit 4 x 4
+    Cholesky (numpy's linalg has no 80-bit routines)."""
+    L = np.longdouble
+    y = np.asarray(y, dtype=L)
+    err = np.ones_like(y) if err is None else np.asarray(err, dtype=L)
+    w = err ** -2
+    prec = np.array([L(sigma_A) ** -2, L(sigma_A) ** -2, L(sigma_alpha) ** -2, L(sigma_beta) ** -2])
+    const = np.sum(np.log(TWO_PI_L * err ** 2)) + 4 * np.log(L(sigma_A)) + 2 * np.log(L(sigma_alpha)) + 2 * np.log(L(sigma_beta))
+    yy = np.dot(w, y * y)
+    out = np.empty(len(frequency))
+    for j, f in enumerate(np.asarray(frequency, dtype=float)):
+        phi = bglst_design(t, f, t_ref)
+        m = phi.T @ (phi * w[:, None]) + np.diag(prec)
+        b = phi.T @ (w * y)
+        c = np.zeros((4, 4), dtype=L)                     # Cholesky, lower
+        for i in range(4):
+            for k in range(i + 1):
+                s = m[i, k] - np.dot(c[i, :k], c[k, :k])
+                c[i, k] = np.sqrt(s) if i == k else s / c[k, k]
+        z = np.zeros(4, dtype=L)
+        for i in range(4):
+            z[i] = (b[i] - np.dot(c[i, :i], z[:i])) / c[i, i]
+        out[j] = float(-0.5 * (yy - np.dot(z, z) + 2 * np.sum(np.log(np.diag(c))) + const))
+    return out

@@ -44,6 +44,8 @@ PROTOTYPES = {
     "pdc_event_record": (_I, [_I, _VP, _VP]),
     "pdc_event_elapsed_ms": (_I, [_I, _VP, _VP, C.POINTER(C.c_float)]),
     "pdc_clock_probe": (_I, [_I, _VP, _I, C.POINTER(C.c_float), C.POINTER(_D), C.POINTER(_D)]),
+    "pdc_bglst_scan": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _L, _VP, _VP, _I]),
+    "pdc_bglst_scan_dev": (_I, [_I, _VP, _VP, _VP, _VP, _L, _D, _D, _L, _L, _VP, _VP, _VP, _L]),
     "pdc_gls_scan": (_I, [_VP, _VP, _VP, _L, _D, _D, _L, _L, _I, _I, _VP, _I]),
     "pdc_gls_scan_batch": (_I, [_VP, _VP, _VP, _VP, _L, _I, _D, _D, _L, _L, _I, _I,
                                 _VP, _VP, _VP, _I]),
@@ -217,6 +219,22 @@ def gls_scan(t, y, dy, f0, delta, nf, fit_mean=True, psd=False, j_begin=0, devic
     dev = default_device() if device is None else device
     check(lib().pdc_gls_scan(_ptr(t), _ptr(y), _ptr(dy), t.size, f0, delta, j_begin, nf,
                              int(bool(fit_mean)), int(bool(psd)), _ptr(out), dev))
+    return out
+
+
+def bglst_scan(t, y, dy, f0, delta, nf, scalars, j_begin=0, device=None):
+    """Log marginal likelihood per trial frequency of the harmonic + linear-trend model (``pdc_bglst_scan``);
+    ``scalars``: the twelve frequency-independent inputs listed in include/periodicity_hip.h."""
+    t, y = _f64(t, "t"), _f64(y, "y")
+    dy = None if dy is None else _f64(dy, "dy")
+    if y.size != t.size or (dy is not None and dy.size != t.size):
+        raise ValueError("Input arrays have incompatible lengths.")
+    scalars = _f64(scalars, "scalars")
+    if scalars.size != 12:
+        raise ValueError("bglst_scan takes twelve scalars")
+    out = np.empty(nf, dtype=np.float64)
+    dev = default_device() if device is None else device
+    check(lib().pdc_bglst_scan(_ptr(t), _ptr(y), _ptr(dy), t.size, f0, delta, j_begin, nf, _ptr(scalars), _ptr(out), dev))
     return out
 
 

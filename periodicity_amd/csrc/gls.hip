@@ -39,8 +39,22 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kPrepBlock = 1024;
 
-enum Mode { MODE_FIT_MEAN = 0, MODE_NO_MEAN = 1, MODE_RAW = 2 };
+// MODE_TREND (round 6, BGLST): the six sums of MODE_FIT_MEAN on the UNcentred values plus sum w t' sin, sum w t' cos,
+// and the marginal log-likelihood of the harmonic + linear-trend model as epilogue (bglst_loglik below).
+enum Mode { MODE_FIT_MEAN = 0, MODE_NO_MEAN = 1, MODE_RAW = 2, MODE_TREND = 3 };
 constexpr bool mode_fits_mean(int m) { return m == MODE_FIT_MEAN; }
+constexpr bool mode_sums_w(int m) { return m == MODE_FIT_MEAN || m == MODE_TREND; }   // sum w sin, sum w cos are wanted
+
+// Frequency-independent inputs of the BGLST epilogue, computed by the host in fp64 (O(N)); sums are over the
+// normalised weights w_i = sigma_i^-2 / W, tau = (t - t_ref) / span.
+struct TrendScalars {
+    double W;                 // sum sigma_i^-2
+    double yy, y1, ty, tt, t1; // sum w y^2, sum w y, sum w tau y, sum w tau^2, sum w tau
+    double shift;             // (t0 - t_ref) / span: the kernel's sums are over t' = t - t0, tau = t' / span + shift
+    double inv_span;          // 1 / span
+    double prec_a, prec_alpha, prec_beta;   // prior precisions 1 / sigma^2 (alpha in units of 1 / span)
+    double log_const;         // sum log(2 pi sigma_i^2) + log(sigma_A^4 sigma_alpha^2 sigma_beta^2)
+};
 
 struct GlsArgs {
     const double *rec;       // [n_total][6]
@@ -66,6 +80,7 @@ struct GlsArgs {
     // every resident workgroup slot gets the same work whatever tiles / slots is; a run covers pieces of at most
     // two tiles, a tile falls into at most three runs (`partial` = [3][6][nf]), gls_finish_kernel adds them
     int64_t bal_slots = 0, bal_units = 0, bal_chunks = 0, bal_tile_freqs = 0;
+    TrendScalars trend = {};   // MODE_TREND only
 };
 
 // balanced pieces: run s covers the units [s U / W, (s + 1) U / W); the run that holds unit x
@@ -265,6 +280,46 @@ __device__ __forceinline__ double gls_power(double Sh, double Ch, double S, doub
     return gls_power_from_sums<mode_fits_mean(MODE)>(Sh, Ch, S, C, S2, C2, YY, Werr, psd);
 }
 
+// ---- BGLST epilogue: log marginal likelihood of y = A cos(2 pi f t) + B sin(2 pi f t) + alpha tau + beta + noise ------
+// (Olspert, Pelt, Kapyla & Lehtinen 2018, A&A 615, A111: Bayesian generalised Lomb-Scargle with trend; the name the
+// reference exports at spectral.py:7,207-208 for an empty class.)  Independent zero-mean Gaussian priors N(0, sigma_A^2)
+// on A and B, N(0, sigma_alpha^2), N(0, sigma_beta^2) on the trend, Gaussian noise sigma_i: the model is linear in its
+// four parameters, so they integrate out in closed form.  With Phi = [cos, sin, tau, 1], N = diag sigma_i^2,
+// M = Phi^T N^-1 Phi + diag(prior precisions), b = Phi^T N^-1 y:
+//     log p(y | f) = -1/2 [ y^T N^-1 y - b^T M^-1 b + log |M| + log |Sigma_prior| + sum log(2 pi sigma_i^2) ]
+// (Woodbury + the matrix determinant lemma on C = Phi Sigma Phi^T + N).  The paper reaches the same number by
+// rotating (cos, sin) so that their cross term vanishes and completing squares one parameter at a time; with
+// sigma_A = sigma_B the likelihood does not depend on that rotation - nor on the kernel's own time origin t0.
+// M is 4 x 4, symmetric positive definite (the priors make it so): an unrolled Cholesky.
+__device__ __forceinline__ double bglst_loglik(double Sh, double Ch, double S, double C, double SS, double SC,
+                                               double TS, double TC, double Wsum, const TrendScalars &q) {
+    // sums over tau = t' / span + shift from the kernel's sums over t'
+    const double tc = TC * q.inv_span + q.shift * C, ts = TS * q.inv_span + q.shift * S;
+    const double W = q.W;
+    // M, lower triangle, basis order (cos, sin, tau, 1)
+    const double m00 = W * (Wsum - SS) + q.prec_a;
+    const double m10 = W * SC, m11 = W * SS + q.prec_a;
+    const double m20 = W * tc, m21 = W * ts, m22 = W * q.tt + q.prec_alpha;
+    const double m30 = W * C, m31 = W * S, m32 = W * q.t1, m33 = W * Wsum + q.prec_beta;
+    const double b0 = W * Ch, b1 = W * Sh, b2 = W * q.ty, b3 = W * q.y1;
+    // Cholesky M = L L^T
+    const double l00 = __builtin_sqrt(m00);
+    const double l10 = m10 / l00, l20 = m20 / l00, l30 = m30 / l00;
+    const double l11 = __builtin_sqrt(m11 - l10 * l10);
+    const double l21 = (m21 - l20 * l10) / l11, l31 = (m31 - l30 * l10) / l11;
+    const double l22 = __builtin_sqrt(m22 - l20 * l20 - l21 * l21);
+    const double l32 = (m32 - l30 * l20 - l31 * l21) / l22;
+    const double l33 = __builtin_sqrt(m33 - l30 * l30 - l31 * l31 - l32 * l32);
+    // z = L^-1 b;  b^T M^-1 b = |z|^2
+    const double z0 = b0 / l00;
+    const double z1 = (b1 - l10 * z0) / l11;
+    const double z2 = (b2 - l20 * z0 - l21 * z1) / l22;
+    const double z3 = (b3 - l30 * z0 - l31 * z1 - l32 * z2) / l33;
+    const double quad = W * q.yy - (z0 * z0 + z1 * z1 + z2 * z2 + z3 * z3);
+    const double logdet = 2.0 * (log(l00) + log(l11) + log(l22) + log(l33));
+    return -0.5 * (quad + logdet + q.log_const);
+}
+
 // ---- the scan ------------------------------------------------------------------------------------------
 // K = trial frequencies per thread; SPLIT ("S") = waves of the workgroup that share one 64-lane frequency
 // tile and split every staged chunk of samples between them (S = 1, 2 or 4), so that a short grid
@@ -344,9 +399,11 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     const double f_tile = __dadd_rn(a.f0, __dmul_rn((double)(a.j_begin + jt), a.delta));
     const double kdelta = (double)K * a.delta;  // spacing of the threads' first frequencies (exact)
 
+    static_assert(MODE != MODE_TREND || (SPLIT == 1 && !BAL && K <= 8), "BGLST: eight sums per frequency, whole curves per tile");
     double Sh[K], Ch[K], S[K], C[K], SS[K], SC[K];
+    double TS[K], TC[K];   // MODE_TREND: sum w t' sin, sum w t' cos (dead code in the other instances)
 #pragma unroll
-    for (int k = 0; k < K; ++k) Sh[k] = Ch[k] = S[k] = C[k] = SS[k] = SC[k] = 0.0;
+    for (int k = 0; k < K; ++k) Sh[k] = Ch[k] = S[k] = C[k] = SS[k] = SC[k] = TS[k] = TC[k] = 0.0;
 
     // plane rotation of {sin, cos} pairs: angle(x) + angle(y)
     auto rot = [](const double2 x, const double2 y) {
@@ -401,7 +458,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
                     tab[il][COLS * 8 + q] = cur;
                 }
                 sincos_fill(frac_product(f_tile, tp), cur.x, cur.y);
-                if (MODE == MODE_FIT_MEAN || MODE == MODE_NO_MEAN) {
+                if (MODE == MODE_FIT_MEAN || MODE == MODE_NO_MEAN || MODE == MODE_TREND) {
                     // carry u = sqrt(w) sin, v = sqrt(w) cos: rotations and the recurrence are linear,
                     // and every sum becomes one fma (the record holds sqrt(w) and sqrt(w) y)
                     cur.x *= sqw;
@@ -441,6 +498,7 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
         struct Ahead {
             d4 r;  // {sqrt(w) y, sqrt(w), cos, sin (2 pi delta t')}
             double cd2;
+            double tp;   // (MODE_TREND) t'
             double2 qa, qt;
         };
         auto fetch = [&](const int i) {
@@ -450,11 +508,13 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
             const cd4 *rp = reinterpret_cast<const cd4 *>(reinterpret_cast<const cdbl *>(srec) + i * 6);
             h.r = rp[0];
             h.cd2 = reinterpret_cast<const cdbl *>(rp)[4];
+            h.tp = MODE == MODE_TREND ? reinterpret_cast<const cdbl *>(rp)[5] : 0.0;
             return h;
         };
         auto accumulate = [&](const Ahead &h) {
             const double2 seed = rot(h.qa, h.qt);
             const double wy = h.r[0], w = h.r[1], cd = h.r[2], sd = h.r[3], cd2 = h.cd2;
+            const double wt = MODE == MODE_TREND ? w * h.tp : 0.0;   // sqrt(w) t': s and c carry the other sqrt(w)
             double s = seed.x, c = seed.y;
             double sp = 0.0, cp = 0.0;  // previous step of the recurrence
 #pragma unroll
@@ -462,9 +522,13 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
                 Sh[k] = __builtin_fma(wy, s, Sh[k]);
                 Ch[k] = __builtin_fma(wy, c, Ch[k]);
                 if (MODE != MODE_RAW) {
-                    if (MODE == MODE_FIT_MEAN) {
+                    if (mode_sums_w(MODE)) {
                         S[k] = __builtin_fma(w, s, S[k]);
                         C[k] = __builtin_fma(w, c, C[k]);
+                    }
+                    if (MODE == MODE_TREND) {
+                        TS[k] = __builtin_fma(wt, s, TS[k]);
+                        TC[k] = __builtin_fma(wt, c, TC[k]);
                     }
                     SS[k] = __builtin_fma(s, s, SS[k]);
                     SC[k] = __builtin_fma(s, c, SC[k]);
@@ -579,8 +643,8 @@ __global__ __launch_bounds__(kBlock, (K >= 16 ? 2 : 1)) void gls_scan_kernel(Gls
     for (int k = 0; k < K; ++k) {
         const int64_t j = jl + k;
         if (owner && j < a.nf) {
-            const double p = gls_power<MODE>(Sh[k], Ch[k], S[k], C[k], SS[k], SC[k], YY, Wsum,
-                                             Werr, a.psd);
+            const double p = MODE == MODE_TREND ? bglst_loglik(Sh[k], Ch[k], S[k], C[k], SS[k], SC[k], TS[k], TC[k], Wsum, a.trend)
+                                                : gls_power<MODE>(Sh[k], Ch[k], S[k], C[k], SS[k], SC[k], YY, Wsum, Werr, a.psd);
             if (a.power) a.power[curve * a.nf + j] = p;
             if (p == p && (best_j < 0 || p > best)) {
                 best = p;
@@ -1141,8 +1205,10 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
              const int64_t *d_offsets, int64_t n_total, int64_t n_curves, int shared_t, double f0,
              double delta, int64_t j_begin, int64_t nf, int mode, int psd, double *d_power,
              double *d_raw_s, double *d_raw_c, double *d_amax, int64_t *d_argmax, void *work,
-             int64_t work_bytes, const int32_t *d_picks = nullptr) {
+             int64_t work_bytes, const int32_t *d_picks = nullptr, const TrendScalars *trend = nullptr) {
     PDC_REQUIRE(d_t && d_y, "gls: t and y must not be NULL");
+    PDC_REQUIRE((mode == MODE_TREND) == (trend != nullptr) && (mode != MODE_TREND || (n_curves == 1 && !d_picks && !shared_t)),
+                "gls: the trend mode takes one curve and its scalars");
     PDC_REQUIRE(!d_picks || (shared_t && d_offsets && mode != MODE_RAW), "gls: picks need a shared time axis");
     PDC_REQUIRE(n_total >= 0 && n_curves >= 1 && nf >= 0 && j_begin >= 0, "gls: negative size");
     PDC_REQUIRE(n_curves == 1 || d_offsets, "gls: a batch needs offsets");
@@ -1260,7 +1326,13 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
 
     int K, S, parts;
     tile_shape(n_curves, nf, n_total, mode != MODE_RAW, &K, &S, &parts);
+    if (mode == MODE_TREND) {   // eight sums per frequency: K <= 8; every tile streams the whole curve (no sample parts)
+        K = K > 8 ? 8 : K;
+        S = 1;
+        parts = 1;
+    }
     GlsArgs a;
+    if (trend) a.trend = *trend;
     a.rec = p.rec;
     a.offsets = d_offsets;
     a.scal = p.scal;
@@ -1302,7 +1374,7 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     // slot gets the same work, and gls_finish_kernel adds the <= 3 pieces of a tile.  PDC_GLS_BAL=0/1 forces it.
     static const int env_bal = [] { const char *e = getenv("PDC_GLS_BAL"); return e ? atoi(e) : -1; }();
     bool balanced = false;
-    if (n_curves == 1 && parts == 1 && mode != MODE_RAW && K == 16 && S >= 2 && env_bal != 0) {
+    if (n_curves == 1 && parts == 1 && mode != MODE_RAW && mode != MODE_TREND && K == 16 && S >= 2 && env_bal != 0) {
         const int64_t slots = 512, nchunks = (n_total + 127) / 128;
         const int64_t full = a.tiles / slots, rem = a.tiles % slots;
         // (a slot's partner gone, a workgroup runs alone on its CU at about twice the speed)
@@ -1328,6 +1400,9 @@ int scan_dev(int device, hipStream_t st, const double *d_t, const double *d_y, c
     }
     if (balanced) {
         // (launched above)
+    } else if (mode == MODE_TREND) {
+        if (K == 4) hipLaunchKernelGGL((gls_scan_kernel<4, MODE_TREND, 1>), grid, dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((gls_scan_kernel<8, MODE_TREND, 1>), grid, dim3(kBlock), 0, st, a);
     } else if (mode == MODE_FIT_MEAN) {
         launch_scan<MODE_FIT_MEAN>(K, S, grid, st, a);
     } else if (mode == MODE_NO_MEAN) {
@@ -1459,6 +1534,50 @@ int pdc_gls_scan(const double *t, const double *y, const double *dy, int64_t n, 
     const int64_t offsets[2] = {0, n};
     return pdc_gls_scan_batch(t, y, dy, offsets, 1, 0, f0, delta, j_begin, nf, fit_mean, psd,
                               power_out, nullptr, nullptr, device);
+}
+
+// ---- BGLST: Bayesian generalised Lomb-Scargle with linear trend (spectral.py:7,207-208 exports the name; the class
+// body upstream is `pass`) ---------------------------------------------------------------------------------------
+// scalars[12] = {W, yy, y1, ty, tt, t1, shift, inv_span, prec_a, prec_alpha, prec_beta, log_const}: TrendScalars in
+// its own order (the host computes them in fp64 - periodicity_amd/spectral.py:BGLST._scalars).
+int pdc_bglst_scan_dev(int device, void *stream, const double *d_t, const double *d_y, const double *d_dy, int64_t n,
+                       double f0, double delta, int64_t j_begin, int64_t nf, const double *scalars, double *d_loglik,
+                       void *work, int64_t work_bytes) {
+    PDC_REQUIRE(scalars && (d_loglik || nf == 0), "bglst: NULL argument");
+    PDC_REQUIRE(n >= 4, "bglst: at least four samples (four parameters are marginalised)");
+    TrendScalars q;
+    q.W = scalars[0]; q.yy = scalars[1]; q.y1 = scalars[2]; q.ty = scalars[3]; q.tt = scalars[4]; q.t1 = scalars[5];
+    q.shift = scalars[6]; q.inv_span = scalars[7]; q.prec_a = scalars[8]; q.prec_alpha = scalars[9]; q.prec_beta = scalars[10];
+    q.log_const = scalars[11];
+    PDC_REQUIRE(q.W > 0.0 && q.prec_a > 0.0 && q.prec_alpha > 0.0 && q.prec_beta > 0.0 && q.inv_span > 0.0,
+                "bglst: weights, prior precisions and the time span must be positive");
+    return scan_dev(device, (hipStream_t)stream, d_t, d_y, d_dy, nullptr, n, 1, 0, f0, delta, j_begin, nf, MODE_TREND, 0,
+                    d_loglik, nullptr, nullptr, nullptr, nullptr, work, work_bytes, nullptr, &q);
+}
+
+int pdc_bglst_scan(const double *t, const double *y, const double *dy, int64_t n, double f0, double delta, int64_t j_begin,
+                   int64_t nf, const double *scalars, double *loglik_out, int device) {
+    PDC_REQUIRE(t && y && scalars && (loglik_out || nf == 0), "bglst: NULL argument");
+    PDC_REQUIRE(n >= 0 && nf >= 0 && j_begin >= 0, "bglst: negative size");
+    PDC_TRY(use_device(device));
+    DeviceLock lock(device);
+    const int64_t wb = pdc_gls_work_bytes(n, 1, nf);
+    void *d_t, *d_y, *d_dy = nullptr, *d_out, *d_work;
+    PDC_TRY(cached(device, SLOT_IN0, n * 8, &d_t));
+    PDC_TRY(cached(device, SLOT_IN1, n * 8, &d_y));
+    if (dy) PDC_TRY(cached(device, SLOT_IN2, n * 8, &d_dy));
+    PDC_TRY(cached(device, SLOT_OUT0, nf * 8, &d_out));
+    PDC_TRY(cached(device, SLOT_WORK, wb, &d_work));
+    hipStream_t st = nullptr;
+    PDC_TRY(host_stream(device, &st));
+    PDC_HIP(hipMemcpyAsync(d_t, t, n * 8, hipMemcpyHostToDevice, st));
+    PDC_HIP(hipMemcpyAsync(d_y, y, n * 8, hipMemcpyHostToDevice, st));
+    if (dy) PDC_HIP(hipMemcpyAsync(d_dy, dy, n * 8, hipMemcpyHostToDevice, st));
+    PDC_TRY(pdc_bglst_scan_dev(device, st, (double *)d_t, (double *)d_y, (double *)d_dy, n, f0, delta, j_begin, nf, scalars,
+                               (double *)d_out, d_work, wb));
+    PDC_HIP(hipMemcpyAsync(loglik_out, d_out, nf * 8, hipMemcpyDeviceToHost, st));
+    PDC_HIP(hipStreamSynchronize(st));
+    return PDC_OK;
 }
 
 int pdc_trig_sums(const double *t, const double *w, int64_t n, double f0, double delta, int64_t nf,

@@ -142,7 +142,8 @@ constexpr int kPkMaxKTotal = 1024;
 #define PDC_PK_SORT_FROM 16
 #endif
 constexpr int kPkSortFrom = PDC_PK_SORT_FROM;      // rankings of more than this many entries sort the candidate list instead of m reduction rounds   // ... per call: chunks of 64, each launch ranking what comes AFTER the chunk before
-constexpr int kPkPre = 68;           // by prominence: the first walks go to the k + 4 highest maxima
+constexpr int kPkPre = 132;          // by prominence: the first walks go to the k + 4 highest maxima (first chunk), to 2 k + 4
+                                     // seeds in the later chunks of a k > 64 call (round 6: a tighter threshold for the second sweep)
 #ifndef PDC_PK_WALK_LOADS
 #define PDC_PK_WALK_LOADS 8
 #endif
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(kPkBlock, SORT ? PDC_PK_WAVES : PDC_PK_WAVES + 1) v
     constexpr int kWin = SORT ? kPkPre : kPkSortFrom + 4;     // winners a ranking of this instance can be asked for
     __shared__ double win_key[kWin], win_h[kWin], win_p[kWin];
     __shared__ long long win_idx[kWin];
-    __shared__ int wtop[kPkBlock / 64 * kWin];
+    constexpr int kTop = kPkSortFrom + 4;                     // few-ranks rankings (m <= kPkSortFrom): every wave's winners
+    __shared__ int wtop[kPkBlock / 64 * kTop];
     __shared__ double s_low[2][8][2];                         // the walks of a pass: lowest sample met leftwards / rightwards               // few ranks: every wave's winners (slots of the candidate list)
     __shared__ unsigned s_need[32];   // second sweep: chunks that can hold a candidate at the initial tau
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(kPkBlock, SORT ? PDC_PK_WAVES : PDC_PK_WAVES + 1) v
         }
         __syncthreads();
     };
-    const bool excl = a.k_off > 0;
+    const bool excl = SORT && a.k_off > 0;   // (later chunks of a k > 64 call always run the SORT instance: launch_topk)
     double prev_key = inf;
     long long prev_idx = -1;
     double h_cut = inf;   // (later chunks by prominence) lowest height among the winners already output
@@ -522,19 +524,19 @@ __global__ __launch_bounds__(kPkBlock, SORT ? PDC_PK_WAVES : PDC_PK_WAVES + 1) v
                     double bk;
                     int bi, be;
                     if (!wave_best(lk, li, le, bk, bi, be)) break;    // (wave-uniform)
-                    if (lane == 0) wtop[wave * kWin + r] = be;
+                    if (lane == 0) wtop[wave * kTop + r] = be;
                     wpk = bk;
                     wpi = bi;
                     any_prev = true;
                 }
-                for (int q = r + lane; q < kWin; q += 64) wtop[wave * kWin + q] = -1;
+                for (int q = r + lane; q < kTop; q += 64) wtop[wave * kTop + q] = -1;
             }
             __syncthreads();
             bool any_prev = ex;
             for (int round = 0; round < m; ++round) {
                 double lk = 0.0;
                 int li = -1, le = -1;
-                for (int q = lane; q < (kPkBlock / 64) * kWin; q += 64) {
+                for (int q = lane; q < (kPkBlock / 64) * kTop; q += 64) {
                     const int e = wtop[q];
                     if (e < 0) continue;
                     const double key = by_prom ? cp[e] : ch[e];
@@ -733,7 +735,9 @@ __global__ __launch_bounds__(kPkBlock, SORT ? PDC_PK_WAVES : PDC_PK_WAVES + 1) v
     };
 
     const int K = a.k < kPkMaxK ? a.k : kPkMaxK;
-    const int pre = K + 4;   // by prominence: the first walks go to the `pre` highest maxima
+    // by prominence: the first walks go to the `pre` highest maxima - in a later chunk (seeds below h_cut, see
+    // rank_candidates) to twice as many: tau is then the K-th of 2 K + 4 prominences instead of the K-th of K + 4
+    const int pre = SORT && a.k_off > 0 ? 2 * K + 4 : K + 4;
     const int64_t ob = (int64_t)blockIdx.x * a.k_total + a.k_off;
     if (excl) {
         prev_key = (a.by_prominence ? a.prom : a.height)[ob - 1];
@@ -945,7 +949,8 @@ int launch_topk(hipStream_t st, PeakArgs a, int64_t n_curves) {
     a.tile = 0;
     const size_t lds = (size_t)(a.nblk > 0 ? a.nblk : 1) * 16 + (size_t)kPkCap * 20 + 16;
     PDC_REQUIRE(lds <= 150 * 1024, "peaks_topk: %lld bins per spectrum need %zu bytes of LDS", (long long)a.nf, lds);
-    if (a.k > kPkSortFrom) {
+    if (a.k > kPkSortFrom || a.k_off > 0) {   // (the exclusion logic of later chunks lives in the SORT instance only: the few-ranks
+                                              // instance keeps the 80 registers of six workgroups per CU)
         PDC_TRY(allow_dynamic_lds((const void *)peaks_topk_kernel<true>, 150 * 1024));
         hipLaunchKernelGGL(peaks_topk_kernel<true>, dim3((unsigned)n_curves), dim3(kPkBlock), lds, st, a);
     } else {

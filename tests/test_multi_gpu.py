@@ -11,6 +11,7 @@
 The fan-out these replace: ``multiprocessing.Pool.map`` over trial periods,
 ``/root/reference/src/periodicity/phase.py:69-70,185-186``."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
