@@ -149,19 +149,18 @@ __global__ __launch_bounds__(kBlock) void fft_pass_kernel(const cplx *__restrict
 //   stage B  (jj, s2) pairs, 16/RB per thread: RB-point DFT over r1 -> Y[s2 + 16 s1]
 //            -> out[(j-k)*R + k + s*Ns]
 // Global accesses are runs of >= 16 consecutive complex numbers (256 B).  Requires N >= 4096.
-// HALVES (round 6): the exchange between the two stages goes through LDS one component at a time - real parts, then
-// imaginary parts - so the tile takes 8 instead of 16 bytes a point: 37 KB instead of 74, three workgroups per CU
-// instead of two (the passes are bound by memory latency at two waves per SIMD, not by bytes: pass 1 reads a fifth of
-// what pass 2 reads and takes as long), for two more barriers.  Same arithmetic, same bits.
-template <int RB, bool HALVES = false>
+// (Round 6, measured and withdrawn - profiles/r06_fft_halves_experiment.patch: the exchange between the stages one
+// component at a time - real parts, then imaginary parts, 37 KB of LDS instead of 74, three to four workgroups per CU
+// instead of two, two more barriers: C2's FFT path 0.599 against 0.538 ms on the same box.  The passes are not short of
+// resident waves.)
+template <int RB>
 __global__ __launch_bounds__(256) void fft_pass_lds_kernel(const cplx *__restrict__ in,
                                                             cplx *__restrict__ out, int64_t N,
                                                             int64_t Ns, int64_t keep, LiveArgs lv) {
     constexpr int R = 16 * RB;
     constexpr int JT = 256 / RB;          // butterflies per workgroup
     constexpr int ROW = R + 16;           // padded LDS row per butterfly
-    __shared__ double tile_raw[JT * ROW * (HALVES ? 1 : 2)];   // [jj][r1][s2]: complex, or one component at a time
-    cplx *tile = reinterpret_cast<cplx *>(tile_raw);
+    __shared__ cplx tile[JT * ROW];       // [jj][r1][s2]
     __shared__ cplx wR[R];
     const int tid = threadIdx.x;
     const int64_t live = live_cells(lv, blockIdx.y, N);
@@ -174,8 +173,6 @@ __global__ __launch_bounds__(256) void fft_pass_lds_kernel(const cplx *__restric
     }
     const int64_t T = N / R;
     const int64_t j_base = (int64_t)blockIdx.x * JT;
-    double carry_im[16];      // HALVES: the imaginary parts of stage A's results wait here for the tile
-    int carry_jj = 0, carry_r1 = 0;
     // ---- stage A -------------------------------------------------------------------------------
     {
         const int jj = tid % JT, r1 = tid / JT;
@@ -203,46 +200,12 @@ __global__ __launch_bounds__(256) void fft_pass_lds_kernel(const cplx *__restric
         }
         Dft<16>::run(v);
         __syncthreads();  // wR ready
-        if (!HALVES) {
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2)
-                tile[jj * ROW + r1 * 16 + s2] = cmul(v[s2], wR[(r1 * s2) % R]);
-        } else {
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) {
-                v[s2] = cmul(v[s2], wR[(r1 * s2) % R]);
-                tile_raw[jj * ROW + r1 * 16 + s2] = v[s2].re;
-            }
-            carry_jj = jj;
-            carry_r1 = r1;
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) carry_im[s2] = v[s2].im;
-        }
+        for (int s2 = 0; s2 < 16; ++s2)
+            tile[jj * ROW + r1 * 16 + s2] = cmul(v[s2], wR[(r1 * s2) % R]);
     }
     __syncthreads();
     // ---- stage B -------------------------------------------------------------------------------
-    cplx vb[16 / RB][RB];
-    if (HALVES) {
-        // real parts in, imaginary parts through the same tile
-#pragma unroll
-        for (int it = 0; it < 16 / RB; ++it) {
-            const int pair = tid + it * 256;
-            const int jj = Ns > 1 ? pair % JT : pair / 16, s2 = Ns > 1 ? pair / JT : pair % 16;
-#pragma unroll
-            for (int r1 = 0; r1 < RB; ++r1) vb[it][r1].re = tile_raw[jj * ROW + r1 * 16 + s2];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) tile_raw[carry_jj * ROW + carry_r1 * 16 + s2] = carry_im[s2];
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 16 / RB; ++it) {
-            const int pair = tid + it * 256;
-            const int jj = Ns > 1 ? pair % JT : pair / 16, s2 = Ns > 1 ? pair / JT : pair % 16;
-#pragma unroll
-            for (int r1 = 0; r1 < RB; ++r1) vb[it][r1].im = tile_raw[jj * ROW + r1 * 16 + s2];
-        }
-    }
 #pragma unroll
     for (int it = 0; it < 16 / RB; ++it) {
         const int pair = tid + it * 256;  // (jj, s2) pairs, JT * 16 of them
@@ -254,7 +217,7 @@ __global__ __launch_bounds__(256) void fft_pass_lds_kernel(const cplx *__restric
         const int64_t k = j & (Ns - 1);
         cplx v[RB];
 #pragma unroll
-        for (int r1 = 0; r1 < RB; ++r1) v[r1] = HALVES ? vb[it][r1] : tile[jj * ROW + r1 * 16 + s2];
+        for (int r1 = 0; r1 < RB; ++r1) v[r1] = tile[jj * ROW + r1 * 16 + s2];
         Dft<RB>::run(v);
         const int64_t j0 = (j - k) * R + k;
 #pragma unroll
@@ -920,16 +883,9 @@ cplx *inverse_fft(hipStream_t st, cplx *a, cplx *b, int64_t N, int batch = 1, in
             const int64_t R = (int64_t)1 << lds_bits;
             const int jt = 256 / (int)(R / 16);
             const dim3 grid((unsigned)((N / R) / jt), (unsigned)batch);
-            static const bool halves = [] { const char *e = getenv("PDC_FFT_HALVES"); return !(e && e[0] == '0'); }();   // (A/B: PDC_FFT_HALVES=0)
             switch (lds_bits) {
-                case 8:
-                    if (halves) hipLaunchKernelGGL((fft_pass_lds_kernel<16, true>), grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv);
-                    else hipLaunchKernelGGL((fft_pass_lds_kernel<16, false>), grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv);
-                    break;
-                case 7:
-                    if (halves) hipLaunchKernelGGL((fft_pass_lds_kernel<8, true>), grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv);
-                    else hipLaunchKernelGGL((fft_pass_lds_kernel<8, false>), grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv);
-                    break;
+                case 8: hipLaunchKernelGGL(fft_pass_lds_kernel<16>, grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv); break;
+                case 7: hipLaunchKernelGGL(fft_pass_lds_kernel<8>, grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv); break;
                 case 6: hipLaunchKernelGGL(fft_pass_lds_kernel<4>, grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv); break;
                 default: hipLaunchKernelGGL(fft_pass_lds_kernel<2>, grid, dim3(256), 0, st, src, dst, N, Ns, keep, lv); break;
             }

@@ -989,7 +989,7 @@ int pdc_peaks_topk_dev(int device, void *stream, const double *d_power, int64_t 
     a.prom = d_prominence;
     a.k_total = k;
     // k > 64: one launch per 64 ranks; launch c ranks what comes after column 64 c - 1 of the outputs (every launch
-    // sweeps the spectra again: 0.4-0.6 ms per 64 ranks for the 1.64 GB of a C3 batch)
+    // sweeps the spectra again: ~1.2 ms per 64 ranks by height for the 1.64 GB of a C3 batch, 2-3 ms by prominence)
     for (int off = 0; off < k; off += kPkMaxK) {
         a.k = k - off < kPkMaxK ? k - off : kPkMaxK;
         a.k_off = off;

@@ -205,7 +205,7 @@ want_sl = _cabi.stringlength_scan(t, m, periods)
 want_short = _cabi.stringlength_scan(t, m, short)
 want_ss = _cabi.supersmoother_scan(t, y, ss_p, 0.0)
 np.testing.assert_allclose(want_sl[[0, 50, 95]], co.stringlength_scan(t, m, periods[[0, 50, 95]]), rtol=1e-9)
-_cabi.release()
+_cabi.check(lib.pdc_release())
 os.environ["PDC_WORK_BUDGET_GB"] = "4"
 tight = [lib.pdc_stringlength_work_bytes(n, 2048), lib.pdc_supersmoother_work_bytes(n, 2048)]
 assert free[0] > 8 << 30 and free[1] > 4 << 30, free          # the built-in caps ask for far more than 4 GB ...
