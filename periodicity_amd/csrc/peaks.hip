@@ -136,7 +136,7 @@ constexpr int kPkBlock = 256;
 #define PDC_PK_WAVES 5
 #endif
 constexpr int kPkMaxBlocks = 4096;   // LDS: two doubles per block
-constexpr int kPkMaxK = 64;          // ranked peaks per launch
+constexpr int kPkMaxK = 128;         // ranked peaks per launch (round 6: 128 - half the launches, and sweeps, of a k > 64 call; round 5: 64)
 constexpr int kPkMaxKTotal = 1024;
 #ifndef PDC_PK_SORT_FROM
 #define PDC_PK_SORT_FROM 16
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(kPkBlock, SORT ? PDC_PK_WAVES : PDC_PK_WAVES + 1) v
     const int K = a.k < kPkMaxK ? a.k : kPkMaxK;
     // by prominence: the first walks go to the `pre` highest maxima - in a later chunk (seeds below h_cut, see
     // rank_candidates) to twice as many: tau is then the K-th of 2 K + 4 prominences instead of the K-th of K + 4
-    const int pre = SORT && a.k_off > 0 ? 2 * K + 4 : K + 4;
+    const int pre = SORT && a.k_off > 0 && 2 * K + 4 <= kPkPre ? 2 * K + 4 : K + 4;
     const int64_t ob = (int64_t)blockIdx.x * a.k_total + a.k_off;
     if (excl) {
         prev_key = (a.by_prominence ? a.prom : a.height)[ob - 1];
@@ -988,7 +988,7 @@ int pdc_peaks_topk_dev(int device, void *stream, const double *d_power, int64_t 
     a.height = d_height;
     a.prom = d_prominence;
     a.k_total = k;
-    // k > 64: one launch per 64 ranks; launch c ranks what comes after column 64 c - 1 of the outputs (every launch
+    // k > 128: one launch per 128 ranks; launch c ranks what comes after column 128 c - 1 of the outputs (every launch
     // sweeps the spectra again: ~1.2 ms per 64 ranks by height for the 1.64 GB of a C3 batch, 2-3 ms by prominence)
     for (int off = 0; off < k; off += kPkMaxK) {
         a.k = k - off < kPkMaxK ? k - off : kPkMaxK;
