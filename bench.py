@@ -29,7 +29,7 @@ The product path is the C ABI (libperiodicity_hip.so).  ``oracle/`` is touched o
 
 Every roofline figure in the line means one of two things, and says which:
   * ``executed_issue_frac``: VALU issue cycles per launch / 1024 SIMDs / 2.4 GHz / the HIP-event time of this
-    run, the cycles priced BY INSTRUCTION TYPE from rocprofv3's typed counters (profiles/r05_pmc_summary.json,
+    run, the cycles priced BY INSTRUCTION TYPE from rocprofv3's typed counters (profiles/r06_pmc_summary.json,
     written by tools/pmc_summary.py for the kernel sources whose hash it records - a summary of other sources
     is refused): the fp64 / int64 classes (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64, _INT64) at 4 cycles per
     wave64 instruction, every other VALU instruction at 2 (SIMD-32); ``executed_issue.frac_all_at_4_cycles`` is
@@ -66,7 +66,7 @@ SL_MODEL_BYTES_PER_PAIR = 48.0  # HBM bucket-pass model
 HBM_PEAK_TBS = 8.0
 N_SAMPLES = 100_000
 NF_PER_GPU = 1_000_000
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")
 GATHER_UBENCH = os.path.join(ROOT, "profiles", "r03_ubench_gather_rate.json")
 
 
@@ -660,6 +660,16 @@ def extra_configs(lib, cabi, dev, stream, t2, y2, dy2, f0, delta, nf2, with_cpu=
                                                                "hbm_bytes") if k in blk}
             else:
                 entry["executed_issue_note"] = why
+            # the front-end kernels of a batch (round 6: the histogram adds one LDS atomic per run of equal buckets)
+            front = {}
+            for kname in ("sl_hist_kernel", "sl_bound_kernel", "sl_sort_kernel"):
+                pm = profiled_ms_of(kname)
+                kk, _ = pmc_for(kname, pm) if pm else (None, None)
+                if kk and kk.get("SQ_LDS_IDX_ACTIVE"):
+                    front[kname] = {"profiled_ms_per_batch": kk["ms"], "lds_bank_conflict_share": round(
+                        kk.get("SQ_LDS_BANK_CONFLICT", 0) / kk["SQ_LDS_IDX_ACTIVE"], 4), "kernel": kk["name"]}
+            if front:
+                entry["per_batch_kernels"] = front
         out[key] = entry
         for b in bl + [bel, wl]:
             b.free()

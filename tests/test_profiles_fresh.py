@@ -1,4 +1,4 @@
-"""bench.py's roofline block reads executed-instruction counts from profiles/r05_pmc_summary.json and
+"""bench.py's roofline block reads executed-instruction counts from profiles/r06_pmc_summary.json and
 refuses entries collected for other kernel sources.  This test keeps the committed summary in step
 with the committed sources of the HEADLINE kernel (re-run tools/collect_pmc.sh on a GPU box after
 touching them), and checks the refusal logic itself."""

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): everything profiles/ needs from ONE lease - the PMC passes + kernel statistics
 # (tools/collect_pmc.sh), the default bench line, the loopback-8 line (strong-scaling entries), the StringLength
-# shapes, the PDM shapes, the Supersmoother timings and the bootstrap end-to-end comparison.   tools/collect_round.sh gpurun_out/r05_final
+# shapes, the PDM shapes, the Supersmoother timings and the bootstrap end-to-end comparison.   tools/collect_round.sh gpurun_out/r06_final
 out=${1:-gpurun_out/round}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
 bash tools/collect_pmc.sh "$out/pmc" > "$out/pmc.log" 2>&1
-cp "$out/pmc/pmc_summary.json" profiles/r05_pmc_summary.json     # bench.py reads it from there (this lease only)
+cp "$out/pmc/pmc_summary.json" profiles/r06_pmc_summary.json     # bench.py reads it from there (this lease only)
 python3 bench.py > "$out/bench_n1.json" 2> "$out/bench_n1.err"
 python3 bench.py --loopback 8 > "$out/bench_loopback8.json" 2> "$out/bench_loopback8.err"
 (LARGE=1 python3 tools/sl_shapes.py; SHAPES=29000x300,50000x1000,74326x1000,60000x20000,131000x8192,250000x4096,300000x4096,400000x2048,1000000x8192,2000000x512,3000000x256 python3 tools/sl_shapes.py; echo "== lists mode only (PDC_SL_SLICES=0: what samples in any order got up to round 4)"; PDC_SL_SLICES=0 SHAPES=300000x4096,400000x2048,1000000x2048,2000000x512 python3 tools/sl_shapes.py; echo "== samples in a random order (ordered by time on the device first: timesort.inc)"; SHUFFLE=1 SHAPES=300000x4096,400000x2048,1000000x2048,2000000x512 python3 tools/sl_shapes.py; echo "== no streamed kernels, no bit planes (round-3 dispatch)"; PDC_SL_STREAM=0 PDC_SL_P17=0 LARGE=1 python3 tools/sl_shapes.py) > "$out/sl_shapes.txt" 2>&1
