@@ -386,7 +386,14 @@ int pdc_phase_plan_destroy(void *plan);
  * now 13.7 against 13.3 ms in order; profiles/r05_sl_shapes.txt).  Non-finite or |t| beyond 1e+-150: no time sort,
  * the lists as before.  Below 262 144 samples the kernels sort any order by phase directly: the periods which outlast
  * the samples are then sorted like any other, and two samples that share a phase WITHOUT sharing a time stamp keep the
- * caller's order there (above: the time order, as the reference's TSeries would have it - core.py:473-477). */
+ * caller's order there (above: the time order, as the reference's TSeries would have it - core.py:473-477).
+ * The `_dev` entry cannot look at the samples from the host: from 262 144 samples on it ALWAYS enqueues the time sort's
+ * intake (a 16 n-byte copy of (t, m) and 25 launches that return at once when the device finds the samples in order:
+ * 3.19 against 3.15 ms at N = 1e6 x 256 periods) and sizes its workspace for the bin lists; the host entry and the
+ * phase plan hold the arrays, check the order and the periods first, and skip both.
+ * Workspace (both forms): PDC_WORK_BUDGET_GB=<float> caps it - pdc_stringlength_work_bytes and the scan read the same
+ * value -, the host entry also fits it to the device's free memory; smaller batches, same bits; a budget that not
+ * even one period fits in is an error whose text names it. */
 int pdc_stringlength_scan(const double *t, const double *m, int64_t n,
                           const double *periods, int64_t n_periods,
                           double *ell_out, int device);

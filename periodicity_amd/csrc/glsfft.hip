@@ -977,34 +977,21 @@ int pdc_gls_scan_fft_dev(int device, void *stream, const double *d_t, const doub
     // batched FFT passes (gridDim.y = ngrid; 6.4 vs 6.7 ms at nfft = 2^26).
     const int64_t mall = (int64_t)256 << 20;
     const cplx *result[3] = {nullptr, nullptr, nullptr};
+    // (round 6: ALL grids' deposits in one launch up front in both branches - a deposit launch is a chain of dependent
+    // searches, ~50 us whatever it writes, and only the live fifth of a grid is written: 27 MB that the other grids'
+    // passes may push out of the Infinity Cache cost ~5 us to read back, a second launch cost 50.)
+    launch_deposit(st, DepositArgs{d_t, wy, w, nullptr, n, 0, ngrid, 0, 2, scal + 2, 0, nfft, df, fmin,
+                                   reinterpret_cast<double *>(grid[0])}, 1);
+    if (n > 0) {
+        Spread3Args s3{d_t, wy, w, scal, n, nfft, df, fmin, reinterpret_cast<double *>(grid[0]), fit_mean};
+        hipLaunchKernelGGL(glsfft_spread3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
+                           dim3(kBlock), 0, st, s3);
+    }
     if (nfft * 32 <= mall && (int64_t)ngrid * nfft * 32 > mall) {
-        for (int g = 0; g < ngrid; ++g) {
-            if (g < 2)   // (slot 0 fills grid 2 along with grid 0: same positions and phases)
-                launch_deposit(st, DepositArgs{d_t, wy, w, nullptr, n, 0, ngrid, g, 1, scal + 2, 0, nfft, df, fmin,
-                                               reinterpret_cast<double *>(grid[0])}, 1);
-            SpreadArgs sp;
-            sp.t = d_t;
-            sp.h = g == 0 ? wy : w;
-            sp.scal = scal;
-            sp.tmin_value = 0.0;
-            sp.n = n;
-            sp.nfft = nfft;
-            sp.df = g == 1 ? 2.0 * df : df;      // _trig_sum(t, w, 2 * df, nf, 2 * fmin)   (:110)
-            sp.fmin = g == 1 ? 2.0 * fmin : fmin;
-            sp.grid = reinterpret_cast<double *>(grid[g]);
-            if (n > 0)
-                hipLaunchKernelGGL(glsfft_spread_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
-                                   dim3(kBlock), 0, st, sp);
+        // the PASSES grid by grid: a grid's 256 MiB ping-pong is what has to stay cache-warm
+        for (int g = 0; g < ngrid; ++g)
             result[g] = inverse_fft(st, grid[g], scratch + g * nfft, nfft, 1, nf, LiveArgs{scal + 2, 0, 1, g, df});
-        }
     } else {
-        launch_deposit(st, DepositArgs{d_t, wy, w, nullptr, n, 0, ngrid, 0, 2, scal + 2, 0, nfft, df, fmin,
-                                       reinterpret_cast<double *>(grid[0])}, 1);
-        if (n > 0) {
-            Spread3Args s3{d_t, wy, w, scal, n, nfft, df, fmin, reinterpret_cast<double *>(grid[0]), fit_mean};
-            hipLaunchKernelGGL(glsfft_spread3_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)),
-                               dim3(kBlock), 0, st, s3);
-        }
         const cplx *res = inverse_fft(st, grid[0], scratch, nfft, ngrid, nf, LiveArgs{scal + 2, 0, ngrid, 0, df});
         for (int g = 0; g < ngrid; ++g) result[g] = res + g * nfft;
     }
