@@ -435,6 +435,8 @@ constexpr int kDepStage = 1024;                  // positions of a workgroup's s
 
 __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
     __shared__ double s_pos[kDepStage];
+    __shared__ double s_dt[kDepStage], s_h[kDepStage], s_h2[kDepStage];   // round 6: the samples themselves too (the deposit loop
+                                                                          // waited for three dependent global loads per sample)
     __shared__ unsigned long long s_ballot[2][kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t curve = blockIdx.y / a.nslots;
@@ -499,7 +501,12 @@ __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
         w_last = lo[1];
         staged = w_last - w_first <= kDepStage;   // (workgroup-uniform)
         if (staged)
-            for (int64_t i = w_first + tid; i < w_last; i += kBlock) s_pos[i - w_first] = position(i);
+            for (int64_t i = w_first + tid; i < w_last; i += kBlock) {
+                s_pos[i - w_first] = position(i);
+                s_dt[i - w_first] = t[i] - tmin;
+                s_h[i - w_first] = h[i];
+                s_h2[i - w_first] = twin ? h2[i] : 0.0;
+            }
         __syncthreads();
     }
     auto pos_at = [&](int64_t i) -> double { return staged ? s_pos[i - w_first] : position(i); };
@@ -528,12 +535,14 @@ __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
             } else if ((int64_t)tn < g0 || (int64_t)tn >= g0 + kDepCells) {
                 continue;
             }
-            const double dt = t[i] - tmin;
+            const double dt = staged ? s_dt[i - w_first] : t[i] - tmin;
+            const double hi_ = staged ? s_h[i - w_first] : h[i];
+            const double h2i = !twin ? 0.0 : (staged ? s_h2[i - w_first] : h2[i]);
             const double ang = (6.283185307179586 * fming) * dt;
             double sn, cs;
             sincos(ang, &sn, &cs);
-            const double hre = h[i] * cs, him = h[i] * sn;
-            const double kre = twin ? h2[i] * cs : 0.0, kim = twin ? h2[i] * sn : 0.0;
+            const double hre = hi_ * cs, him = hi_ * sn;
+            const double kre = twin ? h2i * cs : 0.0, kim = twin ? h2i * sn : 0.0;
             if (whole) {   // one deposit
                 const int64_t ind = (int64_t)tn;
 #pragma unroll
