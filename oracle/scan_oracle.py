@@ -584,10 +584,15 @@ def supersmoother_scan(t, y, periods, alpha=0.0):
 # parameters, which are integrated out - by the two textbook routes that must agree: the dense one (y ~ N(0, Phi Sigma
 # Phi^T + N), scipy's multivariate normal: the third-party pin, small n only) and the 4 x 4 one (Woodbury + the matrix
 # determinant lemma) in 80-bit arithmetic for whole grids.  tau = (t - t_ref) / (t[-1] - t[0]).
-def bglst_design(t, frequency, t_ref):
+def bglst_design(t, frequency, t_ref, trig_origin=None):
+    """Columns (cos, sin, tau, 1).  The trigonometric pair is evaluated on ``t - trig_origin`` (default: the first
+    sample): with one prior width for A and B the marginal likelihood does not change under a rotation of that pair,
+    i.e. under a shift of its time origin (tests/test_bglst.py checks exactly this), and Julian-date stamps times a
+    high frequency would otherwise cost the 80-bit phase its last digits."""
     t = np.asarray(t, dtype=np.longdouble)
     span = t[-1] - t[0] if t[-1] != t[0] else np.longdouble(1)
-    arg = TWO_PI_L * np.longdouble(frequency) * t
+    origin = t[0] if trig_origin is None else np.longdouble(trig_origin)
+    arg = TWO_PI_L * np.longdouble(frequency) * (t - origin)
     return np.stack([np.cos(arg), np.sin(arg), (t - np.longdouble(t_ref)) / span, np.ones_like(t)], axis=1)
 
 

@@ -41,7 +41,16 @@ def test_oracle_properties_of_the_statistic():
     f = np.linspace(0.005, 0.5, 600)
     ll = so.bglst_loglik(t, y, err, f, 1.0, 1.0, 3.0, t_ref=60.0)
     assert abs(1 / f[np.argmax(ll)] - 6.3) < 0.1                       # the injected period, trend and all
-    # the trigonometric basis may be rotated (a shift of the time origin of cos / sin only): same likelihood
+    # the trigonometric basis may be rotated (a shift of the time origin of cos / sin only): same likelihood - the
+    # invariance the device kernel (sums over t - t[0]) and the oracle's own default origin rely on, shown with the
+    # DENSE form, which knows nothing of either
+    for x in (f[10], f[300], f[599]):
+        a = so.bglst_loglik_dense(t[:90], y[:90], err[:90], x, 1.0, 1.0, 3.0, 60.0)
+        phi0 = so.bglst_design(t[:90], x, 60.0, trig_origin=0.0).astype(float)
+        phi1 = so.bglst_design(t[:90], x, 60.0, trig_origin=17.25).astype(float)
+        cov = [p @ np.diag([1.0, 1.0, 1.0, 9.0]) @ p.T + np.diag(err[:90] ** 2) for p in (phi0, phi1)]
+        np.testing.assert_allclose(cov[0], cov[1], rtol=0, atol=1e-12)      # the covariance itself is the same matrix
+        assert abs(a - so.bglst_loglik(t[:90], y[:90], err[:90], [x], 1.0, 1.0, 3.0, 60.0)[0]) < 1e-8 * abs(a)
     shifted = so.bglst_loglik(t + 1000.0, y, err, f, 1.0, 1.0, 3.0, t_ref=1060.0)
     np.testing.assert_allclose(shifted, ll, rtol=0, atol=1e-7)
     # a tighter prior on the trend than the data's slope costs likelihood everywhere

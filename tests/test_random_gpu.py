@@ -419,3 +419,29 @@ def test_supersmoother_random_cases(seed=29):
         alpha = float(rng.choice([0.0, rng.uniform(0.1, 10.0)]))
         got = _cabi.supersmoother_scan(t, y, periods, alpha)
         np.testing.assert_allclose(got, so.supersmoother_scan(t, y, periods, alpha), rtol=1e-9, err_msg=f"n={n} even={even} alpha={alpha}")
+
+
+def test_bglst_random_cases(seed=31):
+    """BGLST (parity unpinned by the reference: the oracle is the published marginal likelihood, pinned to scipy's dense
+    Gaussian in tests/test_bglst.py): random sizes, grids, priors, reference times, offsets, with and without
+    uncertainties, through the C ABI."""
+    from periodicity_amd.spectral import BGLST
+    rng = np.random.default_rng(seed)
+    for case in range(40):
+        n = int(rng.choice([4, 5, 17, 100, 511, 1500, 6000]))
+        t, y, err = random_curve(rng, n)
+        t = t + float(rng.choice([0.0, -37.0, 2454900.5]))
+        y = y + rng.uniform(-3, 3) + rng.uniform(-0.05, 0.05) * (t - t[0])
+        with_err = bool(rng.integers(0, 2))
+        e = err if with_err else np.ones_like(y)
+        priors = tuple(float(v) for v in rng.uniform(0.2, 5.0, 3))
+        t_ref = float(rng.choice([t[0], t[-1], 0.5 * (t[0] + t[-1]), t[0] - 10.0]))
+        nf = int(rng.choice([1, 7, 256, 2048, 2049, 5000]))
+        span = max(t[-1] - t[0], 1e-3)
+        f0, delta = float(rng.uniform(0.05, 2.0)) / span, float(rng.uniform(0.02, 0.5)) / span
+        sc = BGLST._scalars(t, y, e, *priors, t_ref)
+        got = _cabi.bglst_scan(t, y, err if with_err else None, f0, delta, nf, sc)
+        pick = np.unique(np.concatenate([rng.integers(0, nf, min(nf, 12)), [0, nf - 1]]))
+        want = so.bglst_loglik(t, y, err if with_err else None, f0 + delta * pick, *priors, t_ref)
+        tol = 1e-9 * max(float(np.abs(want).max()), float(sc[0] * sc[1]))
+        assert np.max(np.abs(got[pick] - want)) <= tol, (case, n, nf, np.max(np.abs(got[pick] - want)), tol)

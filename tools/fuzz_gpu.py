@@ -14,7 +14,8 @@ CASES = [sweeps.test_gls_direct_random_cases, sweeps.test_gls_long_curves_on_sho
          sweeps.test_gls_batch_random_ragged,
          sweeps.test_gls_fft_random_cases, sweeps.test_pdm_random_cases, sweeps.test_binned_scans_random_cases,
          sweeps.test_stringlength_random_cases, sweeps.test_gls_shared_time_axis_random,
-         sweeps.test_supersmoother_random_cases, sweeps.test_streamed_samples_in_any_order_random]
+         sweeps.test_supersmoother_random_cases, sweeps.test_streamed_samples_in_any_order_random,
+         sweeps.test_bglst_random_cases]
 
 
 def main():
