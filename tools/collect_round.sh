@@ -16,4 +16,10 @@ SHAPES=2000x10000,4096x20000,10000x8192,50000x4096,74326x2048,200000x512,1000000
 python3 tools/peaks_timing.py > "$out/peaks_timing.txt" 2>&1
 # where a row of peaks_topk_kernel spends its time: stamps of all rows from a -DPDC_PK_DBG build (built here, removed again)
 (bash tools/ab_build.sh pkdbg "-DPDC_PK_DBG=1" peaks.hip && for a in "4 1" "4 0" "1 0"; do PDC_LIBRARY=periodicity_amd/libpdc_ab_pkdbg.so python3 tools/peaks_stamps.py $a; done; rm -f periodicity_amd/libpdc_ab_pkdbg.so) > "$out/peaks_stamps.txt" 2>&1
+# bench.py launched the way the driver launches --gpus N (one rank per GPU under torch.distributed.run), at one rank: over RCCL,
+# and with the injected communicator failure through the gloo fallback
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --force-dist --force-sharded-extras --steps 5 --warmup 2 > "$out/bench_dist1_rccl.json" 2> "$out/bench_dist1_rccl.err"
+PDC_FORCE_RCCL_FAIL=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29532 bench.py --gpus 1 --force-dist --force-sharded-extras --steps 5 --warmup 2 > "$out/bench_dist1_gloo_fallback.json" 2> "$out/bench_dist1_gloo_fallback.err"
+# a longer randomised parity run at these sources (bounded: ~12 minutes)
+(timeout 900 python3 tools/fuzz_gpu.py --seeds ${FUZZ_SEEDS:-24} --start 60000 2>&1 | tail -4; timeout 300 python3 tools/fuzz_peaks.py --cases 400 --seed 6 2>&1 | tail -2; timeout 300 python3 tools/fuzz_sl.py --cases 100 --seed 6 2>&1 | tail -2) > "$out/fuzz.txt" 2>&1
 cut -c1-160 "$out/bench_n1.json"
