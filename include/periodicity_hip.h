@@ -418,7 +418,8 @@ int pdc_stringlength_scan_multi(const double *t, const double *m, int64_t n,
  * double-precision updating formulas lose the windows' variances; the device follows the oracle there, not them.
  * Samples may come in any order, as for pdc_stringlength_scan (from 262 144 samples on they are ordered by time on the
  * device first).  The device form takes resident inputs and a workspace of pdc_supersmoother_work_bytes(n, n_periods)
- * bytes. */
+ * bytes; PDC_WORK_BUDGET_GB caps it as for pdc_stringlength_scan (smaller sub-batches and pools: the statistic agrees
+ * to 1e-12 - the tiles' segment count follows the sub-batch -, a budget nothing fits in is an error that names it). */
 int pdc_supersmoother_scan(const double *t, const double *y, int64_t n, const double *periods, int64_t n_periods,
                            double alpha, double *stat_out, int device);
 int pdc_supersmoother_scan_multi(const double *t, const double *y, int64_t n, const double *periods, int64_t n_periods,
