@@ -183,3 +183,42 @@ def gl_scan(t, periods, m, n_offsets=8):
     out = np.empty(p.size)
     lib().oracle_gl_scan(_p(t), C.c_int64(t.size), _p(p), C.c_int64(p.size), C.c_int(m), C.c_int(n_offsets), _p(out))
     return out
+
+
+def bglst_loglik_f64(t, y, err, frequency, sigma_A, sigma_alpha, sigma_beta, t_ref):
+    """``scan_oracle.bglst_loglik`` for whole BASELINE-size grids: the per-frequency sums from the double-precision
+    direct-sum checker (two calls of ``gls_sums_f64``: weights ``w y`` then ``w tau``; ``sum w cos^2`` and
+    ``sum w cos sin`` from its doubled-frequency sums), then the same 4 x 4 marginalisation, vectorised over the
+    frequencies in float64.  Trigonometric origin: the first sample, as the numpy oracle's default (the likelihood is
+    invariant under it).  PARITY UNPINNED BY THE REFERENCE (spectral.py:207-208 is an empty class)."""
+    t = _f(t)
+    y = _f(y)
+    err = np.ones_like(y) if err is None else _f(err)
+    f = _f(frequency)
+    span = t[-1] - t[0] if t[-1] != t[0] else 1.0
+    tau = (t - t_ref) / span
+    w = err ** -2.0
+    W = w.sum()
+    w = w / W
+    tt = t - t[0]
+    Yc_s = gls_sums_f64(tt, w * y, w, f)          # Sh, Ch of w y;  S, C of w;  S2, C2 of w at 2 f
+    Ys, Yc, S, Cc, S2, C2 = Yc_s
+    Ts, Tc = gls_sums_f64(tt, w * tau, w, f)[:2]
+    wsum = w.sum()
+    cc, ss, cs = 0.5 * (wsum + C2), 0.5 * (wsum - C2), 0.5 * S2
+    prec = np.array([sigma_A ** -2.0, sigma_A ** -2.0, sigma_alpha ** -2.0, sigma_beta ** -2.0])
+    m = np.empty((f.size, 4, 4))
+    m[:, 0, 0], m[:, 1, 1] = W * cc + prec[0], W * ss + prec[1]
+    m[:, 2, 2], m[:, 3, 3] = W * np.dot(w, tau * tau) + prec[2], W * wsum + prec[3]
+    m[:, 1, 0] = m[:, 0, 1] = W * cs
+    m[:, 2, 0] = m[:, 0, 2] = W * Tc
+    m[:, 2, 1] = m[:, 1, 2] = W * Ts
+    m[:, 3, 0] = m[:, 0, 3] = W * Cc
+    m[:, 3, 1] = m[:, 1, 3] = W * S
+    m[:, 3, 2] = m[:, 2, 3] = W * np.dot(w, tau)
+    b = np.stack([W * Yc, W * Ys, np.full(f.size, W * np.dot(w, tau * y)), np.full(f.size, W * np.dot(w, y))], axis=1)
+    chol = np.linalg.cholesky(m)
+    z = np.linalg.solve(chol, b[:, :, None])[:, :, 0]
+    logdet = 2.0 * np.log(np.diagonal(chol, axis1=1, axis2=2)).sum(axis=1)
+    const = np.sum(np.log(2 * np.pi * err ** 2)) + 4 * np.log(sigma_A) + 2 * np.log(sigma_alpha) + 2 * np.log(sigma_beta)
+    return -0.5 * (W * np.dot(w, y * y) - np.sum(z * z, axis=1) + logdet + const)

@@ -8,6 +8,7 @@ import inspect
 import numpy as np
 import pytest
 
+from oracle import c_oracle as co
 from oracle import scan_oracle as so
 from periodicity_amd import _cabi
 from periodicity_amd.core import FSeries, TSeries
@@ -34,6 +35,22 @@ def test_oracle_equals_the_dense_gaussian_marginal(priors, t_ref, with_err):
     got = so.bglst_loglik(t, y, err if with_err else None, f, *priors, t_ref)
     want = np.array([so.bglst_loglik_dense(t, y, err, x, *priors, t_ref) for x in f])
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-8 * np.abs(want).max())
+
+
+def test_double_precision_checker_is_pinned_to_the_80_bit_oracle():
+    """`co.bglst_loglik_f64` (the C direct-sum checker's sums, float64 marginalisation) is what the GPU suite checks
+    all 1e6 bins of the C2-shaped run with: here against the 80-bit oracle, Julian-date stamps, with and without
+    uncertainties, and - one frequency - against scipy's dense Gaussian."""
+    t, y, err = curve(3000, 5, t_offset=2454900.5, baseline=300.0)
+    f = 0.003 + 0.0007 * np.arange(400)
+    for e in (err, None):
+        fast = co.bglst_loglik_f64(t, y, e, f, 0.8, 1.5, 4.0, t[0] + 100.0)
+        want = so.bglst_loglik(t, y, e, f[::20], 0.8, 1.5, 4.0, t[0] + 100.0)
+        scale = max(float(np.abs(want).max()), float(np.sum((y / (err if e is not None else 1.0)) ** 2)))
+        assert np.max(np.abs(fast[::20] - want)) <= 1e-12 * scale
+    small = slice(0, 80)
+    dense = so.bglst_loglik_dense(t[small], y[small], err[small], f[37], 0.8, 1.5, 4.0, t[0] + 10.0)
+    assert abs(co.bglst_loglik_f64(t[small], y[small], err[small], f[37:38], 0.8, 1.5, 4.0, t[0] + 10.0)[0] - dense) <= 1e-8 * abs(dense)
 
 
 def test_oracle_properties_of_the_statistic():
@@ -125,9 +142,9 @@ def test_class_call_finds_the_period_under_a_trend_and_posterior_mean():
 
 
 @pytest.mark.gpu
-def test_full_size_c2_shape_runs_and_agrees_on_a_sample():
-    """BASELINE configs[1]'s shape (N = 1e5 x nf = 1e6) through the trend kernel: a stratified sample of bins against
-    the oracle and the peak at the injected period."""
+def test_full_size_c2_shape_every_bin():
+    """BASELINE configs[1]'s shape (N = 1e5 x nf = 1e6) through the trend kernel: a sample of bins against the 80-bit
+    oracle, EVERY bin against the double-precision one, the peak at the injected period."""
     n, nf = 100_000, 1_000_000
     rng = np.random.default_rng(20241010)
     t = np.sort(rng.uniform(0, float(n), n))
@@ -144,3 +161,11 @@ def test_full_size_c2_shape_runs_and_agrees_on_a_sample():
     pick = np.unique(np.concatenate([rng.integers(0, nf, 40), [0, nf - 1, peak, 2047, 2048]]))
     want = so.bglst_loglik(t, y, err, f0 + df * pick, 1.0, 1.0, 2.0, t_ref)
     assert_close(got[pick], want, sc[0] * sc[1])
+    # EVERY bin: the double-precision checker (the direct-sum C oracle's sums + the same marginalisation in numpy),
+    # first re-proved on the sampled bins against the 80-bit oracle, then trusted on all 1e6
+    co.tune_threads()
+    fast = co.bglst_loglik_f64(t, y, err, f0 + df * pick, 1.0, 1.0, 2.0, t_ref)
+    assert np.max(np.abs(fast - want)) <= 1e-11 * max(float(np.abs(want).max()), sc[0] * sc[1])
+    full = co.bglst_loglik_f64(t, y, err, f0 + df * np.arange(nf), 1.0, 1.0, 2.0, t_ref)
+    assert_close(got, full, sc[0] * sc[1])
+    assert int(np.argmax(full)) == peak
