@@ -355,6 +355,9 @@ __global__ __launch_bounds__(kPkBlock, SORT ? PDC_PK_WAVES : PDC_PK_WAVES + 1) v
                 if (cp[e] == cp[e]) continue;
                 const double v = ch[e];
                 const int at = ci[e];
+                // (round 6: both walks in lockstep - the loads of the left and the right step requested together - measured
+                // 6.61 against 6.68 ms for k = 256 by prominence: the walks are bound by how many are in flight, not by a
+                // candidate's own chain of latencies; withdrawn)
                 const double lo = walk(at, -1, v), hi = walk(at, +1, v);
                 if (gl == 0) cp[e] = v - (lo > hi ? lo : hi);
             }
@@ -829,6 +832,60 @@ __global__ __launch_bounds__(kPkBlock, SORT ? PDC_PK_WAVES : PDC_PK_WAVES + 1) v
     // outwards from the peak, four loads per lane in flight, the nearest sign change by ballot.
     PK_STAMP(8)
     if (!a.half_lo && !a.half_hi) return;
+    if (SORT && a.k > 16) {
+        // Many ranked peaks (round 6): a QUARTER wave per peak, four peaks per wave side by side, 64 bins per step.  The
+        // crossings of a periodogram's peaks lie a few bins from the maximum, and one wave per peak spent a 256-bin step
+        // each way on every one of them, 32 peaks per wave one after the other: 136 us of a row's 835 in a 128-rank
+        // launch (profiles/r06_peaks_stamps.txt).  Same searches, same answers.
+        const int sub = lane & 15, grp = lane >> 4;
+        for (int r0 = wave * 4; r0 < a.k; r0 += (kPkBlock / 64) * 4) {
+            const int r = r0 + grp;
+            const long long idmax = (r < a.k && r < nwin) ? win_idx[r] : -1;
+            long long lo_abs = -1, hi_abs = -1;
+            const double half = idmax >= 0 ? x[idmax] - win_key[r] / 2 : 0.0;     // core.py:972 (height or prominence)
+            auto flips = [&](int64_t i) {                       // signbit(x[i]-half) != signbit(x[i+1]-half)
+                return (__double_as_longlong(x[i] - half) < 0) != (__double_as_longlong(x[i + 1] - half) < 0);
+            };
+            // last sign change inside x[:idmax], nearest to the peak first
+            for (int64_t top = idmax - 2;; top -= 64) {
+                const bool go = idmax >= 0 && hi_abs < 0 && top >= 0;
+                if (!__any(go)) break;                          // (wave-uniform)
+                bool f[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = top - (16 * u + sub);
+                    f[u] = go && i >= 0 && flips(i);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned mine = (unsigned)(__ballot(f[u]) >> (16 * grp)) & 0xFFFFu;
+                    if (mine && hi_abs < 0) hi_abs = top - (16 * u + __builtin_ctz(mine));
+                }
+            }
+            // first sign change from the peak rightwards
+            for (int64_t base = idmax;; base += 64) {
+                const bool go = idmax >= 0 && lo_abs < 0 && base < nf - 1;
+                if (!__any(go)) break;                          // (wave-uniform)
+                bool f[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = base + 16 * u + sub;
+                    f[u] = go && i < nf - 1 && flips(i);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned mine = (unsigned)(__ballot(f[u]) >> (16 * grp)) & 0xFFFFu;
+                    if (mine && lo_abs < 0) lo_abs = base + 16 * u + __builtin_ctz(mine);
+                }
+            }
+            if (sub == 0 && r < a.k) {
+                if (a.half_lo) a.half_lo[ob + r] = lo_abs;
+                if (a.half_hi) a.half_hi[ob + r] = hi_abs;
+            }
+        }
+        PK_STAMP(9)
+        return;
+    }
     for (int r = wave; r < a.k; r += kPkBlock / 64) {
         const long long idmax = r < nwin ? win_idx[r] : -1;
         long long lo_abs = -1, hi_abs = -1;
