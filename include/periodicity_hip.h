@@ -270,7 +270,7 @@ int pdc_gls_batch_highest_peak(const double *t, const double *y, const double *d
  * (period[half_lo], period[half_hi]).  Exactly equal keys rank the lower bin first (upstream's argsort()[::-1]
  * leaves ties to numpy's unstable sort: see INTEGRATION.md).
  * k > 128 runs as launches of 128 ranks (round 5: 64), each ranking what comes AFTER the launch before's last winner in that total
- * order (every launch sweeps the spectra again; measured for 4096 spectra of 5e4 bins: ~1.2 ms per 64 ranks by height, ~2 ms for the first 64 by prominence and ~3 ms for every further 64 - profiles/r06_peaks_timing.txt); it needs idx_out
+ * order (every launch sweeps the spectra again; measured for 4096 spectra of 5e4 bins: 64 / 128 / 256 ranks 1.1 / 1.5 / 3.0 ms by height, 1.8 / 2.7 / 6.7 ms by prominence - profiles/r06_peaks_timing.txt); it needs idx_out
  * and the ranking key's output (height_out, or prominence_out).  The host methods of FSeries serve any k.
  * pdc_gls_batch_peaks runs the batched periodogram first; the spectra never leave HBM. */
 int pdc_peaks_topk(const double *power, int64_t n_curves, int64_t nf, int k, int by_prominence,
