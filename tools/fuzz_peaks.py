@@ -66,7 +66,9 @@ def one_case(rng):
     n = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 1000, 1023, 1024, 1025, 2048, 4097, 10_000, 50_000,
                         262_145, 1_100_000],
                        p=[.02, .02, .02, .03, .03, .03, .03, .04, .04, .04, .17, .05, .05, .05, .05, .09, .12, .09, .02, .01]))
-    k = int(rng.integers(1, 17))
+    # (round 6: ranks beyond 16 and beyond one launch of 128 too - the SORT instance's rankings, the quarter-wave
+    # half-maximum searches, the seams between launches)
+    k = int([rng.integers(1, 17), rng.integers(1, 17), rng.integers(17, 129), rng.integers(129, 400)][int(rng.integers(0, 4))])
     by_prominence = bool(rng.integers(0, 2))
     rows = int(rng.choice([1, 1, 3])) if n <= 50_000 else 1
     x = np.stack([make_row(rng, n) for _ in range(rows)])
