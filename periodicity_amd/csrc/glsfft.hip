@@ -159,7 +159,12 @@ __global__ __launch_bounds__(256) void fft_pass_lds_kernel(const cplx *__restric
                                                             int64_t Ns, int64_t keep, LiveArgs lv) {
     constexpr int R = 16 * RB;
     constexpr int JT = 256 / RB;          // butterflies per workgroup
-    constexpr int ROW = R + 16;           // padded LDS row per butterfly
+    // Padded LDS row per butterfly: ONE complex number (16 B) of padding.  Round 6: it was R + 16 - 256 B, a whole number
+    // of LDS bank rows (32 banks x 4 B), i.e. no skew at all: in stage A every lane of a store instruction (fixed s2)
+    // hit the same four banks, a 64-way serialisation, and stage B's loads spread over half of them; the PMC counters
+    // had it (SQ_LDS_BANK_CONFLICT 9.2e6 of 11.3e6 LDS-active cycles per pass, 18 us of a pass's 45 inside LDS).  With
+    // R + 1 the 16-byte slot of (jj, r1, s2) is (jj + s2) mod 8: eight lanes per slot, the minimum for 64 x 16 B.
+    constexpr int ROW = R + 1;
     __shared__ cplx tile[JT * ROW];       // [jj][r1][s2]
     __shared__ cplx wR[R];
     const int tid = threadIdx.x;
@@ -429,14 +434,19 @@ struct DepositArgs {
 };
 
 constexpr int kDepCells = 4;                     // cells per thread
-constexpr int kDepIters = 4;                     // groups of cells per thread: the workgroup's search is shared
+#ifndef PDC_DEP_ITERS
+#define PDC_DEP_ITERS 4
+#endif
+constexpr int kDepIters = PDC_DEP_ITERS;         // groups of cells per thread: the workgroup's search is shared
 constexpr int kDepSpan = kDepCells * kBlock * kDepIters;   // cells per workgroup
-constexpr int kDepStage = 1024;                  // positions of a workgroup's samples kept in LDS
+constexpr int kDepStage = 768;                   // samples of a workgroup's range kept in LDS: position, pre-rotation, weights
 
 __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
     __shared__ double s_pos[kDepStage];
-    __shared__ double s_dt[kDepStage], s_h[kDepStage], s_h2[kDepStage];   // round 6: the samples themselves too (the deposit loop
-                                                                          // waited for three dependent global loads per sample)
+    // round 6: the samples themselves too, with their pre-rotation exp(2 pi i fmin (t - tmin)) evaluated ONCE, by the thread
+    // that stages them (the deposit loop waited for three dependent global loads per sample and ran a sincos for every
+    // (sample, group of cells) visit: 30 us of VALU issue in a 73-us launch)
+    __shared__ double s_cs[kDepStage], s_sn[kDepStage], s_h[kDepStage], s_h2[kDepStage];
     __shared__ unsigned long long s_ballot[2][kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t curve = blockIdx.y / a.nslots;
@@ -503,7 +513,10 @@ __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
         if (staged)
             for (int64_t i = w_first + tid; i < w_last; i += kBlock) {
                 s_pos[i - w_first] = position(i);
-                s_dt[i - w_first] = t[i] - tmin;
+                double sn0, cs0;
+                sincos((6.283185307179586 * fming) * (t[i] - tmin), &sn0, &cs0);
+                s_cs[i - w_first] = cs0;
+                s_sn[i - w_first] = sn0;
                 s_h[i - w_first] = h[i];
                 s_h2[i - w_first] = twin ? h2[i] : 0.0;
             }
@@ -535,12 +548,15 @@ __global__ __launch_bounds__(kBlock) void glsfft_deposit_kernel(DepositArgs a) {
             } else if ((int64_t)tn < g0 || (int64_t)tn >= g0 + kDepCells) {
                 continue;
             }
-            const double dt = staged ? s_dt[i - w_first] : t[i] - tmin;
             const double hi_ = staged ? s_h[i - w_first] : h[i];
             const double h2i = !twin ? 0.0 : (staged ? s_h2[i - w_first] : h2[i]);
-            const double ang = (6.283185307179586 * fming) * dt;
             double sn, cs;
-            sincos(ang, &sn, &cs);
+            if (staged) {
+                sn = s_sn[i - w_first];
+                cs = s_cs[i - w_first];
+            } else {
+                sincos((6.283185307179586 * fming) * (t[i] - tmin), &sn, &cs);
+            }
             const double hre = hi_ * cs, him = hi_ * sn;
             const double kre = twin ? h2i * cs : 0.0, kim = twin ? h2i * sn : 0.0;
             if (whole) {   // one deposit
