@@ -74,3 +74,30 @@ def test_integration_md_binding_snippet_runs_against_the_built_library(built, mo
     else:
         for call in calls:
             assert np.all(np.isfinite(call()))
+
+
+def test_workspace_budget_scales_the_size_functions_without_a_gpu(built, monkeypatch):
+    """PDC_WORK_BUDGET_GB (round 6) is read by the size functions themselves - no device involved -, so the rule can be
+    checked here: the built-in caps ask for tens of GB at a million samples, a budget holds the answer under itself,
+    a smaller budget gives a smaller workspace, and without the variable the old sizes come back."""
+    lib = _cabi.lib()
+    n, n_per = 1_000_000, 2048
+    monkeypatch.delenv("PDC_WORK_BUDGET_GB", raising=False)
+    free_sl, free_ss = lib.pdc_stringlength_work_bytes(n, n_per), lib.pdc_supersmoother_work_bytes(n, n_per)
+    assert free_sl > 8 << 30 and free_ss > 2 << 30
+    sizes = {}
+    for gb in ("8", "4", "2"):
+        monkeypatch.setenv("PDC_WORK_BUDGET_GB", gb)
+        sizes[gb] = (lib.pdc_stringlength_work_bytes(n, n_per), lib.pdc_supersmoother_work_bytes(n, n_per),
+                     lib.pdc_phase_work_bytes(3, n, n_per, 0, 0))
+        assert max(sizes[gb]) <= int(gb) << 30, (gb, sizes[gb])
+        assert sizes[gb][2] == sizes[gb][0]                  # the generic entry asks the same function
+    assert sizes["2"][0] < sizes["4"][0] < sizes["8"][0] < free_sl
+    assert sizes["2"][1] < free_ss
+    # a curve that needs little is not touched by a budget it fits in
+    monkeypatch.delenv("PDC_WORK_BUDGET_GB")
+    small = lib.pdc_stringlength_work_bytes(5000, 100)
+    monkeypatch.setenv("PDC_WORK_BUDGET_GB", "4")
+    assert lib.pdc_stringlength_work_bytes(5000, 100) == small
+    monkeypatch.delenv("PDC_WORK_BUDGET_GB")
+    assert lib.pdc_stringlength_work_bytes(n, n_per) == free_sl
